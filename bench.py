@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- train rays/s of the stage-1 state-conditional mip-NeRF-360 step on MI355X.
+
+Workload = BASELINE.json configs[1]: "Stage-1 background mip-NeRF-360 Backpack, 1024 rays/batch,
+1xMI355X" restated on synthetic rays: 1024 rays per GPU, 64/64/32 samples,
+2x PropMLP 4x256 + NeRFMLP 8x1024 (9.50 M params), reference-style random init, fp32.
+One "step" = forward (3 levels) + Charbonnier/interlevel/distortion losses + backward + gradient
+all-reduce (N>1) + norm clipping (0.001) + Adam -- nothing skipped, inputs resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU; rays are independent, so each rank renders its own 1024 rays
+(weak scaling, like the reference's 4096 rays over 4 GPUs) and the only exchange is ONE RCCL
+all-reduce of the flat 38 MB gradient per step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+S1_TRAIN_FLOP_PER_RAY = 1841e6     # 2*(128*881408 + 32*25242496)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def basedir():
+    d = tempfile.mkdtemp(prefix="hos_bench_")
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({"f0": {"time": 0.4}}, f)
+    return d
+
+
+def cpu_baseline(num_rays: int):
+    """The oracle (torch CPU fp32 restatement of the reference op graph, autograd backward, torch Adam)
+    timed on the host cores on a bounded sample of the same workload."""
+    import oracle.background as ob
+    from hosnerf_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.background_state_dict(777, 2).items()}
+    params = list(sd.values())
+    opt = torch.optim.Adam(params, lr=2e-3)
+    batch = synth.stage1_batch(num_rays, seed=777)
+
+    def step():
+        opt.zero_grad()
+        rend, hist = ob.mipnerf360_forward(sd, batch, 0.5, True, 0.1, 1e6, transitions_times=[0.4])
+        loss, _ = ob.stage1_loss(rend[-1]["rgb"], batch["target"], hist)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.001)
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        if time.perf_counter() - t0 > 12.0 or n >= 8:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": num_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed step(s) of {num_rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); use tests -m 'not gpu' on CPU")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from hosnerf_amd import ops, synth
+    from hosnerf_amd.mipnerf360 import MipNeRF360
+    from hosnerf_amd.train import FusedAdam, stage1_loss, stage1_lr
+
+    model = MipNeRF360(basedir(), opaque_background=True)
+    model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
+    model = model.to(dev)
+    opt = FusedAdam(model, lr=2e-3, max_grad_norm=0.001)
+    batch = {k: v.to(dev) for k, v in synth.stage1_batch(args.rays, seed=777 + rank).items()}
+    max_steps = 500000
+
+    def step(i):
+        opt.zero_grad()
+        rend, hist = model(batch, i / max_steps, True, True, 0.1, 1e6)
+        loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
+        loss.backward()
+        opt.step(stage1_lr(i, max_steps))
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    prof = None
+    if rank == 0 and not args.no_kernel_events:
+        prof = ops.KernelEvents()
+        ops.set_kernel_events(prof)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_events(None)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    final_loss = float(loss)
+
+    if rank == 0:
+        rays_total = args.rays * world * args.steps
+        out = {
+            "metric": "train rays/sec (stage-1 state-conditional mip-NeRF-360, fwd+loss+bwd+clip+Adam)",
+            "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
+            "config": {"workload": "BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, "
+                                   "64/64/32 samples, PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states",
+                       "rays_per_gpu": args.rays, "global_rays": args.rays * world, "parallelism": f"dp{world} (ray shards, 1 flat-gradient all-reduce/step)"},
+            "final_loss": final_loss,
+            "algorithmic_tflops": rays_total * S1_TRAIN_FLOP_PER_RAY / dt / 1e12,
+        }
+        if prof is not None:
+            table = prof.summary()
+            dom = max(table, key=lambda r: r["total_ms"]) if table else None
+            if dom is not None:
+                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
+                                   "flop_per_launch": dom["flop_per_launch"]}
+            out["kernels"] = table
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""ctypes binding of libhosrender.so (the C ABI declared in include/hosrender.h).
+
+There is deliberately no fallback: if the shared library has not been built, or a tensor handed
+to an op is not a contiguous fp32 HIP tensor, this module raises.  The product path never
+routes through oracle/ or any CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhosrender.so")
+
+
+class HosLibraryError(RuntimeError):
+    pass
+
+
+_P, _I, _F, _L = c_void_p, c_int, c_float, c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/hosrender.h one to one
+PROTOTYPES = {
+    "hos_version": [],
+    "hos_device_count": [],
+    "hos_error_string": [_I],
+    "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P],
+    "hos_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],
+    "hos_encode_ipe": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
+    "hos_encode_viewdirs": [_P, _I, _I, _P, _I, _I, _P],
+    "hos_alpha_weights_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "hos_alpha_weights_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "hos_volrender_fwd": [_P, _P, _I, _I, _F, _P, _P],
+    "hos_volrender_bwd": [_P, _P, _P, _I, _I, _F, _P, _P, _P],
+    "hos_interlevel_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "hos_interlevel_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P],
+    "hos_distortion_fwd": [_P, _P, _I, _I, _P, _P],
+    "hos_distortion_bwd": [_P, _P, _I, _I, _F, _P, _P],
+    "hos_head_grad": [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P, _I, _P],
+    "hos_sumsq": [_P, _L, _P, _P],
+    "hos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _F, _P],
+}
+_RESTYPES = {"hos_error_string": c_char_p}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise HosLibraryError with a build hint if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HosLibraryError(
+            f"{LIB_PATH} not found: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "hosnerf_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HosLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HosLibraryError(f"{LIB_PATH} does not export {name}; rebuild the library") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().hos_error_string(int(code))
+        raise HosLibraryError(f"{what} failed with code {code}: {msg.decode() if msg else '?'}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HosLibraryError("no HIP device visible: hosnerf_amd ops run on MI355X only (no CPU fallback)")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, dtype=torch.float32) -> int:
+    """Device pointer of a contiguous HIP tensor of the expected dtype (None -> NULL)."""
+    if t is None:
+        return 0
+    if not isinstance(t, torch.Tensor):
+        raise HosLibraryError(f"expected a tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise HosLibraryError("hosnerf_amd ops take HIP (device='cuda') tensors only -- there is no CPU path")
+    if t.dtype != dtype:
+        raise HosLibraryError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HosLibraryError("expected a contiguous tensor")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke an entry point on the current stream (appended as the last argument) and check it."""
+    lib = load()
+    code = getattr(lib, name)(*args, stream_ptr())
+    check(code, name)

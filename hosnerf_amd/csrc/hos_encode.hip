@@ -1,0 +1,185 @@
+// Sample-point encoders for the background branch.
+//
+// hos_encode_ipe: conical-frustum moments (H:294-304) -> full-covariance lift (H:318-339) ->
+// scene contraction with closed-form Jacobian (H:33-68; SURVEY 7.1: equals functorch.jacrev to
+// 1.5e-8) -> projection on the 21-direction icosahedron basis (H:71-74) -> integrated positional
+// encoding (H:78-89) -> [IPE(504) | state embedding(64) | 0-pad] rows ready for the layer-0 GEMM.
+// In the reference this is ~40 torch launches with [B,S,3,3] / [B,S,12,21] temporaries and a
+// vmap(jacrev) autograd pass (13.5 % + 18 % of its forward time).
+//
+// HBM-bound on the write of X: algorithmic bytes/sample = 4*ldx written + 4 read (tdist).
+// Built with -ffp-contract=off: sin(x*2^l + pi/2) must round the sum in fp32 exactly like the
+// reference does (for 2^11*x ~ 4096 the fp32 ulp is 4.9e-4 -- a fused or cosf() variant differs
+// from the reference by up to 2.4e-4, more than the whole parity budget).
+#include "hos_common.h"
+
+namespace {
+
+constexpr int NDIR = 21;
+constexpr int NLVL = 12;
+constexpr int NIPE = 2 * NDIR * NLVL;   // 504
+constexpr int NEMB = 64;
+constexpr int SB = 64;                  // samples per workgroup
+constexpr float EPS = 1.1920929e-07f;
+constexpr float HALF_PI = 1.57079637050628662109375f;   // float32(0.5*pi)
+
+__global__ __launch_bounds__(256) void encode_ipe_kernel(
+    const float* __restrict__ tdist, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ radii, const float* __restrict__ basis, const float* __restrict__ embed,
+    int B, int S, float* __restrict__ X, int ldx) {
+    __shared__ float s_mean[SB][3];
+    __shared__ float s_cov[SB][9];
+    __shared__ float s_lm[SB][NDIR];
+    __shared__ float s_lv[SB][NDIR];
+    __shared__ float s_basis[3][NDIR];
+    __shared__ float s_embed[NEMB];
+
+    const int t = threadIdx.x;
+    const long P = (long)B * S;
+    const long p0 = (long)blockIdx.x * SB;
+    if (t < 3 * NDIR) s_basis[t / NDIR][t % NDIR] = basis[t];
+    if (t >= 64 && t < 64 + NEMB) s_embed[t - 64] = embed[t - 64];
+
+    if (t < SB && p0 + t < P) {
+        const long p = p0 + t;
+        const int ray = (int)(p / S), s = (int)(p % S);
+        const float t0 = tdist[(size_t)ray * (S + 1) + s], t1 = tdist[(size_t)ray * (S + 1) + s + 1];
+        const float ox = rays_o[ray * 3 + 0], oy = rays_o[ray * 3 + 1], oz = rays_o[ray * 3 + 2];
+        const float d[3] = {rays_d[ray * 3 + 0], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+        const float rad = radii[ray];
+        // H:296-302
+        const float mu = (t0 + t1) / 2.f, hw = (t1 - t0) / 2.f;
+        const float mu2 = mu * mu, hw2 = hw * hw, hw4 = hw2 * hw2;
+        const float denom = fmaxf(3.f * mu2 + hw2, EPS);
+        const float t_mean = mu + (2.f * mu * hw2) / denom;
+        const float t_var = hw2 / 3.f - (4.f / 15.f) * hw4 * (12.f * mu2 - hw2) / (denom * denom);
+        float r_var = mu2 / 4.f + (5.f / 12.f) * hw2 - (4.f / 15.f) * hw4 / denom;
+        r_var *= rad * rad;
+        // H:320-338 (diag=False)
+        const float dmag = fmaxf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2], 1e-10f);
+        float x[3] = {d[0] * t_mean + ox, d[1] * t_mean + oy, d[2] * t_mean + oz};
+        float cov[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float outer = d[a] * d[c];
+                const float nul = (a == c ? 1.f : 0.f) - d[a] * (d[c] / dmag);
+                cov[a][c] = t_var * outer + r_var * nul;
+            }
+        // H:37-42 contraction and its Jacobian
+        const float r2 = fmaxf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2], 1e-32f);
+        float J[3][3];
+        float z[3];
+        if (r2 <= 1.f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                z[a] = x[a];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) J[a][c] = (a == c) ? 1.f : 0.f;
+            }
+        } else {
+            const float r = sqrtf(r2);
+            const float sc = (2.f * r - 1.f) / r2;
+            const float cc = (2.f / (r2 * r) - 2.f / r2) / r;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                z[a] = sc * x[a];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) J[a][c] = (a == c ? sc : 0.f) + cc * (x[a] * x[c]);
+            }
+        }
+        float JC[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) JC[a][c] = J[a][0] * cov[0][c] + J[a][1] * cov[1][c] + J[a][2] * cov[2][c];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            s_mean[t][a] = z[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)   // (J cov) J^T
+                s_cov[t][a * 3 + c] = JC[a][0] * J[c][0] + JC[a][1] * J[c][1] + JC[a][2] * J[c][2];
+        }
+    }
+    __syncthreads();
+    // lift: mean . b_j  and  b_j^T cov b_j   (H:71-74)
+    for (int it = t; it < SB * NDIR; it += 256) {
+        const int s = it / NDIR, j = it % NDIR;
+        const float b0 = s_basis[0][j], b1 = s_basis[1][j], b2 = s_basis[2][j];
+        s_lm[s][j] = s_mean[s][0] * b0 + s_mean[s][1] * b1 + s_mean[s][2] * b2;
+        const float* c = s_cov[s];
+        const float c0 = c[0] * b0 + c[1] * b1 + c[2] * b2;
+        const float c1 = c[3] * b0 + c[4] * b1 + c[5] * b2;
+        const float c2 = c[6] * b0 + c[7] * b1 + c[8] * b2;
+        s_lv[s][j] = b0 * c0 + b1 * c1 + b2 * c2;
+    }
+    __syncthreads();
+    // IPE features (H:78-89, H:104-105): col = level*21 + dir ; second half = +pi/2
+    constexpr int HALF = NDIR * NLVL;   // 252
+    for (int it = t; it < SB * HALF; it += 256) {
+        const int s = it / HALF, c = it % HALF;
+        if (p0 + s >= P) break;
+        const int lvl = c / NDIR, j = c % NDIR;
+        const float sc = (float)(1 << lvl);
+        const float sm = s_lm[s][j] * sc;
+        const float sv = s_lv[s][j] * (sc * sc);
+        const float damp = expf(-0.5f * sv);
+        float* row = X + (size_t)(p0 + s) * ldx;
+        row[c] = damp * sinf(sm);
+        row[c + HALF] = damp * sinf(sm + HALF_PI);
+    }
+    const int tail = ldx - NIPE;   // embedding + zero pad
+    for (int it = t; it < SB * tail; it += 256) {
+        const int s = it / tail, c = it % tail;
+        if (p0 + s >= P) break;
+        X[(size_t)(p0 + s) * ldx + NIPE + c] = (c < NEMB) ? s_embed[c] : 0.f;
+    }
+}
+
+// pos_enc(viewdirs, 0, 4, append_identity=True) (H:93-100) broadcast over the S samples of a ray.
+__global__ __launch_bounds__(256) void encode_viewdirs_kernel(const float* __restrict__ viewdirs, int B, int S,
+                                                              float* __restrict__ Xv, int ldx, int col0) {
+    const int width = ldx - col0;   // 27 features + zero pad
+    const long total = (long)B * S * width;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / width;
+        const int c = (int)(it % width);
+        const int ray = (int)(p / S);
+        float v = 0.f;
+        if (c < 3) {
+            v = viewdirs[ray * 3 + c];
+        } else if (c < 27) {
+            const int k = (c - 3) % 12, half = (c - 3) / 12;
+            const int lvl = k / 3, ax = k % 3;
+            const float xb = viewdirs[ray * 3 + ax] * (float)(1 << lvl);
+            v = half ? sinf(xb + HALF_PI) : sinf(xb);
+        }
+        Xv[(size_t)p * ldx + col0 + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int hos_encode_ipe(const float* tdist, const float* rays_o, const float* rays_d, const float* radii,
+                              const float* basis, const float* embed, int B, int S, float* X, int ldx,
+                              hos_stream_t stream) {
+    if (!tdist || !rays_o || !rays_d || !radii || !basis || !embed || !X || B <= 0 || S <= 0) return HOS_E_ARG;
+    if (ldx < NIPE + NEMB) return HOS_E_SHAPE;
+    const long P = (long)B * S;
+    hipLaunchKernelGGL(encode_ipe_kernel, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tdist, rays_o, rays_d, radii, basis, embed, B, S, X, ldx);
+    return hos_launch_status();
+}
+
+extern "C" int hos_encode_viewdirs(const float* viewdirs, int B, int S, float* Xv, int ldx, int col0,
+                                   hos_stream_t stream) {
+    if (!viewdirs || !Xv || B <= 0 || S <= 0) return HOS_E_ARG;
+    if (ldx - col0 < 27 || col0 < 0) return HOS_E_SHAPE;
+    const long total = (long)B * S * (ldx - col0);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(encode_viewdirs_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       viewdirs, B, S, Xv, ldx, col0);
+    return hos_launch_status();
+}

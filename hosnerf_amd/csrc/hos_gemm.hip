@@ -1,0 +1,348 @@
+// Dense MLP contractions on the CDNA4 matrix cores, exact fp32 (v_mfma_f32_32x32x2_f32).
+//
+// One tile kernel, three operand-layout instantiations:
+//   FWD   C[m,n]  = epi(sum_k A[m,k] W[n,k] + b[n])     A,W k-contiguous  -> LDS-transposed staging
+//   DGRAD dX[m,k] = (sum_n dY[m,n] W[n,k]) * relu'(X)   dY k(=n)-contiguous, W row = reduction index
+//   WGRAD dW[n,k] += sum_m dY[m,n] X[m,k]               both operands: reduction index = row
+//
+// Workgroup = 256 threads = 4 wave64.  Tile BM x BN x 32; LDS holds both operand tiles as
+// [k][i] (reduction-major) so an MFMA fragment read (lane -> i = lane&31, k = lane>>5) is a
+// conflict-free ds_read_b32 of 32 consecutive floats.  Register-staged global->LDS double buffer,
+// one barrier per K tile.  Every reduction dimension is a multiple of 32 by construction (the
+// host pads activations / weights), so there is no K-tail path.
+//
+// Numerics: v_mfma_f32_32x32x2_f32 is bitwise an fp32 fmaf chain in k order (MI355X guide), i.e.
+// the same class as the reference's fp32 addmm; SURVEY 7.1 shows bf16/TF32 inputs break the 1e-4
+// RGB budget, so this path is the parity-safe one.
+#include "hos_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+enum Mode { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
+
+struct GemmArgs {
+    const float* A0; int lda0; int kt0;   // A segment 0, number of K tiles in it
+    const float* A1; int lda1;            // optional A segment 1 (fwd skip-concat)
+    const float* B;  int ldb;
+    float* C; int ldc;
+    int M, N;                // store extents (rows i, cols j)
+    int Mload, Nload;        // operand extents (may include zero padding)
+    int nk;                  // K tiles in total
+    int kt_per_split;
+    int tiles_m, tiles_n;
+    const float* bias;
+    const float* mask; int ldmask;
+    float* aux; int aux_col; float p0, p1;
+    float* db;
+    int accumulate;
+    int epi;
+};
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- global -> register staging -------------------------------------------------------------
+// K-contiguous operand P[i][k]: tile rows i0.., 32 floats of k.  thread -> (k4 = t&7, i = t>>3 + 32r)
+template <int BMN>
+__device__ __forceinline__ void load_kc(float4 (&v)[BMN / 32], const float* __restrict__ P, int ld,
+                                        int i0, int limit, int k0, int t) {
+    const int k4 = t & 7, ir = t >> 3;
+#pragma unroll
+    for (int r = 0; r < BMN / 32; ++r) {
+        const int gi = i0 + ir + 32 * r;
+        v[r] = gi < limit ? ldg4(P + (size_t)gi * ld + k0 + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int BMN, int LD>
+__device__ __forceinline__ void store_kc(const float4 (&v)[BMN / 32], float* __restrict__ S, int t) {
+    const int k4 = t & 7, ir = t >> 3;
+#pragma unroll
+    for (int r = 0; r < BMN / 32; ++r) {
+        const int i = ir + 32 * r;
+        S[(k4 * 4 + 0) * LD + i] = v[r].x;
+        S[(k4 * 4 + 1) * LD + i] = v[r].y;
+        S[(k4 * 4 + 2) * LD + i] = v[r].z;
+        S[(k4 * 4 + 3) * LD + i] = v[r].w;
+    }
+}
+// reduction-row operand P[red][i]: 32 rows, BMN contiguous floats.  thread -> (i4 = t % (BMN/4), row = t/(BMN/4) + RP*r)
+template <int BMN>
+__device__ __forceinline__ void load_rc(float4 (&v)[BMN / 32], const float* __restrict__ P, int ld,
+                                        int i0, int limit, int k0, int t) {
+    constexpr int C4 = BMN / 4, RP = NT / C4;
+    const int i4 = t % C4, rr = t / C4;
+    const int gi = i0 + i4 * 4;
+#pragma unroll
+    for (int r = 0; r < BMN / 32; ++r) {
+        const int row = k0 + rr + RP * r;
+        v[r] = gi < limit ? ldg4(P + (size_t)row * ld + gi) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int BMN, int LD>
+__device__ __forceinline__ void store_rc(const float4 (&v)[BMN / 32], float* __restrict__ S, int t) {
+    constexpr int C4 = BMN / 4, RP = NT / C4;
+    const int i4 = t % C4, rr = t / C4;
+#pragma unroll
+    for (int r = 0; r < BMN / 32; ++r)
+        *reinterpret_cast<float4*>(S + (rr + RP * r) * LD + i4 * 4) = v[r];
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
+    constexpr bool A_KC = (MODE != MODE_WGRAD);
+    constexpr bool B_KC = (MODE == MODE_FWD);
+    constexpr int LDA = BM + (A_KC ? 2 : 4);
+    constexpr int LDB = BN + (B_KC ? 2 : 4);
+    constexpr int WN = (BN == 32) ? 1 : ((BM == 32) ? 4 : 2);   // waves along n
+    constexpr int WM = 4 / WN;                                  // waves along m
+    constexpr int TM = BM / (WM * 32);           // 32x32 MFMA tiles per wave along m
+    constexpr int TN = BN / (WN * 32);
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BK][LDA]
+    float* Bs = smem + 2 * BK * LDA;        // [2][BK][LDB]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tile ids
+    // (n fastest) so neighbouring tiles that share the A row panel hit the same L2.
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+    }
+    const int tn_i = bid % a.tiles_n;
+    const int tm_i = (bid / a.tiles_n) % a.tiles_m;
+    const int split = bid / (a.tiles_n * a.tiles_m);
+    const int i0 = tm_i * BM, j0 = tn_i * BN;
+    const int kt_begin = split * a.kt_per_split;
+    const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
+    if (kt_begin >= kt_end) return;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // WGRAD bias-gradient partial (column sums of dY)
+    const bool do_db = (MODE == MODE_WGRAD) && a.db != nullptr && tn_i == 0;
+
+    auto gload = [&](int kt) {
+        if constexpr (A_KC) {
+            const float* P = a.A0; int ld = a.lda0; int k0 = kt * BK;
+            if (MODE == MODE_FWD && kt >= a.kt0) { P = a.A1; ld = a.lda1; k0 = (kt - a.kt0) * BK; }
+            load_kc<BM>(ra, P, ld, i0, a.Mload, k0, t);
+        } else {
+            load_rc<BM>(ra, a.A0, a.lda0, i0, a.Mload, kt * BK, t);
+            if (do_db) {
+#pragma unroll
+                for (int r = 0; r < BM / 32; ++r) { bsum.x += ra[r].x; bsum.y += ra[r].y; bsum.z += ra[r].z; bsum.w += ra[r].w; }
+            }
+        }
+        if constexpr (B_KC) load_kc<BN>(rb, a.B, a.ldb, j0, a.Nload, kt * BK, t);
+        else                load_rc<BN>(rb, a.B, a.ldb, j0, a.Nload, kt * BK, t);
+    };
+    auto sstore = [&](int buf) {
+        if constexpr (A_KC) store_kc<BM, LDA>(ra, As + buf * BK * LDA, t);
+        else                store_rc<BM, LDA>(ra, As + buf * BK * LDA, t);
+        if constexpr (B_KC) store_kc<BN, LDB>(rb, Bs + buf * BK * LDB, t);
+        else                store_rc<BN, LDB>(rb, Bs + buf * BK * LDB, t);
+    };
+
+    gload(kt_begin);
+    sstore(0);
+    __syncthreads();
+
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) gload(kt + 1);
+        const float* Ab = As + buf * BK * LDA + wm * (TM * 32) + l31;
+        const float* Bb = Bs + buf * BK * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = ks * 2 + lhi;
+            float fa[TM], fb[TN];
+#pragma unroll
+            for (int x = 0; x < TM; ++x) fa[x] = Ab[kk * LDA + x * 32];
+#pragma unroll
+            for (int y = 0; y < TN; ++y) fb[y] = Bb[kk * LDB + y * 32];
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int y = 0; y < TN; ++y)
+                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x], fb[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue -------------------------------------------------------------------------
+#pragma unroll
+    for (int x = 0; x < TM; ++x) {
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int col = j0 + wn * (TN * 32) + y * 32 + l31;
+            if (col >= a.N) continue;
+            float bcol = 0.f;
+            if (MODE == MODE_FWD && a.bias != nullptr) bcol = a.bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * (TM * 32) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= a.M) continue;
+                float v = acc[x][y][r];
+                if constexpr (MODE == MODE_FWD) {
+                    v += bcol;
+                    switch (a.epi) {
+                        case HOS_EPI_RELU: v = fmaxf(v, 0.f); break;
+                        case HOS_EPI_DENSITY: a.aux[row] = softplus_f(v + a.p0); continue;
+                        case HOS_EPI_RGB: v = sigmoid_f(v) * (1.f + 2.f * a.p0) - a.p0; break;
+                        case HOS_EPI_NERF_HEAD:
+                            if (col == a.aux_col) { a.aux[row] = softplus_f(v + a.p0); continue; }
+                            break;
+                        case HOS_EPI_SIGMOID_RELU4: v = (col < 3) ? sigmoid_f(v) : fmaxf(v, 0.f); break;
+                        default: break;
+                    }
+                    a.C[(size_t)row * a.ldc + col] = v;
+                } else if constexpr (MODE == MODE_DGRAD) {
+                    if (a.mask != nullptr && !(a.mask[(size_t)row * a.ldmask + col] > 0.f)) v = 0.f;
+                    float* dst = a.C + (size_t)row * a.ldc + col;
+                    *dst = a.accumulate ? (*dst + v) : v;
+                } else {
+                    __hip_atomic_fetch_add(a.C + (size_t)row * a.ldc + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+
+    if constexpr (MODE == MODE_WGRAD) {
+        if (do_db) {
+            // reduce the per-thread float4 column sums over the NT/(BM/4) row groups, then one atomic per column
+            constexpr int C4 = BM / 4, RP = NT / C4;
+            float* red = smem;  // reuse (all MFMA reads are behind the loop's final barrier)
+            const int i4 = t % C4, rr = t / C4;
+            *reinterpret_cast<float4*>(red + rr * BM + i4 * 4) = bsum;
+            __syncthreads();
+            if (t < BM) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RP; ++r) s += red[r * BM + t];
+                if (i0 + t < a.M)
+                    __hip_atomic_fetch_add(a.db + i0 + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int MODE>
+int launch(const GemmArgs& a, int splits, hipStream_t stream) {
+    constexpr bool A_KC = (MODE != MODE_WGRAD);
+    constexpr bool B_KC = (MODE == MODE_FWD);
+    constexpr int LDA = BM + (A_KC ? 2 : 4);
+    constexpr int LDB = BN + (B_KC ? 2 : 4);
+    constexpr size_t smem = sizeof(float) * 2 * BK * (LDA + LDB);
+    static bool attr_set = false;   // idempotent; racing setters write the same value
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nblocks = a.tiles_m * a.tiles_n * splits;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE>), dim3(nblocks), dim3(NT), smem, stream, a);
+    return hos_launch_status();
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
+                              const float* W, int ldw, const float* bias, float* C, int ldc,
+                              int M, int N, int epilogue, float* aux, int aux_col, float p0, float p1,
+                              hos_stream_t stream) {
+    if (!A0 || !W || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
+    if (K1 > 0 && !A1) return HOS_E_ARG;
+    if ((K0 % BK) || (K1 % BK)) return HOS_E_SHAPE;
+    if ((lda0 & 3) || (ldw & 3) || (K1 > 0 && (lda1 & 3))) return HOS_E_ALIGN;
+    if (!al16(A0) || !al16(W) || (K1 > 0 && !al16(A1))) return HOS_E_ALIGN;
+    const bool aux_only = (epilogue == HOS_EPI_DENSITY);
+    if (!aux_only && !C) return HOS_E_ARG;
+    if ((epilogue == HOS_EPI_DENSITY || epilogue == HOS_EPI_NERF_HEAD) && !aux) return HOS_E_ARG;
+    if (epilogue == HOS_EPI_DENSITY && N != 1) return HOS_E_SHAPE;
+    if (epilogue == HOS_EPI_SIGMOID_RELU4 && N != 4) return HOS_E_SHAPE;
+    GemmArgs a{};
+    a.A0 = A0; a.lda0 = lda0; a.kt0 = K0 / BK; a.A1 = A1; a.lda1 = lda1;
+    a.B = W; a.ldb = ldw; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.Mload = M; a.Nload = N;
+    a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk;
+    a.bias = bias; a.aux = aux; a.aux_col = aux_col; a.p0 = p0; a.p1 = p1; a.epi = epilogue;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (N <= 32) {
+        a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 32);
+        return launch<128, 32, MODE_FWD>(a, 1, s);
+    }
+    a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 128);
+    return launch<128, 128, MODE_FWD>(a, 1, s);
+}
+
+extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad,
+                                const float* Xact, int ldx, float* dX, int lddx, int M, int K,
+                                int accumulate, hos_stream_t stream) {
+    if (!dY || !W || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
+    if (Npad % BK) return HOS_E_SHAPE;
+    if ((lddy & 3) || (ldw & 3) || (K & 3)) return HOS_E_ALIGN;
+    if (!al16(dY) || !al16(W)) return HOS_E_ALIGN;
+    GemmArgs a{};
+    a.A0 = dY; a.lda0 = lddy; a.kt0 = Npad / BK;
+    a.B = W; a.ldb = ldw; a.C = dX; a.ldc = lddx;
+    a.M = M; a.N = K; a.Mload = M; a.Nload = K;
+    a.nk = Npad / BK; a.kt_per_split = a.nk;
+    a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
+    a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(K, 128);
+    return launch<128, 128, MODE_DGRAD>(a, 1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
+                                float* db, int M, int N, int K, int splits, hos_stream_t stream) {
+    if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+    if (M % BK) return HOS_E_SHAPE;
+    if ((lddy & 3) || (ldx & 3) || (K & 3)) return HOS_E_ALIGN;
+    if (!al16(dY) || !al16(X)) return HOS_E_ALIGN;
+    GemmArgs a{};
+    a.A0 = dY; a.lda0 = lddy; a.B = X; a.ldb = ldx; a.C = dW; a.ldc = ldw;
+    a.M = N; a.N = K;
+    a.Mload = (N + 3) & ~3;          // dY is zero-padded to a multiple of 32 columns by contract
+    if (a.Mload > lddy) a.Mload = lddy & ~3;
+    a.Nload = K;
+    a.nk = M / BK;
+    a.db = db;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool narrow = (N <= 32);
+    a.tiles_m = hos_cdiv(N, narrow ? 32 : 128);
+    a.tiles_n = hos_cdiv(K, 128);
+    if (splits <= 0) {
+        const int tiles = a.tiles_m * a.tiles_n;
+        splits = hos_cdiv(1024, tiles);          // ~4 workgroups per CU
+        if (splits > a.nk / 8) splits = a.nk / 8 > 0 ? a.nk / 8 : 1;   // >= 8 K tiles per split
+    }
+    if (splits > a.nk) splits = a.nk;
+    a.kt_per_split = hos_cdiv(a.nk, splits);
+    splits = hos_cdiv(a.nk, a.kt_per_split);
+    if (narrow) return launch<32, 128, MODE_WGRAD>(a, splits, s);
+    return launch<128, 128, MODE_WGRAD>(a, splits, s);
+}

@@ -1,0 +1,283 @@
+"""Python-side wrappers of the C-ABI kernels: shape checks, output allocation, autograd glue.
+
+Nothing here computes on the CPU; every function enqueues HIP kernels of libhosrender.so on the
+current torch stream.  Tensors are fp32, contiguous, on the HIP device.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+EPS = 1.1920929e-07
+
+EPI_NONE, EPI_RELU, EPI_DENSITY, EPI_RGB, EPI_NERF_HEAD, EPI_SIGMOID_RELU4 = 0, 1, 2, 3, 4, 5
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------ kernel timing
+class KernelEvents:
+    """Optional HIP-event timing of every GEMM launch (bench.py's live roofline measurement).
+
+    Events are recorded on the current torch stream -- the stream the kernels are launched on -- so the
+    elapsed time of a (start, stop) pair is that launch's device duration (plus launch gaps)."""
+
+    def __init__(self):
+        self.records = {}
+
+    def record(self, key, flops, launch):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        self.records.setdefault(key, []).append((a, b, flops))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        rows = []
+        for key, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            flops = recs[0][2]
+            tot = sum(ms)
+            rows.append({"kernel": key, "launches": len(recs), "total_ms": tot, "avg_us": 1e3 * tot / len(recs),
+                         "flop_per_launch": flops, "tflops": flops * len(recs) / (tot * 1e-3) / 1e12 if tot > 0 else 0.0})
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
+
+
+_EVENTS: Optional[KernelEvents] = None
+
+
+def set_kernel_events(ev: Optional[KernelEvents]):
+    global _EVENTS
+    _EVENTS = ev
+
+
+def _timed(key, flops, launch):
+    if _EVENTS is None:
+        launch()
+    else:
+        _EVENTS.record(key, flops, launch)
+
+
+# ------------------------------------------------------------------------------------------ GEMMs
+def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
+               out: Optional[torch.Tensor], epilogue: int = EPI_NONE, A1: Optional[torch.Tensor] = None,
+               K1: int = 0, aux: Optional[torch.Tensor] = None, aux_col: int = -1, p0: float = 0.0,
+               ldc: Optional[int] = None, M: Optional[int] = None):
+    """out[M,N] = epi([A0[:, :K0] | A1[:, :K1]] @ W[:N, :K0+K1]^T + bias).  W is a [rows, ldw] buffer."""
+    M = A0.shape[0] if M is None else M
+    _timed(f"gemm_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
+        "hos_linear_fwd", ptr(A0), A0.stride(0), K0, ptr(A1), 0 if A1 is None else A1.stride(0), K1,
+        ptr(W), W.stride(0), ptr(bias), ptr(out), (0 if out is None else out.stride(0)) if ldc is None else ldc,
+        M, N, epilogue, ptr(aux), aux_col, float(p0), 0.0))
+    return out
+
+
+def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torch.Tensor,
+                 mask_src: Optional[torch.Tensor] = None, accumulate: bool = False, w_col0: int = 0):
+    """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src > 0)."""
+    M = dY.shape[0]
+    wptr = ptr(W) + 4 * w_col0
+    _timed(f"gemm_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
+        "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
+        0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K, int(accumulate)))
+    return out
+
+
+def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], N: int, K: int,
+                 w_col0: int = 0, splits: int = 0):
+    """dW[:N, w_col0:w_col0+K] += dY[:, :N]^T @ X[:, :K];  db[:N] += colsum(dY[:, :N])."""
+    M = dY.shape[0]
+    _timed(f"gemm_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
+        "hos_linear_wgrad", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0),
+        ptr(db), M, N, K, splits))
+
+
+# ------------------------------------------------------------------------------------------ rays
+_U_CACHE = {}
+
+
+def _u_base(S: int, randomized: bool, device) -> Tuple[torch.Tensor, float]:
+    """The torch.linspace grid of H:354 / H:363 (built with torch on the host so it is bit-identical)."""
+    key = (S, randomized, str(device))
+    if key not in _U_CACHE:
+        if randomized:
+            u_max = EPS + (1 - EPS) / S
+            max_jitter = (1 - u_max) / (S - 1) - EPS
+            u = torch.linspace(0, 1 - u_max, S)
+        else:
+            pad = 1 / (2 * S)
+            max_jitter = 0.0
+            u = torch.linspace(pad, 1 - pad - EPS, S)
+        _U_CACHE[key] = (u.to(device), float(np.float32(max_jitter)))
+    return _U_CACHE[key]
+
+
+def resample(sdist_prev: torch.Tensor, w_prev: torch.Tensor, S: int, dilation: float, anneal: float,
+             randomized: bool, near: float, far: float, jitter: Optional[torch.Tensor] = None,
+             resample_padding: float = 0.0, want_index: bool = False):
+    """Fused max_dilate -> logits -> inverse-CDF -> interval edges -> s_to_t.  Returns (sdist, tdist[, idx])."""
+    B, n = w_prev.shape
+    dev = w_prev.device
+    u, scale = _u_base(S, randomized, dev)
+    if randomized and jitter is None:
+        jitter = torch.rand(B, device=dev)
+    if not randomized:
+        jitter = None
+    sdist = torch.empty(B, S + 1, device=dev)
+    tdist = torch.empty(B, S + 1, device=dev)
+    idx = torch.empty(B, S, dtype=torch.int32, device=dev) if want_index else None
+    call("hos_resample", ptr(sdist_prev.detach()), ptr(w_prev.detach()), n, B, S, float(dilation), float(anneal),
+         float(resample_padding), ptr(u), ptr(None if jitter is None else jitter.reshape(-1)), scale,
+         float(near), float(far), ptr(sdist), ptr(tdist), ptr(idx, torch.int32))
+    return (sdist, tdist, idx) if want_index else (sdist, tdist)
+
+
+def encode_ipe(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, out=None):
+    B, S1 = tdist.shape
+    S = S1 - 1
+    X = torch.empty(B * S, ldx, device=tdist.device) if out is None else out
+    call("hos_encode_ipe", ptr(tdist), ptr(rays_o), ptr(rays_d), ptr(radii.reshape(-1)), ptr(basis), ptr(embed),
+         B, S, ptr(X), ldx)
+    return X
+
+
+def encode_viewdirs(viewdirs, S: int, Xv: torch.Tensor, col0: int):
+    B = viewdirs.shape[0]
+    call("hos_encode_viewdirs", ptr(viewdirs), B, S, ptr(Xv), Xv.stride(0), col0)
+    return Xv
+
+
+class _AlphaWeights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density, tdist, dirs, opaque):
+        B, S = density.shape
+        w = torch.empty_like(density)
+        call("hos_alpha_weights_fwd", ptr(density), ptr(tdist), ptr(dirs), B, S, int(opaque), ptr(w))
+        ctx.save_for_backward(density, tdist, dirs)
+        ctx.opaque = int(opaque)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        density, tdist, dirs = ctx.saved_tensors
+        B, S = density.shape
+        gd = torch.empty_like(density)
+        call("hos_alpha_weights_bwd", ptr(gw.contiguous()), ptr(density), ptr(tdist), ptr(dirs), B, S, ctx.opaque, ptr(gd))
+        return gd, None, None, None
+
+
+def alpha_weights(density, tdist, dirs, opaque_background: bool):
+    """compute_alpha_weights(...)[0] (H:235-261); differentiable w.r.t. density."""
+    return _AlphaWeights.apply(density.contiguous(), tdist.contiguous(), dirs.contiguous(), opaque_background)
+
+
+class _VolRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgbs, weights, bg):
+        B, S = weights.shape
+        out = torch.empty(B, 3, device=weights.device)
+        call("hos_volrender_fwd", ptr(rgbs), ptr(weights), B, S, float(bg), ptr(out))
+        ctx.save_for_backward(rgbs, weights)
+        ctx.bg = float(bg)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rgbs, weights = ctx.saved_tensors
+        B, S = weights.shape
+        g_rgbs = torch.empty_like(rgbs) if ctx.needs_input_grad[0] else None
+        g_w = torch.empty_like(weights) if ctx.needs_input_grad[1] else None
+        call("hos_volrender_bwd", ptr(g.contiguous()), ptr(rgbs), ptr(weights), B, S, ctx.bg, ptr(g_rgbs), ptr(g_w))
+        return g_rgbs, g_w, None
+
+
+def volumetric_rendering(rgbs, weights, bg_rgb: float):
+    """H:265-275: rgb[B,3]."""
+    return _VolRender.apply(rgbs.contiguous(), weights.contiguous(), bg_rgb)
+
+
+class _Interlevel(torch.autograd.Function):
+    """sum over rays and NeRF bins of lossfun_outer(c, w, cp, wp) (H:136-138); grad w.r.t. wp only."""
+
+    @staticmethod
+    def forward(ctx, c, w, cp, wp):
+        B, Sc = w.shape
+        Sp = wp.shape[1]
+        per_ray = torch.empty(B, device=w.device)
+        call("hos_interlevel_fwd", ptr(c), ptr(w), ptr(cp), ptr(wp), B, Sc, Sp, ptr(per_ray), 0, 0)
+        ctx.save_for_backward(c, w, cp, wp)
+        return per_ray
+
+    @staticmethod
+    def backward(ctx, g):
+        c, w, cp, wp = ctx.saved_tensors
+        B, Sc = w.shape
+        Sp = wp.shape[1]
+        gwp = torch.empty_like(wp)
+        call("hos_interlevel_bwd", ptr(c), ptr(w), ptr(cp), ptr(wp), B, Sc, Sp, 1.0, ptr(gwp))
+        return None, None, None, gwp * g[:, None]
+
+
+def interlevel_loss_per_ray(c, w, cp, wp):
+    return _Interlevel.apply(c.detach().contiguous(), w.detach().contiguous(), cp.detach().contiguous(), wp.contiguous())
+
+
+def interlevel_indices(c, w, cp, wp):
+    """(idx_lo, idx_hi) int32 [B,Sc+1] -- the bit-exact searchsorted indices of H:109-114."""
+    B, Sc = w.shape
+    Sp = wp.shape[1]
+    lo = torch.empty(B, Sc + 1, dtype=torch.int32, device=w.device)
+    hi = torch.empty_like(lo)
+    per_ray = torch.empty(B, device=w.device)
+    call("hos_interlevel_fwd", ptr(c), ptr(w), ptr(cp), ptr(wp), B, Sc, Sp, ptr(per_ray), ptr(lo, torch.int32), ptr(hi, torch.int32))
+    return lo, hi
+
+
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, w):
+        B, S = w.shape
+        per_ray = torch.empty(B, device=w.device)
+        call("hos_distortion_fwd", ptr(t), ptr(w), B, S, ptr(per_ray))
+        ctx.save_for_backward(t, w)
+        return per_ray
+
+    @staticmethod
+    def backward(ctx, g):
+        t, w = ctx.saved_tensors
+        B, S = w.shape
+        gw = torch.empty_like(w)
+        call("hos_distortion_bwd", ptr(t), ptr(w), B, S, 1.0, ptr(gw))
+        return None, gw * g[:, None]
+
+
+def distortion_loss_per_ray(t, w):
+    """H:142-149 per ray; differentiable w.r.t. w (t = sdist is detached in the reference, M:493-494)."""
+    return _Distortion.apply(t.detach().contiguous(), w.contiguous())
+
+
+def head_grad(g_density, density, g_rgb, rgb, rgb_padding, dz_density, col_dd, dz_rgb):
+    P = density.numel()
+    call("hos_head_grad", ptr(g_density), ptr(density), ptr(g_rgb), ptr(rgb), P, float(rgb_padding),
+         ptr(dz_density), 0 if dz_density is None else dz_density.stride(0), col_dd,
+         ptr(dz_rgb), 0 if dz_rgb is None else dz_rgb.stride(0))
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    call("hos_sumsq", ptr(g), g.numel(), ptr(out))
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, sumsq_buf=None, max_norm=0.0):
+    call("hos_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), int(step), float(grad_scale), ptr(sumsq_buf), float(max_norm))

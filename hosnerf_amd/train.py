@@ -1,0 +1,113 @@
+"""Training-step pieces for the stage-1 (background) model: losses on HIP kernels, the flat fused
+Adam, the reference's LR schedule and the ray-sharded data-parallel step.
+
+Mirrors 1st_State-Conditional_Scene/src/model/mipnerf360/model.py:491-514 (training_step),
+:536-569 (configure_optimizers / optimizer_step), :611-627 (interlevel / distortion losses) and
+run.py:155 (`gradient_clip_val=grad_max_norm`, norm clipping).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .flat import FlatModule
+
+
+def stage1_loss(rgb: torch.Tensor, target: torch.Tensor, ray_history: List[Dict[str, torch.Tensor]],
+                data_loss_mult: float = 1.0, interlevel_loss_mult: float = 1.0, distortion_loss_mult: float = 0.01,
+                charb_padding: float = 0.001) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    """M1:491-514: sqrt(mse + charb^2) + interlevel + 0.01 * distortion (means over the local ray batch)."""
+    mse = torch.mean((rgb - target.to(rgb.dtype)) ** 2)
+    loss = torch.sqrt(mse + charb_padding**2) * data_loss_mult
+    last = ray_history[-1]
+    c, w = last["sdist"], last["weights"]
+    B, Sc = w.shape
+    inter = rgb.new_zeros(())
+    for h in ray_history[:-1]:
+        inter = inter + ops.interlevel_loss_per_ray(c, w, h["sdist"], h["weights"]).sum() / (B * Sc)
+    distortion = ops.distortion_loss_per_ray(c, w).mean()
+    total = loss + inter * interlevel_loss_mult + distortion * distortion_loss_mult
+    return total, {"mse": mse.detach(), "interlevel": inter.detach(), "distortion": distortion.detach()}
+
+
+def stage1_lr(step: int, max_steps: int, lr_init: float = 2.0e-3, lr_final: float = 2.0e-5,
+              lr_delay_steps: int = 512, lr_delay_mult: float = 0.01) -> float:
+    """M1:551-563 log-linear decay with a sine warm-up."""
+    if lr_delay_steps > 0:
+        delay = lr_delay_mult + (1 - lr_delay_mult) * math.sin(0.5 * math.pi * float(np.clip(step / lr_delay_steps, 0, 1)))
+    else:
+        delay = 1.0
+    t = float(np.clip(step / max_steps, 0, 1))
+    return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+class FusedAdam:
+    """torch.optim.Adam semantics over the flat parameter buffer of a FlatModule: one sum-of-squares
+    launch (norm clipping), one RCCL all-reduce of the whole gradient (multi-GPU) and one Adam launch."""
+
+    def __init__(self, module: FlatModule, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 max_grad_norm: float = 0.0, process_group=None):
+        self.module = module
+        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.group = process_group
+        p = module.flat_param
+        self.exp_avg = torch.zeros_like(p)
+        self.exp_avg_sq = torch.zeros_like(p)
+        self._sumsq = torch.zeros(1, device=p.device)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.module.store.zero_grad()
+
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def step(self, lr: Optional[float] = None):
+        g = self.module.flat_grad
+        world = self.world_size()
+        if world > 1:
+            # ONE collective per step over the whole 38 MB gradient: xGMI is point-to-point, so a
+            # single large message keeps every link busy (DDP's 25 MB buckets would split it in two).
+            dist.all_reduce(g, group=self.group)
+        self.step_count += 1
+        sumsq = None
+        if self.max_grad_norm > 0:
+            self._sumsq.zero_()
+            ops.sumsq(g, self._sumsq)
+            sumsq = self._sumsq
+        ops.adam_step(self.module.flat_param, g, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
+                      self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world, sumsq, self.max_grad_norm)
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+
+
+def shard_rays(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
+    """S1/src/data/sampler.py:96: each rank renders rays[rank::world] of the global batch."""
+    if world == 1:
+        return batch
+    out = {}
+    for k, v in batch.items():
+        out[k] = v[rank::world].contiguous() if isinstance(v, torch.Tensor) and v.dim() > 0 else v
+    return out
+
+
+def train_step_stage1(model, opt: FusedAdam, batch: Dict[str, torch.Tensor], train_frac: float, near: float,
+                      far: float, lr: Optional[float] = None):
+    """One full stage-1 optimisation step: forward (3 levels) + losses + backward + clip + Adam."""
+    opt.zero_grad()
+    renderings, hist = model(batch, train_frac, True, True, near, far)
+    loss, parts = stage1_loss(renderings[-1]["rgb"], batch["target"], hist)
+    loss.backward()
+    opt.step(lr)
+    return loss.detach(), parts

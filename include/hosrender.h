@@ -1,0 +1,160 @@
+/*
+ * hosrender.h -- C ABI of libhosrender.so: MI355X (gfx950) kernels for HOSNeRF's per-ray hot path.
+ *
+ * The reference (TencentARC/HOSNeRF) is 100% Python/torch and has no FFI of its own; its plugin
+ * surface is the two nn.Module.forward signatures.  This library is the native
+ * layer *below* that surface: hosnerf_amd/{mipnerf360,human_nerf,hosnerf}.py mirror the reference
+ * modules and call these entry points through ctypes.  Each entry point cites the reference
+ * lines (torch-op chain) it replaces.  Abbreviations:
+ *   H: 3rd_Complete_HOSNeRF/src/model/mipnerf360/helper.py     M: .../mipnerf360/model.py
+ *   N: 3rd_Complete_HOSNeRF/core/nets/human_nerf/network.py    U: .../core/utils/network_util.py
+ *
+ * Conventions (all entry points):
+ *   - plain C: device pointers + sizes + a hipStream_t (passed as void*); no torch types.
+ *   - return 0 on success, a negative HOS_E_* code on bad arguments, or the positive hipError_t
+ *     of a failed launch.  Never throws, never allocates, never synchronises: work is enqueued on
+ *     `stream` and ordered with the caller's other work on that stream.
+ *   - all tensors are fp32 row-major unless stated; "ld" = leading dimension in elements.
+ *   - re-entrant per device; the caller owns all memory (workspaces are passed in).
+ */
+#ifndef HOSRENDER_H
+#define HOSRENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOS_OK 0
+#define HOS_E_ARG (-1)       /* null pointer / negative size                        */
+#define HOS_E_ALIGN (-2)     /* pointer or leading dimension not 16-byte compatible */
+#define HOS_E_SHAPE (-3)     /* unsupported shape (see the entry point)             */
+#define HOS_E_NODEVICE (-4)  /* no HIP device visible                               */
+
+typedef void* hos_stream_t; /* hipStream_t */
+
+/* Library / device probes (no compute). */
+int hos_version(void);                 /* 100*major + minor */
+int hos_device_count(void);            /* >=0, or HOS_E_NODEVICE */
+const char* hos_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense MLP contractions (fp32 MFMA v_mfma_f32_32x32x2_f32, exact-fp32 numerics).
+ * Replaces every nn.Linear on the path: M:299-351 (PropMLP/NeRFMLP), canonical_mlps/
+ * mlp_rgb_sigma.py:49-58, non_rigid_motion_mlps/mlp_offset.py:54-66.
+ * All reduction dimensions must be multiples of 32 (buffers are zero-padded by the host side).
+ * ------------------------------------------------------------------------------------------ */
+
+/* epilogues for hos_linear_fwd */
+#define HOS_EPI_NONE 0       /* C = acc + bias                                                */
+#define HOS_EPI_RELU 1       /* C = relu(acc + bias)                                          */
+#define HOS_EPI_DENSITY 2    /* N==1: aux[m] = softplus(acc + bias + density_bias)   (M:316)   */
+#define HOS_EPI_RGB 3        /* C = sigmoid(acc+bias)*(1+2*pad) - pad               (M:345-346)*/
+#define HOS_EPI_NERF_HEAD 4  /* cols < aux_col: C = acc+bias; col == aux_col: aux[m] = softplus(acc+bias+density_bias) */
+#define HOS_EPI_SIGMOID_RELU4 5 /* N==4: cols 0..2 sigmoid, col 3 relu (N:539-540)             */
+
+/* C[M,N] = epi( [A0 | A1][M, K0+K1] @ W[N, K0+K1]^T + bias[N] ).
+ * A1 may be NULL (K1 = 0); K0, K1 multiples of 32; W row n starts at W + n*ldw.  */
+int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
+                   const float* W, int ldw, const float* bias, float* C, int ldc,
+                   int M, int N, int epilogue, float* aux, int aux_col, float p0, float p1,
+                   hos_stream_t stream);
+
+/* dX[M,K] = (dY[M,Npad] @ W[Npad,K]) (* (Xact[M,K] > 0) if Xact != NULL).
+ * Npad (the reduction dim = padded layer width) multiple of 32; rows >= N of W must be zero.
+ * If accumulate != 0, dX += result (used for skip / multi-consumer activations). */
+int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad,
+                     const float* Xact, int ldx, float* dX, int lddx, int M, int K,
+                     int accumulate, hos_stream_t stream);
+
+/* dW[N,K] += dY[M,N]^T @ X[M,K]   and, if db != NULL, db[N] += column sums of dY.
+ * M (the reduction dim = number of sample points) multiple of 32.  Accumulates with fp32
+ * atomics over `splits` partitions of M (splits <= 0: chosen by the library). */
+int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
+                     float* db, int M, int N, int K, int splits, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Background branch, per-ray kernels (one wavefront per ray).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Proposal resampling: replaces H:187-194 (max_dilate_weights) + M:469-482 (trim, logits) +
+ * H:373-399 (sample_intervals -> sample -> invert_cdf -> sorted_interp) + H:169-174 (s_to_t).
+ * n_prev == 1 selects the level-0 path (t=[0,1], w=1, no dilation).
+ *   sdist_prev [B,n_prev+1], w_prev [B,n_prev]       previous level histogram
+ *   u_base [S]        torch.linspace grid of H:354 / H:363 (host supplies it; bit-exact u)
+ *   jitter [B] or NULL, jitter_scale = max_jitter of H:360 (train); NULL -> u = u_base (eval)
+ *   outputs: sdist [B,S+1], tdist [B,S+1], bin_idx [B,S] int32 (optional, may be NULL):
+ *            index of the CDF knot left of every sample centre (bit-exact target of SURVEY B4). */
+int hos_resample(const float* sdist_prev, const float* w_prev, int n_prev, int B, int S,
+                 float dilation, float anneal, float resample_padding,
+                 const float* u_base, const float* jitter, float jitter_scale,
+                 float near_, float far_, float* sdist, float* tdist, int32_t* bin_idx,
+                 hos_stream_t stream);
+
+/* Conical-frustum cast + contraction + lift + integrated positional encoding (+ state embedding
+ * columns + zero pad): replaces H:279-339, H:33-68 (closed-form Jacobian), H:71-89, M:295-296.
+ *   X [B*S, ldx]: cols [0,504) IPE (level-major, 21 dirs; sin part then sin(.+pi/2) part),
+ *                 [504,568) = state embedding, [568,ldx) = 0.   basis [3,21] row-major. */
+int hos_encode_ipe(const float* tdist, const float* rays_o, const float* rays_d, const float* radii,
+                   const float* basis, const float* embed, int B, int S, float* X, int ldx,
+                   hos_stream_t stream);
+
+/* View-direction encoding (H:93-100, deg 0..4, identity appended = 27) broadcast over samples
+ * into columns [col0, col0+27) of Xv [B*S, ldx]; columns [col0+27, ldx) are zeroed (M:330-335). */
+int hos_encode_viewdirs(const float* viewdirs, int B, int S, float* Xv, int ldx, int col0,
+                        hos_stream_t stream);
+
+/* compute_alpha_weights (H:235-261):  weights [B,S]  from density [B,S], tdist [B,S+1], dirs [B,3]. */
+int hos_alpha_weights_fwd(const float* density, const float* tdist, const float* dirs, int B, int S,
+                          int opaque_background, float* weights, hos_stream_t stream);
+/* g_density [B,S] from g_weights [B,S] (recomputes alpha/trans). */
+int hos_alpha_weights_bwd(const float* g_weights, const float* density, const float* tdist,
+                          const float* dirs, int B, int S, int opaque_background, float* g_density,
+                          hos_stream_t stream);
+
+/* volumetric_rendering (H:265-275): rgb [B,3] = sum w*c + clip(1-sum w,0)*bg. */
+int hos_volrender_fwd(const float* rgbs, const float* weights, int B, int S, float bg, float* rgb,
+                      hos_stream_t stream);
+int hos_volrender_bwd(const float* g_rgb, const float* rgbs, const float* weights, int B, int S,
+                      float bg, float* g_rgbs, float* g_weights, hos_stream_t stream);
+
+/* Stage-1 losses (M1:611-627 -> H:136-149).  Per-ray partial losses are written to loss_ray [B]
+ * (the host sums / means them); the backward kernels take the upstream scale g (dLoss/dmean / B).
+ *   interlevel: c [B,Sc+1], w [B,Sc] (detached NeRF histogram), cp [B,Sp+1], wp [B,Sp].
+ *   idx_lo/idx_hi [B,Sc+1] int32 optional outputs (bit-exact vs H:109-114). */
+int hos_interlevel_fwd(const float* c, const float* w, const float* cp, const float* wp, int B,
+                       int Sc, int Sp, float* loss_ray, int32_t* idx_lo, int32_t* idx_hi,
+                       hos_stream_t stream);
+int hos_interlevel_bwd(const float* c, const float* w, const float* cp, const float* wp, int B,
+                       int Sc, int Sp, float scale, float* g_wp, hos_stream_t stream);
+int hos_distortion_fwd(const float* t, const float* w, int B, int S, float* loss_ray,
+                       hos_stream_t stream);
+int hos_distortion_bwd(const float* t, const float* w, int B, int S, float scale, float* g_w,
+                       hos_stream_t stream);
+
+/* Activation derivatives that turn (g_density, g_rgb) into pre-activation gradients, written
+ * into the zero-padded dY buffers the dgrad/wgrad kernels consume.
+ *   dz_density[m*ld_dd + col_dd] = g_density[m] * (1 - exp(-density[m]))     (softplus')
+ *   dz_rgb[m*ld_dr + c]          = g_rgb[m,c] * (1+2pad) * s*(1-s), s=(rgb+pad)/(1+2pad)  */
+int hos_head_grad(const float* g_density, const float* density, const float* g_rgb, const float* rgb,
+                  int P, float rgb_padding, float* dz_density, int ld_dd, int col_dd,
+                  float* dz_rgb, int ld_dr, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimiser over flat buffers (torch.optim.Adam semantics, M1:536-539; PL norm clipping,
+ * S1/run.py:155 gradient_clip_val).
+ * ------------------------------------------------------------------------------------------ */
+/* sumsq[0] += sum g^2  (caller zeroes sumsq). */
+int hos_sumsq(const float* g, int64_t n, float* sumsq, hos_stream_t stream);
+/* Adam step; if sumsq != NULL and max_norm > 0 the gradient is scaled by
+ * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) first; grad_scale multiplies g before that
+ * (1/world_size for DDP averaging). */
+int hos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float grad_scale, const float* sumsq,
+                  float max_norm, hos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOSRENDER_H */
