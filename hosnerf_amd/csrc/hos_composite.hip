@@ -21,8 +21,11 @@ __device__ __forceinline__ void ray_excl_scan(const float (&v)[CH], float (&out)
     float run = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) { loc[c] = run; run += v[c]; }
+    // exclusive base = inclusive scan of the lane totals shifted by one lane.  (NOT incl - run: the
+    // opaque-background interval is 1e10 and would cancel the whole prefix.)
     const float incl = wave_incl_scan(run, lane);
-    const float base = incl - run;
+    float base = __shfl_up(incl, 1, 64);
+    if (lane == 0) base = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) out[c] = base + loc[c];
 }
@@ -33,7 +36,8 @@ __device__ __forceinline__ void ray_excl_rscan(const float (&v)[CH], float (&out
 #pragma unroll
     for (int c = CH - 1; c >= 0; --c) { loc[c] = run; run += v[c]; }
     const float incl = wave_incl_rscan(run, lane);
-    const float base = incl - run;
+    float base = __shfl_down(incl, 1, 64);
+    if (lane == 63) base = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) out[c] = base + loc[c];
 }
@@ -180,7 +184,8 @@ __device__ __forceinline__ float interlevel_common(InterLds& L, const float* c, 
         const float a = j0 < Sp ? wp[(size_t)ray * Sp + j0] : 0.f;
         const float b = j0 + 1 < Sp ? wp[(size_t)ray * Sp + j0 + 1] : 0.f;
         const float incl = wave_incl_scan(a + b, lane);
-        const float base = incl - (a + b);
+        float base = __shfl_up(incl, 1, 64);
+        if (lane == 0) base = 0.f;
         if (lane == 0) L.cy[0] = 0.f;
         if (j0 < Sp) L.cy[j0 + 1] = base + a;
         if (j0 + 1 < Sp) L.cy[j0 + 2] = base + a + b;
