@@ -91,3 +91,201 @@ def pinhole_batch(hw: int = 64, seed: int = 777, time: float = 0.5) -> Dict[str,
         "rays_o": t(o), "rays_d": t(dn.astype(np.float32)), "viewdirs": t(dn.astype(np.float32).copy()),
         "radii": t(radii), "times": torch.full((d.shape[0],), float(time)), "target": t(target),
     }
+
+
+# ------------------------------------------------------------------ human-object branch (configs 3/4)
+SMPL_PARENT = {1: 0, 2: 0, 3: 0, 4: 1, 5: 2, 6: 3, 7: 4, 8: 5, 9: 6, 10: 7, 11: 8, 12: 9, 13: 9, 14: 9, 15: 12,
+               16: 13, 17: 14, 18: 16, 19: 17, 20: 18, 21: 19, 22: 20, 23: 21, 24: 23, 25: 22}
+TORSO = (0, 3, 6, 9, 13, 14)
+
+
+def tpose_joints() -> np.ndarray:
+    """A fixed SMPL-like T-pose (metres) with the two object joints extrapolated from the hands
+    like the reference does (train.py:132-145): J24 = J23 + (J23 - J19), J25 = J22 + (J22 - J18)."""
+    J = np.array([
+        (0.00, 0.00, 0.00), (0.07, -0.09, 0.00), (-0.07, -0.09, 0.00), (0.00, 0.11, -0.02),
+        (0.10, -0.47, 0.00), (-0.10, -0.47, 0.00), (0.00, 0.25, 0.00), (0.09, -0.87, -0.03),
+        (-0.09, -0.87, -0.03), (0.00, 0.30, 0.02), (0.11, -0.93, 0.09), (-0.11, -0.93, 0.09),
+        (0.00, 0.51, -0.01), (0.08, 0.42, 0.00), (-0.08, 0.42, 0.00), (0.00, 0.60, 0.04),
+        (0.19, 0.45, -0.01), (-0.19, 0.45, -0.01), (0.45, 0.44, -0.03), (-0.45, 0.44, -0.03),
+        (0.70, 0.45, -0.03), (-0.70, 0.45, -0.03), (0.79, 0.44, -0.04), (-0.79, 0.44, -0.04)], dtype=np.float32)
+    obj_r = J[23] + (J[23] - J[19])
+    obj_l = J[22] + (J[22] - J[18])
+    return np.concatenate([J, obj_r[None], obj_l[None]], 0).astype(np.float32)
+
+
+def _axis_angle_to_matrix(r: np.ndarray) -> np.ndarray:
+    th = float(np.linalg.norm(r))
+    k = r / (th + 1e-5)
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]], dtype=np.float64)
+    return (math.cos(th) * np.eye(3) + math.sin(th) * Kx + (1 - math.cos(th)) * np.outer(k, k)).astype(np.float32)
+
+
+def _rotation_between(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    a = a / (np.linalg.norm(a) + 1e-12)
+    b = b / (np.linalg.norm(b) + 1e-12)
+    v = np.cross(a, b)
+    s, c = np.linalg.norm(v), float(a @ b)
+    if s < 1e-8:
+        return np.eye(3, dtype=np.float32) if c > 0 else np.diag([1.0, -1.0, -1.0]).astype(np.float32)
+    return _axis_angle_to_matrix(v / s * math.atan2(s, c))
+
+
+def bone_prior_volume(joints: np.ndarray, bmin: np.ndarray, bmax: np.ndarray, V: int = 32) -> np.ndarray:
+    """Gaussian bone-occupancy prior [K+1,V,V,V] (last channel = background), strictly positive,
+    channel-normalised -- same construction idea as body_util.approx_gaussian_bone_volumes
+    (anisotropic Gaussians along bones, isotropic at leaf joints); volume axes are (z,y,x)."""
+    K = joints.shape[0]
+    zz, yy, xx = np.meshgrid(np.linspace(bmin[2], bmax[2], V), np.linspace(bmin[1], bmax[1], V),
+                             np.linspace(bmin[0], bmax[0], V), indexing="ij")
+    grid = np.stack([xx, yy, zz], -1).astype(np.float32)
+    vols = []
+    for j in range(K):
+        vol = np.zeros((V, V, V), np.float32)
+        kids = [c for c, p in SMPL_PARENT.items() if p == j]
+        for c in kids:
+            std = np.array([0.03, 0.06, 0.03]) * 2.0
+            S = np.diag(1.0 / std)
+            if j in TORSO:
+                S[0, 0] /= 1.5
+                S[2, 2] /= 1.5
+            a, b = joints[j], joints[c]
+            R = _rotation_between(np.array([0.0, 1.0, 0.0]), b - a)
+            Sig = R @ S @ S @ R.T
+            d = grid - (a + b) / 2.0
+            vol += np.exp(-np.einsum("...i,ij,...j->...", d, Sig, d)).astype(np.float32)
+        if not kids:
+            std = (0.06 if j in (15, 24, 25) else 0.02) * 2.0
+            d = grid - joints[j]
+            vol = np.exp(-np.sum(d * d, -1) / (std * std)).astype(np.float32)
+        vols.append(vol)
+    vols = np.stack(vols, 0)
+    bg = 1.0 - np.clip(vols.sum(0, keepdims=True), 0.0, 1.0)
+    vols = np.concatenate([vols, bg], 0)
+    vols = vols / np.clip(vols.sum(0, keepdims=True), 0.001, None)
+    return np.clip(vols, 1e-6, None).astype(np.float32)       # log(prior) must stay finite
+
+
+def _ray_bbox(o, d, bmin, bmax):
+    inv = 1.0 / np.where(np.abs(d) < 1e-9, 1e-9, d)
+    t0, t1 = (bmin - o) * inv, (bmax - o) * inv
+    near = np.max(np.minimum(t0, t1), -1)
+    far = np.min(np.maximum(t0, t1), -1)
+    return near, far
+
+
+def human_batch(num_rays: int = 2048, seed: int = 777, time: float = 0.5, is_train: bool = True,
+                iter_val: float = 3e5, pose_sigma: float = 0.2) -> Dict[str, torch.Tensor]:
+    """SURVEY 8(d) configs 3/4 + Appendix B: one synthetic training item of the human-object branch
+    (reference kwargs of Network.forward) plus the stage-3 extras (`*_bkg`, `radii`, similarity)."""
+    rs = np.random.RandomState(seed)
+    J = tpose_joints()
+    K = J.shape[0]
+    pose = (rs.standard_normal((K, 3)) * pose_sigma).astype(np.float32)
+    pose[24:] = 0.0
+    pose_prev = pose + (rs.standard_normal((K, 3)) * 0.02).astype(np.float32)
+    pose_prev[24:] = 0.0
+
+    def rts(p):
+        Rs = np.stack([_axis_angle_to_matrix(p[i]) for i in range(K)], 0)
+        Ts = np.stack([J[0]] + [J[i] - J[SMPL_PARENT[i]] for i in range(1, K)], 0).astype(np.float32)
+        return Rs.astype(np.float32), Ts
+
+    dst_Rs, dst_Ts = rts(pose)
+    dst_Rs_prev, dst_Ts_prev = rts(pose_prev)
+    gt = np.zeros((K, 4, 4), np.float32)
+    gt[:, :3, :3] = np.eye(3)
+    gt[:, 3, 3] = 1.0
+    gt[:, :3, 3] = J                                   # chain of pure translations
+    bmin, bmax = J.min(0) - 0.6, J.max(0) + 0.6
+    prior = bone_prior_volume(J, bmin, bmax)
+
+    # posed joints (for aiming rays at the body) via the kinematic chain
+    G = [np.block([[dst_Rs[0], dst_Ts[0][:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])]
+    for i in range(1, K):
+        L = np.block([[dst_Rs[i], dst_Ts[i][:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+        G.append(G[SMPL_PARENT[i]] @ L)
+    posed = np.stack([g[:3, 3] for g in G], 0).astype(np.float32)
+    pmin, pmax = posed.min(0) - 0.6, posed.max(0) + 0.6
+
+    cam = np.array([0.3, 0.2, 3.0], np.float32)
+    tgt = posed[rs.randint(0, K, size=num_rays)] + (rs.standard_normal((num_rays, 3)) * 0.25).astype(np.float32)
+    d = tgt - cam
+    d = d / np.abs(d[:, 2:3])                           # pixel-style directions: |d_z| = 1, not unit length
+    o = np.broadcast_to(cam, d.shape).copy()
+    near, far = _ray_bbox(o, d, pmin, pmax)
+    near = np.maximum(near, 0.0)
+    bad = far <= near
+    far = np.where(bad, near + 1.0, far)
+
+    # stage-3 extras: the same rays in the (scaled) background world
+    s = 0.2
+    Rw = _axis_angle_to_matrix(np.array([0.1, -0.4, 0.05], np.float32))
+    A = np.eye(4, dtype=np.float32)
+    A[:3, :3] = s * Rw
+    A[:3, 3] = np.array([0.05, -0.02, 0.1], np.float32)
+    o_b = o @ A[:3, :3].T + A[:3, 3]
+    d_b = d @ A[:3, :3].T
+    vd = d_b / np.linalg.norm(d_b, axis=-1, keepdims=True)
+    radii = (1e-3 * rs.uniform(0.5, 2.0, size=(num_rays, 1))).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return {
+        "rays": torch.stack([t(o), t(d)], 0), "near": t(near[:, None]), "far": t(far[:, None]),
+        "dst_Rs": t(dst_Rs), "dst_Ts": t(dst_Ts), "cnl_gtfms": t(gt), "motion_weights_priors": t(prior),
+        "dst_posevec": t(pose[1:].reshape(-1) + 0.01), "dst_Rs_prev": t(dst_Rs_prev), "dst_Ts_prev": t(dst_Ts_prev),
+        "dst_posevec_prev": t(pose_prev[1:].reshape(-1) + 0.01),
+        "cnl_bbox_min_xyz": t(bmin), "cnl_bbox_max_xyz": t(bmax), "cnl_bbox_scale_xyz": t(2.0 / (bmax - bmin)),
+        "bgcolor": t(rs.uniform(0, 255, size=3)), "time": torch.tensor(float(time)), "is_train": is_train,
+        "iter_val": torch.full((1,), float(iter_val)),
+        "rays_o_bkg": t(o_b), "rays_d_bkg": t(d_b), "viewdirs_bkg": t(vd), "radii": t(radii),
+        "newsmpl_to_scale_world": t(A), "target_rgbs": t(rs.uniform(0, 1, size=(num_rays, 3))),
+        "canonical_joints": t(J),
+    }
+
+
+def human_state_dict(seed: int = 777, n_states: int = 2, small_decoder_scale: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Random-init state_dict of the reference human `Network` (64.67 M params; key names of SURVEY
+    section 5).  Xavier-uniform with ReLU gain like network_util.initseq; last layers of the offset /
+    pose heads use +-`off` (the reference uses 1e-5; a larger value exercises those paths in tests)."""
+    rs = np.random.RandomState(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, n_out, n_in, gain=math.sqrt(2.0), bound=None):
+        b = gain * math.sqrt(2.0 / (n_in + n_out)) * math.sqrt(3.0) if bound is None else bound
+        sd[name + ".weight"] = torch.from_numpy(rs.uniform(-b, b, size=(n_out, n_in)).astype(np.float32))
+        sd[name + ".bias"] = torch.zeros(n_out)
+
+    # motion-weight volume decoder (U:21-59): Linear 256->1024, 5 ConvTranspose3d
+    sd["mweight_vol_decoder.const_embedding"] = torch.from_numpy(rs.standard_normal(256).astype(np.float32))
+    lg = math.sqrt(2.0 / (1 + 0.2**2))
+    lin("mweight_vol_decoder.decoder.block_mlp.0", 1024, 256, gain=lg)
+    chans = [(1024, 512), (512, 512), (512, 256), (256, 256), (256, 27)]
+    for n, (ci, co) in enumerate(chans):
+        gain = lg if n < len(chans) - 1 else 1.0
+        std = gain * math.sqrt(2.0 / ((ci + co) * 8.0))          # ksize = 4^3 / 2^3
+        b = std * math.sqrt(3.0)
+        w = rs.uniform(-b, b, size=(ci, co, 2, 2, 2)).astype(np.float32)
+        # blockwise init (U:283-297): every 2x2x2 phase copies the (0::2,0::2,0::2) entries
+        full = np.zeros((ci, co, 4, 4, 4), np.float32)
+        for a in range(2):
+            for bb in range(2):
+                for c in range(2):
+                    full[:, :, a::2, bb::2, c::2] = w[:, :, 0:2, 0:2, 0:2]
+        sd[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"] = torch.from_numpy(full * small_decoder_scale)
+        sd[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"] = torch.zeros(co)
+    for pre in ("non_rigid_mlp", "non_rigid_forward_mlp"):
+        for i in range(6):
+            lin(f"{pre}.block_mlps.{2 * i}", 128, 164 if i == 4 else (111 if i == 0 else 128))
+        lin(f"{pre}.block_mlps.12", 3, 128, bound=1e-2)
+    for k in range(n_states):
+        sd[f"human_stateembeds.{k}"] = torch.from_numpy(rs.standard_normal(64).astype(np.float32))
+    for i in range(8):
+        lin(f"cnl_mlp.pts_linears.{2 * i}", 256, 127 if i == 0 else (383 if i == 5 else 256))
+    lin("cnl_mlp.output_linear.0", 4, 256, gain=1.0)
+    lin("pose_decoder.block_mlps.0", 256, 75)
+    lin("pose_decoder.block_mlps.2", 256, 256)
+    lin("pose_decoder.block_mlps.4", 256, 256)
+    for head in ("dstR", "dstT"):
+        lin(f"pose_decoder.block_mlps_{head}.0", 256, 256)
+        lin(f"pose_decoder.block_mlps_{head}.2", 75, 256, bound=1e-3)
+    return sd
