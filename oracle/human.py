@@ -336,7 +336,7 @@ def stage3_composite(bkg_tdist, bkg_rgb, bkg_density, human, rays_o_bkg, rays_d_
     total_order = torch.zeros(0, z_b.shape[1] + z_h.shape[1], dtype=torch.int64)
     hw = torch.zeros(0, z_h.shape[1])
     if int(fg.sum()) > 0:
-        zz, total_order = torch.sort(torch.cat([z_b[fg], z_h[fg]], -1), -1, stable=True)   # M:1565
+        zz, total_order = torch.sort(torch.cat([z_b[fg], z_h[fg]], -1), dim=-1, stable=True)   # M:1565
         allv = torch.cat([bkg[fg], hum[fg]], 1)
         allv = torch.gather(allv, 1, total_order[..., None].expand(-1, -1, 4))
         m = torch.cat([torch.ones_like(z_b[fg]), mask[fg]], -1)

@@ -1,0 +1,201 @@
+"""Golden vectors for the human-object branch (P1-P10) and the stage-3 composite (C1-C3), produced by
+running the reference (stub-imported).  Build container only:  python -m tests.golden.make_golden human
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests.golden import refload  # noqa: E402
+from hosnerf_amd import synth  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: _np(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KB, {len(arrays)} arrays")
+
+
+def _kw(batch):
+    """reference Network.forward(**kwargs) from a synth.human_batch item."""
+    skip = ("rays_o_bkg", "rays_d_bkg", "viewdirs_bkg", "radii", "newsmpl_to_scale_world")
+    return {k: v for k, v in batch.items() if k not in skip}
+
+
+def golden_human_parts(net, cfg, sd):
+    """function-level in/out (P2-P10) on small inputs."""
+    out = {}
+    b = synth.human_batch(8, seed=3)
+    with refload.stage(3):
+        from core.utils.network_util import RodriguesModule
+        rs = np.random.RandomState(5)
+        rvec = torch.from_numpy(rs.standard_normal((7, 3)).astype(np.float32) * 0.3)
+        rvec[0] = 0.0
+        out.update(rod_in=rvec, rod_out=RodriguesModule()(rvec))
+        po = net.pose_decoder(b["dst_posevec"][None])
+        out.update(pose_Rs=po["Rs"], pose_Ts=po["Ts"])
+        mb = net.motion_basis_computer(b["dst_Rs"][None], b["dst_Ts"][None], b["cnl_gtfms"][None])
+        out.update(mb_R=mb[0][0], mb_T=mb[1][0], mb_Rf=mb[2][0], mb_Tf=mb[3][0])
+        vol = net.mweight_vol_decoder(motion_weights_priors=b["motion_weights_priors"][None])[0]
+        out.update(vol_sub=vol[:, ::4, ::4, ::4], vol_sum=vol.double().sum(), vol_absmean=vol.abs().mean())
+        # LBS on 96 points spread through (and beyond) the bbox
+        J = b["canonical_joints"]
+        posed = torch.einsum("kij,kj->ki", mb[2][0], J) + mb[3][0]          # forward map of the canonical joints
+        near_body = posed[rs.randint(0, 26, size=64)] + torch.from_numpy(rs.standard_normal((64, 3)).astype(np.float32) * 0.04)
+        pts = torch.cat([near_body, torch.from_numpy(rs.uniform(-1.4, 1.4, size=(32, 3)).astype(np.float32))], 0)[None]
+        mv = net._sample_motion_fields(pts=pts, motion_scale_Rs=mb[0][0], motion_Ts=mb[1][0], motion_weights_vol=vol,
+                                       cnl_bbox_min_xyz=b["cnl_bbox_min_xyz"], cnl_bbox_scale_xyz=b["cnl_bbox_scale_xyz"],
+                                       output_list=["x_skel", "fg_likelihood_mask"])
+        out.update(lbs_pts=pts[0], lbs_x_skel=mv["x_skel"][0], lbs_mask=mv["fg_likelihood_mask"][0, :, 0])
+        cn = torch.cat([J[rs.randint(0, 26, size=64)] + torch.from_numpy(rs.standard_normal((64, 3)).astype(np.float32) * 0.04),
+                        torch.from_numpy(rs.uniform(-0.9, 0.9, size=(32, 3)).astype(np.float32))], 0)
+        fw = net._sample_motion_fields_forward(cnl_pts=cn, motion_scale_Rs_forward=mb[2][0], motion_Ts_forward=mb[3][0],
+                                               motion_weights_vol=vol, cnl_bbox_min_xyz=b["cnl_bbox_min_xyz"],
+                                               cnl_bbox_scale_xyz=b["cnl_bbox_scale_xyz"], output_list=["x_deform"])
+        out.update(flbs_pts=cn, flbs_x=fw["x_deform"])
+        # embedders
+        for it in (0.0, 150000.0, 3e5):
+            fn, _ = net.get_non_rigid_embedder(multires=6, is_identity=0, cfg=cfg, iter_val=torch.tensor(it))
+            out[f"hann_{int(it)}"] = fn(cn)
+        out["fourier"] = net.pos_embed_fn(cn)
+        fn, _ = net.get_non_rigid_embedder(multires=6, is_identity=0, cfg=cfg, iter_val=torch.tensor(3e5))
+        cond = b["dst_posevec"][None]
+        out["nonrigid_xyz"] = net.non_rigid_mlp(pos_embed=fn(cn), pos_xyz=cn, condition_code=cond.expand(96, 75))["xyz"]
+        out["nonrigid_fwd_xyz"] = net.non_rigid_forward_mlp(pos_embed=fn(cn), pos_xyz=cn, condition_code=cond.expand(96, 75))["xyz"]
+        emb = torch.cat([net.pos_embed_fn(cn), net.human_stateembeds[1].repeat(96, 1)], -1)
+        out["cnl_raw"] = net.cnl_mlp(pos_embed=emb)
+        # raw2outputs, stage-3 module-level form
+        import importlib
+        M = importlib.import_module("src.model.mipnerf360.model")
+        raw = torch.from_numpy(rs.uniform(0, 1, size=(6, 40, 4)).astype(np.float32))
+        raw[..., 3] *= 4
+        z = torch.from_numpy(np.sort(rs.uniform(2, 4, size=(6, 40)).astype(np.float32), -1))
+        rd = torch.from_numpy(rs.standard_normal((6, 3)).astype(np.float32))
+        msk = torch.from_numpy(rs.uniform(0, 1, size=(6, 40, 1)).astype(np.float32))
+        r0 = M._raw2outputs(raw, z, rd, msk)
+        r1 = M._raw2outputs(raw, z, rd, msk, bgcolor=torch.tensor([10.0, 120.0, 250.0]))
+        out.update(r2o_raw=raw, r2o_z=z, r2o_d=rd, r2o_mask=msk[..., 0], r2o_rgb=r0[0], r2o_acc=r0[1], r2o_w=r0[2],
+                   r2o_depth=r0[3], r2o_rgb_bg=r1[0])
+    save("human_parts.npz", **out)
+
+
+def golden_human_forward(net, cfg):
+    out = {}
+    cfg.defrost() if hasattr(cfg, "defrost") else None
+    for tag, time, is_train, it, perturb in (("evalA", 0.5, False, 3e5, 0.0), ("trainA", 0.5, True, 3e5, 1.0),
+                                             ("earlyB", 0.3, True, 1000.0, 0.0), ("t0C", 0.0, True, 3e5, 0.0)):
+        b = synth.human_batch(8, seed=21, time=time, is_train=is_train, iter_val=it)
+        cfg.perturb = perturb
+        seed = 77
+        torch.manual_seed(seed)
+        t_rand = torch.rand(8, 128)
+        torch.manual_seed(seed)
+        with refload.stage(3), torch.no_grad():
+            res = net(**_kw(b))
+        p = f"s3_{tag}_"
+        out[p + "meta"] = np.array([time, float(is_train), it, perturb], dtype=np.float64)
+        if perturb > 0:
+            out[p + "t_rand"] = t_rand
+        for k in ("human_rgb", "human_density", "newsmpl_pts", "pts_mask", "deform_pts_final", "observe_pts",
+                  "deform_pts_prev_final", "z_vals"):
+            if k in res and res[k] is not None:
+                out[p + k] = res[k]
+    cfg.perturb = 0.0
+    save("human_forward.npz", **out)
+
+
+def golden_stage3_step(net, cfg, hsd):
+    """Drive the reference's inline composite (M:1501-1629 training_step) on CPU -- SURVEY Appendix C.6."""
+    bsd = synth.background_state_dict(777, 2)
+    with refload.stage(3):
+        import importlib
+        M = importlib.import_module("src.model.mipnerf360.model")
+        lit = object.__new__(M.LitMipNeRF360)
+        torch.nn.Module.__init__(lit)
+        lit.model = M.MipNeRF360(cfg.basedir, opaque_background=True)
+        lit.model.load_state_dict(bsd, strict=False)
+        lit.human = net
+        lit.cfg = cfg
+        lit.near_bkg, lit.far_bkg = 0.1, 1e6
+        type(lit).trainer = property(lambda s: types.SimpleNamespace(global_step=300000))
+        lit.log = lambda *a, **k: None
+        lit.progress = lambda *a, **k: False
+        captured = {}
+
+        def fake_get_loss(net_output, idx_fg=None, human_weights_onlyfg=None, **kw):
+            captured.update(rgb=net_output["rgb"], idx_fg=idx_fg, hw=human_weights_onlyfg)
+            return net_output["rgb"].sum() * 0.0 + 1.0, {"mse": torch.tensor(0.0), "lpips": torch.tensor(0.0), "cycle": 0.0, "flow": 0.0}
+
+        lit.get_loss = fake_get_loss
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        out = {}
+        for tag, B, seed, tweak in (("A", 16, 31, None), ("tinyd", 8, 32, "tinyd"), ("nofg", 8, 33, "nofg")):
+            b = synth.human_batch(B, seed=seed, time=0.5, is_train=True, iter_val=3e5)
+            if tweak == "tinyd":
+                b["rays_d_bkg"][0, 0] = 1e-7          # forces the |d| < 1e-5 fallback for every ray (M:1526)
+                b["rays_d_bkg"][1, 1] = 5e-6
+            if tweak == "nofg":
+                b["near"] += 50.0                      # samples far outside the bbox: no foreground ray
+                b["far"] += 50.0
+            b["ray_grid"] = torch.zeros(B, 5)
+            b["newsmpl_to_camera_prev"] = torch.eye(4)
+            b["intrinsics_prev"] = torch.eye(3)
+            b["patch_masks"] = torch.ones(1, 1, B, dtype=torch.bool)
+            b["target_patches"] = torch.zeros(1, 1, B, 3)
+            b["patch_div_indices"] = torch.tensor([0, B])
+            cfg.perturb = 0.0
+            orders = []
+            real_sort = torch.sort
+
+            def spy_sort(*a, **k):
+                r = real_sort(*a, **k)
+                if a[0].dim() == 2 and a[0].shape[1] == 160:
+                    orders.append(r[1])
+                return r
+
+            torch.sort = spy_sort
+            torch.manual_seed(seed)
+            jit = [torch.rand(B, 1) for _ in range(3)]
+            torch.manual_seed(seed)
+            try:
+                batch = {k: (v[None] if isinstance(v, torch.Tensor) else torch.tensor(v)[None]) for k, v in b.items()}
+                lit.training_step(batch, 0)
+            finally:
+                torch.sort = real_sort
+            p = f"c_{tag}_"
+            for l in range(3):
+                out[p + f"jitter{l}"] = jit[l]
+            out[p + "rgb"] = captured["rgb"]
+            out[p + "idx_fg"] = captured["idx_fg"]
+            out[p + "human_weights_onlyfg"] = captured["hw"]
+            out[p + "total_order"] = orders[-1] if orders else np.zeros((0, 160), np.int64)
+    save("stage3_step.npz", **out)
+
+
+def main():
+    assert refload.available()
+    cfg, net = refload.human_network(3, transitions=(0.4,))
+    hsd = synth.human_state_dict(777, 2)
+    print(net.load_state_dict(hsd, strict=True))
+    net.eval()
+    golden_human_parts(net, cfg, hsd)
+    golden_human_forward(net, cfg)
+    golden_stage3_step(net, cfg, hsd)
+
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,14 @@ def human_cfg(n: int = 3, transitions=(0.4,)):
     with stage(n):
         from third_parties.yacs import CfgNode as CN
         cfg = CN()
+        # run.py:33-49 defaults that precede the yaml merge
+        cfg.resume = False
+        cfg.eval_iter = 10000000
+        cfg.render_folder_name = ""
+        cfg.ignore_non_rigid_motions = False
+        cfg.render_skip = 1
+        cfg.render_frames = 100
+        cfg.num_workers = 4
         cfg.merge_from_file("configs/default.yaml")
         cfg.merge_from_file("configs/human_nerf/wild/monocular/adventure.yaml")
         cfg.basedir = make_basedir(transitions)
