@@ -215,6 +215,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
                             if (col == a.aux_col) { a.aux[row] = softplus_f(v + a.p0); continue; }
                             break;
                         case HOS_EPI_SIGMOID_RELU4: v = (col < 3) ? sigmoid_f(v) : fmaxf(v, 0.f); break;
+                        case HOS_EPI_RESIDUAL: v += a.mask[(size_t)row * a.ldmask + col]; break;
                         default: break;
                     }
                     a.C[(size_t)row * a.ldc + col] = v;
@@ -285,12 +286,14 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
     if ((epilogue == HOS_EPI_DENSITY || epilogue == HOS_EPI_NERF_HEAD) && !aux) return HOS_E_ARG;
     if (epilogue == HOS_EPI_DENSITY && N != 1) return HOS_E_SHAPE;
     if (epilogue == HOS_EPI_SIGMOID_RELU4 && N != 4) return HOS_E_SHAPE;
+    if (epilogue == HOS_EPI_RESIDUAL && !aux) return HOS_E_ARG;
     GemmArgs a{};
     a.A0 = A0; a.lda0 = lda0; a.kt0 = K0 / BK; a.A1 = A1; a.lda1 = lda1;
     a.B = W; a.ldb = ldw; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.Mload = M; a.Nload = N;
     a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk;
     a.bias = bias; a.aux = aux; a.aux_col = aux_col; a.p0 = p0; a.p1 = p1; a.epi = epilogue;
+    if (epilogue == HOS_EPI_RESIDUAL) { a.mask = aux; a.ldmask = aux_col; }   // residual [M, ld=aux_col]
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N <= 32) {
         a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 32);

@@ -1,0 +1,448 @@
+"""State-conditional human-object renderer (HumanNeRF-style) on MI355X.
+
+Drop-in mirror of `core/nets/human_nerf/network.py::Network` of the reference (stage 3, N:27-698; the
+stage-2 variant composites inside, `stage=2`): same constructor (`Network(cfg)`), same
+`forward(rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec, near, far, iter_val, **kwargs)`
+signature (swallows arbitrary extra kwargs), same output dict, same state_dict keys
+(`mweight_vol_decoder.*`, `non_rigid_mlp.*`, `non_rigid_forward_mlp.*`, `cnl_mlp.*`, `pose_decoder.*`,
+`human_stateembeds.*`).
+
+Per-step prologue (P2-P4: pose refiner MLP on one 75-vector, 26-joint kinematic chain, the 5-layer
+ConvTranspose3d volume decoder) runs as torch ops on the device -- once per call, a few launches
+(SURVEY 2.2 marks MIOpen/rocBLAS acceptable there).  Everything per sample point (P5-P10) is HIP:
+sample+backward-LBS warp, hann/Fourier embedders, fp32-MFMA MLPs, forward LBS.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .flat import FlatModule, FlatStore, Region
+from .mipnerf360 import select_state, _Lin
+
+SMPL_PARENT = {1: 0, 2: 0, 3: 0, 4: 1, 5: 2, 6: 3, 7: 4, 8: 5, 9: 6, 10: 7, 11: 8, 12: 9, 13: 9, 14: 9, 15: 12,
+               16: 13, 17: 14, 18: 16, 19: 17, 20: 18, 21: 19, 22: 20, 23: 21, 24: 23, 25: 22}   # U:100-103
+
+
+class Cfg(dict):
+    """Minimal attribute-access config (the reference uses a vendored yacs CfgNode; any object with the same
+    attributes works, including that CfgNode)."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def default_cfg(basedir: Optional[str] = None) -> Cfg:
+    """configs/default.yaml merged with configs/human_nerf/wild/monocular/adventure.yaml (hot-path fields)."""
+    return Cfg(
+        basedir=basedir, total_bones=26, N_samples=128, perturb=1.0, chunk=8192, chunk_bkg=8192, netchunk_per_gpu=10000,
+        ignore_non_rigid_motions=False,
+        canonical_mlp=Cfg(mlp_depth=8, mlp_width=256, multires=10, i_embed=0),
+        mweight_volume=Cfg(embedding_size=256, volume_size=32),
+        non_rigid_motion_mlp=Cfg(condition_code_size=75, mlp_width=128, mlp_depth=6, skips=[4], multires=6, i_embed=0,
+                                 kick_in_iter=100000, full_band_iter=200000),
+        non_rigid_forward_mlp=Cfg(condition_code_size=75, mlp_width=128, mlp_depth=6, skips=[4], multires=6, i_embed=0),
+        pose_decoder=Cfg(embedding_size=75, mlp_width=256, mlp_depth=4, kick_in_iter=20000),
+    )
+
+
+def _xavier_(w: torch.Tensor, gain: float, fan_sum: float):
+    b = gain * math.sqrt(2.0 / fan_sum) * math.sqrt(3.0)
+    w.uniform_(-b, b)
+
+
+class _LayerSpec:
+    __slots__ = ("W", "b", "N", "K", "Kpad", "Npad")
+
+    def __init__(self, store: FlatStore, N: int, K: int, Kpad: Optional[int] = None):
+        self.N, self.K = N, K
+        self.Kpad, self.Npad = (ops.round_up(K, 32) if Kpad is None else Kpad), ops.round_up(N, 32)
+        self.W = store.alloc(N, K, self.Npad, self.Kpad)
+        self.b = store.alloc(1, N, 1, self.Npad)
+
+    def bind(self, store: FlatStore) -> _Lin:
+        return _Lin(store.bind(self.W, (slice(0, self.N), slice(0, self.K)), (self.N, self.K)),
+                    store.bind(self.b, (0, slice(0, self.N)), (self.N,)))
+
+
+class _Holder(nn.Module):
+    pass
+
+
+NR_LDE = 128      # [cond(75) | hann features(36) | 0]  -> first-layer input row of the non-rigid MLPs
+NR_LDPE = 64      # hann features alone (36, zero padded) for the skip concat
+CNL_LDE = 128     # [fourier(63) | state(64) | 0]
+CNL_CAT = 384     # skip-concat row [fourier+state (127) | h (256) | 0]
+
+
+class Network(FlatModule):
+    def __init__(self, cfg, stage: int = 3):
+        super().__init__()
+        self.cfg = cfg
+        self.stage = stage
+        K = cfg.total_bones
+        if K != 26 or cfg.N_samples > 256 or cfg.canonical_mlp.mlp_width != 256 or cfg.canonical_mlp.mlp_depth != 8 \
+                or cfg.canonical_mlp.multires != 10 or cfg.non_rigid_motion_mlp.mlp_width != 128 \
+                or cfg.non_rigid_motion_mlp.mlp_depth != 6 or list(cfg.non_rigid_motion_mlp.skips) != [4] \
+                or cfg.non_rigid_motion_mlp.multires != 6 or cfg.non_rigid_motion_mlp.condition_code_size != 75 \
+                or cfg.mweight_volume.volume_size != 32 or cfg.pose_decoder.mlp_depth != 4 \
+                or getattr(cfg, "ignore_non_rigid_motions", False):
+            raise NotImplementedError("hosnerf_amd implements the configuration the reference ships (default.yaml + adventure.yaml)")
+        st = self.store
+        V = cfg.mweight_volume.volume_size
+
+        # ---- parameters that feed torch ops (prologue): natural shapes, still inside the flat buffer
+        def plain(shape):
+            n = int(np.prod(shape))
+            r = st.alloc(1, n)
+            return r, tuple(shape)
+
+        pl = {}
+        pl["mweight_vol_decoder.const_embedding"] = plain((cfg.mweight_volume.embedding_size,))
+        pl["mweight_vol_decoder.decoder.block_mlp.0.weight"] = plain((1024, cfg.mweight_volume.embedding_size))
+        pl["mweight_vol_decoder.decoder.block_mlp.0.bias"] = plain((1024,))
+        chans, ci, co = [], 1024, 512
+        for _ in range(int(np.log2(V)) - 1):                      # U:31-44
+            chans.append((ci, co))
+            if ci == co:
+                co = ci // 2
+            else:
+                ci = co
+        chans.append((ci, K + 1))
+        self._deconv_chans = chans
+        for n, (a, b) in enumerate(chans):
+            pl[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"] = plain((a, b, 4, 4, 4))
+            pl[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"] = plain((b,))
+        pw, pe = cfg.pose_decoder.mlp_width, cfg.pose_decoder.embedding_size
+        for name, shp in (("block_mlps.0", (pw, pe)), ("block_mlps.2", (pw, pw)), ("block_mlps.4", (pw, pw)),
+                          ("block_mlps_dstR.0", (pw, pw)), ("block_mlps_dstR.2", (3 * (K - 1), pw)),
+                          ("block_mlps_dstT.0", (pw, pw)), ("block_mlps_dstT.2", (3 * (K - 1), pw))):
+            pl[f"pose_decoder.{name}.weight"] = plain(shp)
+            pl[f"pose_decoder.{name}.bias"] = plain((shp[0],))
+
+        # ---- HIP MLPs: zero-padded GEMM layouts
+        def nonrigid_specs():
+            L = [_LayerSpec(st, 128, 111, NR_LDE)]
+            for i in range(1, 6):
+                L.append(_LayerSpec(st, 128, 164, 128 + NR_LDPE) if i == 4 else _LayerSpec(st, 128, 128))
+            L.append(_LayerSpec(st, 3, 128))
+            return L
+
+        self._nr = nonrigid_specs()
+        self._nrf = nonrigid_specs()
+        self._cnl = [_LayerSpec(st, 256, 127, CNL_LDE)]
+        for i in range(1, 8):
+            self._cnl.append(_LayerSpec(st, 256, 383, CNL_CAT) if i == 5 else _LayerSpec(st, 256, 256))
+        self._cnl.append(_LayerSpec(st, 4, 256))
+
+        tt_path = os.path.join(cfg.basedir, "transitions_times.json") if getattr(cfg, "basedir", None) else None
+        if tt_path is not None and os.path.exists(tt_path):
+            with open(tt_path, "r") as f:
+                infos = json.load(f)
+            self.transitions_times = np.stack([np.array(infos[k]["time"], dtype=np.float32) for k in infos], axis=0)
+            n_states = self.transitions_times.shape[0] + 1
+        else:
+            self.transitions_times = None
+            n_states = 1
+        self._embeds = st.alloc(n_states, 64)
+        st.materialize()
+
+        # ---- module tree with the reference's names
+        def tree_set(root: nn.Module, dotted: str, param: nn.Parameter):
+            parts = dotted.split(".")
+            m = root
+            for p_ in parts[:-1]:
+                if not hasattr(m, p_):
+                    setattr(m, p_, _Holder())
+                m = getattr(m, p_)
+            setattr(m, parts[-1], param)
+
+        self._plain: Dict[str, nn.Parameter] = {}
+        for name, (region, shape) in pl.items():
+            p_ = st.bind(region, (0, slice(0, region.cols)), shape)
+            self._plain[name] = p_
+            tree_set(self, name, p_)
+
+        def attach(prefix: str, specs: List[_LayerSpec], attr: str, idxs: List[int]):
+            holder = _Holder()
+            md = _Holder()
+            for L, i in zip(specs, idxs):
+                setattr(md, str(i), L.bind(st))
+            setattr(holder, attr, md)
+            return holder
+
+        self.non_rigid_mlp = attach("non_rigid_mlp", self._nr, "block_mlps", [0, 2, 4, 6, 8, 10, 12])
+        self.non_rigid_forward_mlp = attach("non_rigid_forward_mlp", self._nrf, "block_mlps", [0, 2, 4, 6, 8, 10, 12])
+        self.cnl_mlp = attach("cnl_mlp", self._cnl[:-1], "pts_linears", [0, 2, 4, 6, 8, 10, 12, 14])
+        out_holder = _Holder()
+        setattr(out_holder, "0", self._cnl[-1].bind(st))
+        self.cnl_mlp.output_linear = out_holder
+        self.human_stateembeds = nn.ParameterList([st.bind(self._embeds, (k, slice(None)), (64,)) for k in range(n_states)])
+        self.reset_parameters()
+        self._token = torch.zeros(1, requires_grad=True)
+
+    # ------------------------------------------------------------------ init (U:181-308 initseq rules)
+    @torch.no_grad()
+    def reset_parameters(self):
+        relu = math.sqrt(2.0)
+        lrelu = math.sqrt(2.0 / (1 + 0.2**2))
+        P = self._plain
+        P["mweight_vol_decoder.const_embedding"].normal_()
+        w = P["mweight_vol_decoder.decoder.block_mlp.0.weight"]
+        _xavier_(w, lrelu, w.shape[0] + w.shape[1])
+        P["mweight_vol_decoder.decoder.block_mlp.0.bias"].zero_()
+        for n, (a, b) in enumerate(self._deconv_chans):
+            w = P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"]
+            gain = lrelu if n < len(self._deconv_chans) - 1 else 1.0
+            _xavier_(w, gain, (a + b) * 8.0)
+            base = w[:, :, 0::2, 0::2, 0::2].clone()
+            for i in range(2):
+                for j in range(2):
+                    for k in range(2):
+                        w[:, :, i::2, j::2, k::2] = base
+            P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"].zero_()
+        for name in ("block_mlps.0", "block_mlps.2", "block_mlps.4", "block_mlps_dstR.0", "block_mlps_dstT.0"):
+            w = P[f"pose_decoder.{name}.weight"]
+            _xavier_(w, relu, w.shape[0] + w.shape[1])
+            P[f"pose_decoder.{name}.bias"].zero_()
+        for head in ("dstR", "dstT"):
+            P[f"pose_decoder.block_mlps_{head}.2.weight"].uniform_(-1e-5, 1e-5)
+            P[f"pose_decoder.block_mlps_{head}.2.bias"].zero_()
+        for holder in (self.non_rigid_mlp, self.non_rigid_forward_mlp):
+            for i in (0, 2, 4, 6, 8, 10):
+                lin = getattr(holder.block_mlps, str(i))
+                _xavier_(lin.weight, relu, lin.weight.shape[0] + lin.weight.shape[1])
+                lin.bias.zero_()
+            last = getattr(holder.block_mlps, "12")
+            last.weight.uniform_(-1e-5, 1e-5)
+            last.bias.zero_()
+        for i in range(0, 16, 2):
+            lin = getattr(self.cnl_mlp.pts_linears, str(i))
+            _xavier_(lin.weight, relu, lin.weight.shape[0] + lin.weight.shape[1])
+            lin.bias.zero_()
+        lin = getattr(self.cnl_mlp.output_linear, "0")
+        _xavier_(lin.weight, 1.0, lin.weight.shape[0] + lin.weight.shape[1])
+        lin.bias.zero_()
+        for e in self.human_stateembeds:
+            e.normal_()
+
+    def _after_flat_move(self):
+        self._token = torch.zeros(1, device=self.store.param.device, requires_grad=True)
+
+    def _w(self, L: _LayerSpec, grad: bool = False):
+        flat = self.store.grad if grad else self.store.param
+        return L.W.view(flat), L.b.view(flat).view(-1)
+
+    # ------------------------------------------------------------------ prologue (torch ops, once per call)
+    def _pose_refine(self, Rs, Ts, posevec):
+        """N:589-605 + pose_decoders/mlp_delta_body_pose.py + U:66-92."""
+        P = self._plain
+        h = posevec[None]
+        for name in ("block_mlps.0", "block_mlps.2", "block_mlps.4"):
+            h = torch.relu(F.linear(h, P[f"pose_decoder.{name}.weight"], P[f"pose_decoder.{name}.bias"]))
+
+        def head(tag):
+            y = torch.relu(F.linear(h, P[f"pose_decoder.block_mlps_{tag}.0.weight"], P[f"pose_decoder.block_mlps_{tag}.0.bias"]))
+            return F.linear(y, P[f"pose_decoder.block_mlps_{tag}.2.weight"], P[f"pose_decoder.block_mlps_{tag}.2.bias"])
+
+        rvec = head("dstR").view(-1, 3)
+        theta = torch.sqrt(1e-5 + torch.sum(rvec**2, dim=1))
+        r = rvec / theta[:, None]
+        c, s = torch.cos(theta), torch.sin(theta)
+        x, y, z = r[:, 0], r[:, 1], r[:, 2]
+        dR = torch.stack([x * x + (1 - x * x) * c, x * y * (1 - c) - z * s, x * z * (1 - c) + y * s,
+                          x * y * (1 - c) + z * s, y * y + (1 - y * y) * c, y * z * (1 - c) - x * s,
+                          x * z * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z + (1 - z * z) * c], dim=1).view(-1, 3, 3)
+        dT = head("dstT").view(-1, 3)
+        Rs = torch.cat([Rs[0:1], torch.matmul(Rs[1:], dR)], 0)
+        Ts = torch.cat([Ts[0:1], Ts[1:] + dT], 0)
+        return Rs, Ts
+
+    @staticmethod
+    def _motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
+        """U:134-174."""
+        K = dst_Rs.shape[0]
+        G = torch.zeros(K, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
+        G[:, :3, :3] = dst_Rs
+        G[:, :3, 3] = dst_Ts
+        G[:, 3, 3] = 1.0
+        chain = [G[0]]
+        for i in range(1, K):
+            chain.append(chain[SMPL_PARENT[i]] @ G[i])
+        dst = torch.stack(chain, 0)
+        bwd = cnl_gtfms @ torch.inverse(dst)
+        fwd = dst @ torch.inverse(cnl_gtfms)
+        return (bwd[:, :3, :3].contiguous(), bwd[:, :3, 3].contiguous(),
+                fwd[:, :3, :3].contiguous(), fwd[:, :3, 3].contiguous())
+
+    def _motion_weight_volume(self, priors):
+        """deconv_vol_decoder.py:34-42 + U:21-59 -> [K+1, V, V, V]."""
+        P = self._plain
+        h = F.leaky_relu(F.linear(P["mweight_vol_decoder.const_embedding"][None],
+                                  P["mweight_vol_decoder.decoder.block_mlp.0.weight"],
+                                  P["mweight_vol_decoder.decoder.block_mlp.0.bias"]), 0.2).view(-1, 1024, 1, 1, 1)
+        n_conv = len(self._deconv_chans)
+        for n in range(n_conv):
+            h = F.conv_transpose3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
+                                   P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], stride=2, padding=1)
+            if n < n_conv - 1:
+                h = F.leaky_relu(h, 0.2)
+        return F.softmax(h + torch.log(priors[None]), dim=1)[0].contiguous()
+
+    def _band_weights(self, iter_val: float, device) -> torch.Tensor:
+        """hannw_fourier.py:29-44 (evaluated with torch on the host, 6 floats)."""
+        c = self.cfg.non_rigid_motion_mlp
+        kick = torch.tensor(float(c.kick_in_iter), dtype=torch.float32)
+        t = torch.clamp(torch.tensor(float(iter_val), dtype=torch.float32) - kick, min=0.0)
+        Nn = c.full_band_iter - kick
+        alpha = c.multires * t / Nn
+        j = torch.arange(c.multires, dtype=torch.float32)
+        return ((1.0 - torch.cos(np.pi * torch.clamp(alpha - j, min=0.0, max=1.0))) / 2.0).to(device)
+
+    # ------------------------------------------------------------------ HIP MLP chains (forward)
+    def _nonrigid_fwd(self, specs: List[_LayerSpec], x: torch.Tensor, cond: torch.Tensor, band_w: torch.Tensor, save: bool):
+        """mlp_offset.py:54-70: xyz + MLP([cond | hann(x)]) with the hann features re-concatenated before Linear #4."""
+        Pn = x.shape[0]
+        dev = x.device
+        E = torch.empty(Pn, NR_LDE, device=dev)
+        PE = torch.empty(Pn, NR_LDPE, device=dev)
+        ops.embed_hannw(x, band_w, cond.reshape(-1), E, PE)
+        acts = []
+        h = E
+        for i in range(6):
+            L = specs[i]
+            Wt, bt = self._w(L)
+            out = torch.empty(Pn, 128, device=dev)
+            if i == 4:
+                ops.linear_fwd(h, 128, Wt, bt, 128, out, ops.EPI_RELU, A1=PE, K1=NR_LDPE)
+            else:
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 128, out, ops.EPI_RELU)
+            acts.append(out)
+            h = out
+        Wt, bt = self._w(specs[6])
+        xyz = torch.empty(Pn, 3, device=dev)
+        ops.linear_fwd(h, 128, Wt, bt, 3, xyz, ops.EPI_RESIDUAL, aux=x)
+        return xyz, ((E, PE, acts) if save else None)
+
+    def _canonical_fwd(self, cnl: torch.Tensor, state: int, save: bool):
+        """mlp_rgb_sigma.py:49-58 + N:539-540: [P,4] = (sigmoid rgb, relu sigma)."""
+        Pn = cnl.shape[0]
+        dev = cnl.device
+        E = torch.empty(Pn, CNL_LDE, device=dev)
+        CAT = torch.empty(Pn, CNL_CAT, device=dev)
+        CAT[:, CNL_CAT - 1].zero_()
+        embed = self._embeds.view(self.store.param)[state]
+        ops.embed_fourier(cnl, 10, embed, E, CAT)
+        acts = []
+        h = E
+        for i in range(8):
+            L = self._cnl[i]
+            Wt, bt = self._w(L)
+            if i == 4:      # its output feeds the skip concat: write it at column 127 of CAT
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, CAT, ops.EPI_RELU, out_col0=127)
+                acts.append(CAT)
+                h = CAT
+            else:
+                out = torch.empty(Pn, 256, device=dev)
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, out, ops.EPI_RELU)
+                acts.append(out)
+                h = out
+        Wt, bt = self._w(self._cnl[8])
+        raw = torch.empty(Pn, 4, device=dev)
+        ops.linear_fwd(h, 256, Wt, bt, 4, raw, ops.EPI_SIGMOID_RELU4)
+        return raw, ((E, acts) if save else None)
+
+    # ------------------------------------------------------------------ reference-style forward
+    def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None, near=None, far=None,
+                iter_val=1e7, t_rand=None, **kwargs):
+        cfg = self.cfg
+        dev = rays.device
+        K = cfg.total_bones
+        iter_v = float(torch.as_tensor(iter_val).reshape(-1)[0])
+        time = float(kwargs["time"])
+        is_train = bool(kwargs["is_train"])
+        flow = time > 0.005 and is_train
+        state = select_state(time, self.transitions_times)
+        nr_kick = cfg.non_rigid_motion_mlp.kick_in_iter
+
+        def refine(Rs, Ts, pv):
+            if iter_v >= cfg.pose_decoder.get("kick_in_iter", 0):
+                return self._pose_refine(Rs, Ts, pv)
+            return Rs, Ts
+
+        def cond_of(pv):
+            return torch.zeros_like(pv) * pv if iter_v < nr_kick else pv          # N:653-656
+
+        Rs, Ts = refine(dst_Rs, dst_Ts, dst_posevec)
+        R_b, T_b, R_f, T_f = self._motion_basis(Rs, Ts, cnl_gtfms)
+        if flow:
+            Rp, Tp = refine(kwargs["dst_Rs_prev"], kwargs["dst_Ts_prev"], kwargs["dst_posevec_prev"])
+            _, _, R_fp, T_fp = self._motion_basis(Rp, Tp, cnl_gtfms)
+            cond_prev = cond_of(kwargs["dst_posevec_prev"]).contiguous()
+        band_w = self._band_weights(iter_v, dev)
+        cond = cond_of(dst_posevec).contiguous()
+        vol = self._motion_weight_volume(motion_weights_priors)
+        vol_cl = None
+        bmin = kwargs["cnl_bbox_min_xyz"].contiguous()
+        bscale = kwargs["cnl_bbox_scale_xyz"].contiguous()
+
+        rays_o = rays[0].reshape(-1, 3).float().contiguous()
+        rays_d = rays[1].reshape(-1, 3).float().contiguous()
+        B = rays_o.shape[0]
+        N = cfg.N_samples
+        if t_rand is None and cfg.perturb > 0.0:
+            t_rand = torch.rand(B, N, device=dev)                                  # N:421
+        outs: Dict[str, List[torch.Tensor]] = {}
+        chunk = int(cfg.chunk)
+        for c0 in range(0, B, chunk):
+            sl = slice(c0, min(B, c0 + chunk))
+            tr = None if t_rand is None else t_rand[sl].contiguous()
+            z, pts, x_skel, mask = ops.human_sample_warp(rays_o[sl], rays_d[sl], near[sl].contiguous(), far[sl].contiguous(),
+                                                         N, R_b, T_b, vol, bmin, bscale, tr, K)
+            cnl, _ = self._nonrigid_fwd(self._nr, x_skel, cond, band_w, save=False)
+            raw, _ = self._canonical_fwd(cnl, state, save=False)
+            b = z.shape[0]
+            ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
+                   "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
+            if flow or True:
+                if vol_cl is None:   # channel-last copy of the K bone channels for the K-channel forward tap
+                    vol_cl = torch.zeros(vol.shape[1], vol.shape[2], vol.shape[3], 32, device=dev)
+                    vol_cl[..., :K] = vol[:K].permute(1, 2, 3, 0)
+            if flow:                                                               # N:474-502
+                d_prev = ops.lbs_forward(cnl, R_fp, T_fp, vol_cl, bmin, bscale, K)
+                dp, _ = self._nonrigid_fwd(self._nrf, d_prev, cond_prev, band_w, save=False)
+                ret["deform_pts_prev_final"] = dp.view(b, N, 3)
+            sel = torch.nonzero(mask > 0.005).reshape(-1)                          # N:505-536 (data-dependent size)
+            if sel.numel() > 0:
+                cnl_sel = cnl.index_select(0, sel)
+                d_cur = ops.lbs_forward(cnl_sel, R_f, T_f, vol_cl, bmin, bscale, K)
+                dc, _ = self._nonrigid_fwd(self._nrf, d_cur, cond, band_w, save=False)
+                ret["deform_pts_final"] = dc
+                ret["observe_pts"] = pts.view(-1, 3).index_select(0, sel)
+            else:
+                ret["deform_pts_final"] = pts[0, 0][None]
+                ret["observe_pts"] = pts[0, 0][None]
+            if not flow:
+                ret["z_vals"] = z
+                ret["rays_d"] = rays_d[sl]
+            for k, v in ret.items():
+                outs.setdefault(k, []).append(v)
+        all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}
+        all_ret["bgcolor"] = kwargs.get("bgcolor")
+        return all_ret

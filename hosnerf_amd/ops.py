@@ -16,7 +16,7 @@ from ._lib import call, ptr
 
 EPS = 1.1920929e-07
 
-EPI_NONE, EPI_RELU, EPI_DENSITY, EPI_RGB, EPI_NERF_HEAD, EPI_SIGMOID_RELU4 = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_RELU, EPI_DENSITY, EPI_RGB, EPI_NERF_HEAD, EPI_SIGMOID_RELU4, EPI_RESIDUAL = 0, 1, 2, 3, 4, 5, 6
 
 
 def round_up(x: int, m: int) -> int:
@@ -72,12 +72,15 @@ def _timed(key, flops, launch):
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
                out: Optional[torch.Tensor], epilogue: int = EPI_NONE, A1: Optional[torch.Tensor] = None,
                K1: int = 0, aux: Optional[torch.Tensor] = None, aux_col: int = -1, p0: float = 0.0,
-               ldc: Optional[int] = None, M: Optional[int] = None):
-    """out[M,N] = epi([A0[:, :K0] | A1[:, :K1]] @ W[:N, :K0+K1]^T + bias).  W is a [rows, ldw] buffer."""
+               ldc: Optional[int] = None, M: Optional[int] = None, out_col0: int = 0):
+    """out[M, out_col0:out_col0+N] = epi([A0[:, :K0] | A1[:, :K1]] @ W[:N, :K0+K1]^T + bias).  W is a [rows, ldw] buffer.
+    For EPI_RESIDUAL `aux` is the residual matrix [M, >=N] (its row stride is passed as aux_col)."""
     M = A0.shape[0] if M is None else M
+    if epilogue == EPI_RESIDUAL:
+        aux_col = aux.stride(0)
     _timed(f"gemm_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linear_fwd", ptr(A0), A0.stride(0), K0, ptr(A1), 0 if A1 is None else A1.stride(0), K1,
-        ptr(W), W.stride(0), ptr(bias), ptr(out), (0 if out is None else out.stride(0)) if ldc is None else ldc,
+        ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, (0 if out is None else out.stride(0)) if ldc is None else ldc,
         M, N, epilogue, ptr(aux), aux_col, float(p0), 0.0))
     return out
 
@@ -281,3 +284,49 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, sumsq_buf=None, max_norm=0.0):
     call("hos_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
          float(eps), int(step), float(grad_scale), ptr(sumsq_buf), float(max_norm))
+
+
+# ------------------------------------------------------------------------------------------ human branch
+_T_CACHE = {}
+
+
+def _t_vals(N: int, device) -> torch.Tensor:
+    key = (N, str(device))
+    if key not in _T_CACHE:
+        _T_CACHE[key] = torch.linspace(0.0, 1.0, steps=N).to(device)      # N:410, built by torch for bit-exactness
+    return _T_CACHE[key]
+
+
+def human_sample_warp(rays_o, rays_d, near, far, N: int, R, T, vol, bbox_min, bbox_scale, t_rand=None, K: int = 26):
+    """(z_vals [B,N], pts [B,N,3], x_skel [B*N,3], mask [B*N]) -- N:409-424, N:451, N:304-355 fused."""
+    B = rays_o.shape[0]
+    dev = rays_o.device
+    z = torch.empty(B, N, device=dev)
+    pts = torch.empty(B, N, 3, device=dev)
+    x_skel = torch.empty(B * N, 3, device=dev)
+    mask = torch.empty(B * N, device=dev)
+    V = vol.shape[-1]
+    call("hos_human_sample_warp", ptr(rays_o), ptr(rays_d), ptr(near.reshape(-1)), ptr(far.reshape(-1)),
+         ptr(_t_vals(N, dev)), ptr(None if t_rand is None else t_rand.reshape(-1)), ptr(R), ptr(T), ptr(vol), V,
+         ptr(bbox_min), ptr(bbox_scale), B, N, K, ptr(z), ptr(pts), ptr(x_skel), ptr(mask))
+    return z, pts, x_skel, mask
+
+
+def lbs_forward(cnl_pts, R_f, T_f, vol_cl, bbox_min, bbox_scale, K: int = 26):
+    P = cnl_pts.shape[0]
+    out = torch.empty(P, 3, device=cnl_pts.device)
+    V, CL = vol_cl.shape[0], vol_cl.shape[-1]
+    call("hos_lbs_forward", ptr(cnl_pts), ptr(R_f), ptr(T_f), ptr(vol_cl), V, CL, ptr(bbox_min), ptr(bbox_scale), P, K, ptr(out))
+    return out
+
+
+def embed_hannw(x, band_w, cond, E, PE=None):
+    P = x.shape[0]
+    call("hos_embed_hannw", ptr(x), ptr(band_w), band_w.numel(), ptr(cond), 0 if cond is None else cond.numel(), P,
+         ptr(E), E.stride(0), ptr(PE), 0 if PE is None else PE.stride(0))
+
+
+def embed_fourier(x, num_freqs, state, E, E2=None):
+    P = x.shape[0]
+    call("hos_embed_fourier", ptr(x), num_freqs, ptr(state), 0 if state is None else state.numel(), P,
+         ptr(E), E.stride(0), ptr(E2), 0 if E2 is None else E2.stride(0))

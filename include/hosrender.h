@@ -53,6 +53,7 @@ const char* hos_error_string(int code);
 #define HOS_EPI_RGB 3        /* C = sigmoid(acc+bias)*(1+2*pad) - pad               (M:345-346)*/
 #define HOS_EPI_NERF_HEAD 4  /* cols < aux_col: C = acc+bias; col == aux_col: aux[m] = softplus(acc+bias+density_bias) */
 #define HOS_EPI_SIGMOID_RELU4 5 /* N==4: cols 0..2 sigmoid, col 3 relu (N:539-540)             */
+#define HOS_EPI_RESIDUAL 6   /* C = acc + bias + aux[m*aux_col + n]  (xyz + offset, mlp_offset.py:66; aux_col = ld of aux) */
 
 /* C[M,N] = epi( [A0 | A1][M, K0+K1] @ W[N, K0+K1]^T + bias[N] ).
  * A1 may be NULL (K1 = 0); K0, K1 multiples of 32; W row n starts at W + n*ldw.  */
@@ -140,6 +141,40 @@ int hos_distortion_bwd(const float* t, const float* w, int B, int S, float scale
 int hos_head_grad(const float* g_density, const float* density, const float* g_rgb, const float* rgb,
                   int P, float rgb_padding, float* dz_density, int ld_dd, int col_dd,
                   float* dz_rgb, int ld_dr, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Human-object branch, per-sample kernels (N: = core/nets/human_nerf/network.py of stage 3).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Ray samples + backward LBS warp: replaces N:409-424 (_get_samples_along_ray, _stratified_sampling),
+ * N:451 (pts = o + d z) and N:304-355 (_sample_motion_fields: 26 rigid maps, 26 single-channel
+ * grid_sample taps, weight-normalised blend).
+ *   t_vals [N] = torch.linspace(0,1,N) (host supplies it);  t_rand [B*N] uniform draws or NULL (cfg.perturb == 0)
+ *   R [K,3,3], T [K,3] backward motion basis;  vol [>=K, V,V,V] motion-weight volume (z,y,x order)
+ *   outputs: z_vals [B*N] (may be NULL), pts [B*N,3] (may be NULL), x_skel [B*N,3], mask [B*N]. */
+int hos_human_sample_warp(const float* rays_o, const float* rays_d, const float* near_, const float* far_,
+                          const float* t_vals, const float* t_rand, const float* R, const float* T,
+                          const float* vol, int V, const float* bbox_min, const float* bbox_scale,
+                          int B, int N, int K, float* z_vals, float* pts, float* x_skel, float* mask,
+                          hos_stream_t stream);
+
+/* Forward LBS (N:357-399): one K-channel tap at each canonical point, blend of the K forward maps.
+ * vol_cl is the volume in channel-LAST layout [V,V,V,CL] (CL >= K, multiple of 4). */
+int hos_lbs_forward(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
+                    int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
+                    float* x_deform, hos_stream_t stream);
+
+/* Hann-windowed positional encoding of the non-rigid MLP (embedders/hannw_fourier.py:15-71) written
+ * as the MLP's first-layer input row  E[p] = [cond(cond_size) | w_j sin(2^j x), w_j cos(2^j x) | 0]
+ * (mlp_offset.py:55) and optionally the features alone into PE [P, ldpe] for the skip concat (:59-60). */
+int hos_embed_hannw(const float* x, const float* band_w, int num_freqs, const float* cond, int cond_size,
+                    int64_t P, float* E, int lde, float* PE, int ldpe, hos_stream_t stream);
+
+/* Canonical-MLP input row  E[p] = [x, sin(2^j x), cos(2^j x) (j<num_freqs) | state embedding | 0]
+ * (embedders/fourier.py:11-57, N:248-249); E2 (optional) receives the same 3+6F+state_size columns
+ * (the skip-concat buffer of mlp_rgb_sigma.py:52-53). */
+int hos_embed_fourier(const float* x, int num_freqs, const float* state, int state_size, int64_t P,
+                      float* E, int lde, float* E2, int lde2, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimiser over flat buffers (torch.optim.Adam semantics, M1:536-539; PL norm clipping,
