@@ -419,7 +419,7 @@ class Network(FlatModule):
             raw, _ = self._canonical_fwd(cnl, state, save=False)
             b = z.shape[0]
             ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
-                   "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
+                   "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
             if flow or True:
                 if vol_cl is None:   # channel-last copy of the K bone channels for the K-channel forward tap
                     vol_cl = torch.zeros(vol.shape[1], vol.shape[2], vol.shape[3], 32, device=dev)

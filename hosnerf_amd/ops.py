@@ -330,3 +330,87 @@ def embed_fourier(x, num_freqs, state, E, E2=None):
     P = x.shape[0]
     call("hos_embed_fourier", ptr(x), num_freqs, ptr(state), 0 if state is None else state.numel(), P,
          ptr(E), E.stride(0), ptr(E2), 0 if E2 is None else E2.stride(0))
+
+
+# ------------------------------------------------------------------------------------------ composites
+class _Raw2Outputs(torch.autograd.Function):
+    """rgb [B,3] (+ weights [B,S]) from packed rgb-sigma [B,S,4]; differentiable w.r.t. rgbsigma and mask."""
+
+    @staticmethod
+    def forward(ctx, rgbsigma, z_vals, rays_d, mask, bgcolor, last_dist):
+        B, S = z_vals.shape
+        dev = z_vals.device
+        rgb = torch.empty(B, 3, device=dev)
+        acc = torch.empty(B, device=dev)
+        w = torch.empty(B, S, device=dev)
+        depth = torch.empty(B, device=dev)
+        call("hos_raw2outputs_fwd", ptr(rgbsigma), 4, ptr(rgbsigma) + 12, 4, ptr(z_vals), ptr(rays_d), ptr(mask), ptr(bgcolor),
+             float(last_dist), B, S, ptr(rgb), ptr(acc), ptr(w), ptr(depth))
+        ctx.save_for_backward(rgbsigma, z_vals, rays_d, mask, bgcolor)
+        ctx.last_dist = float(last_dist)
+        ctx.mark_non_differentiable(acc, depth)
+        return rgb, acc, w, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_acc, g_w, g_depth):
+        rgbsigma, z_vals, rays_d, mask, bgcolor = ctx.saved_tensors
+        B, S = z_vals.shape
+        g_rs = torch.empty_like(rgbsigma)
+        g_mask = torch.empty(B, S, device=z_vals.device) if mask is not None else None
+        call("hos_raw2outputs_bwd", ptr(g_rgb.contiguous()), ptr(None if g_w is None else g_w.contiguous()), ptr(rgbsigma), 4,
+             ptr(rgbsigma) + 12, 4, ptr(z_vals), ptr(rays_d), ptr(mask), ptr(bgcolor), ctx.last_dist, B, S,
+             ptr(g_rs), 4, ptr(g_rs) + 12, 4, ptr(g_mask))
+        return g_rs, None, None, g_mask, None, None
+
+
+def raw2outputs(rgbsigma, z_vals, rays_d, mask=None, bgcolor=None, last_dist: float = 1e10):
+    """M:73-99 on activated samples.  Returns (rgb_map, acc_map, weights, depth_map)."""
+    return _Raw2Outputs.apply(rgbsigma.contiguous(), z_vals.contiguous(), rays_d.contiguous(),
+                              None if mask is None else mask.contiguous(),
+                              None if bgcolor is None else bgcolor.contiguous().float(), last_dist)
+
+
+class _MergeComposite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bkg_rgb, bkg_density, human_rgbsigma, pts_mask, bkg_tdist, pts, rays_o, rays_d, A, tiny_flag, thre_fg):
+        B, Sb = bkg_density.shape
+        Sh = pts_mask.shape[1]
+        dev = bkg_density.device
+        rgb = torch.empty(B, 3, device=dev)
+        idx_fg = torch.empty(B, dtype=torch.int32, device=dev)
+        order = torch.empty(B, Sb + Sh, dtype=torch.int32, device=dev)
+        hw = torch.empty(B, Sh, device=dev)
+        zh = torch.empty(B, Sh, device=dev)
+        call("hos_merge_composite_fwd", ptr(bkg_tdist), ptr(bkg_rgb), ptr(bkg_density), ptr(human_rgbsigma), ptr(pts),
+             ptr(pts_mask), ptr(rays_o), ptr(rays_d), ptr(A), ptr(tiny_flag, torch.int32), B, Sb, Sh, float(thre_fg),
+             ptr(rgb), ptr(idx_fg, torch.int32), ptr(order, torch.int32), ptr(hw), ptr(zh))
+        ctx.save_for_backward(bkg_rgb, bkg_density, human_rgbsigma, pts_mask, bkg_tdist, pts, rays_o, rays_d, A, tiny_flag)
+        ctx.thre = float(thre_fg)
+        ctx.mark_non_differentiable(idx_fg, order, zh)
+        return rgb, hw, idx_fg, order, zh
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_hw, *_):
+        bkg_rgb, bkg_density, human, mask, tdist, pts, ro, rd, A, flag = ctx.saved_tensors
+        B, Sb = bkg_density.shape
+        Sh = mask.shape[1]
+        g_brgb = torch.empty_like(bkg_rgb)
+        g_bden = torch.empty_like(bkg_density)
+        g_h = torch.empty_like(human)
+        g_m = torch.empty_like(mask)
+        call("hos_merge_composite_bwd", ptr(g_rgb.contiguous()), ptr(None if g_hw is None else g_hw.contiguous()),
+             ptr(tdist), ptr(bkg_rgb), ptr(bkg_density), ptr(human), ptr(pts), ptr(mask), ptr(ro), ptr(rd), ptr(A),
+             ptr(flag, torch.int32), B, Sb, Sh, ctx.thre, ptr(g_brgb), ptr(g_bden), ptr(g_h), ptr(g_m))
+        return g_brgb, g_bden, g_h, g_m, None, None, None, None, None, None, None
+
+
+def merge_composite(bkg_tdist, bkg_rgb, bkg_density, human_rgbsigma, newsmpl_pts, pts_mask, rays_o_bkg, rays_d_bkg,
+                    newsmpl_to_scale_world, thre_fg: float = 5e-3):
+    """Stage-3 inline composite (M:1524-1596).  Returns (rgb [B,3], human_weights_sorted [B,Sh], idx_fg [B] int32,
+    total_order [B,Sb+Sh] int32, z_human [B,Sh]).  No host synchronisation: the `any |d| < 1e-5` test of M:1526
+    stays on the device."""
+    rd = rays_d_bkg.contiguous()
+    tiny = (rd.abs() < 1e-5).any().to(torch.int32).reshape(1)
+    return _MergeComposite.apply(bkg_rgb.contiguous(), bkg_density.contiguous(), human_rgbsigma.contiguous(),
+                                 pts_mask.contiguous(), bkg_tdist.contiguous(), newsmpl_pts.contiguous(),
+                                 rays_o_bkg.contiguous(), rd, newsmpl_to_scale_world.contiguous().float(), tiny, thre_fg)

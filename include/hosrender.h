@@ -176,6 +176,43 @@ int hos_embed_hannw(const float* x, const float* band_w, int num_freqs, const fl
 int hos_embed_fourier(const float* x, int num_freqs, const float* state, int state_size, int64_t P,
                       float* E, int lde, float* E2, int lde2, hos_stream_t stream);
 
+/* NeRF-style composite `_raw2outputs` (M:73-99; S2 form N2:273-299 with the activations applied by
+ * the MLP epilogue): dists = [dz..., last_dist]*|d|; alpha = (1-exp(-sigma*dists))*mask;
+ * w = alpha * cumprod([1, 1-alpha+1e-10])[:-1]; rgb = sum w c (+ (1-sum w)*bgcolor/255 if bgcolor).
+ * rgbs / sigma are strided views (element (ray,s) at [(ray*S+s)*ld]) so a packed [B,S,4] buffer works.
+ * mask / bgcolor / acc / weights / depth may be NULL. */
+int hos_raw2outputs_fwd(const float* rgbs, int rgb_ld, const float* sigma, int sigma_ld, const float* z_vals,
+                        const float* rays_d, const float* mask, const float* bgcolor, float last_dist,
+                        int B, int S, float* rgb, float* acc, float* weights, float* depth, hos_stream_t stream);
+/* gradients w.r.t. rgbs / sigma / mask from g_rgb [B,3] (+ optional g_weights [B,S]). */
+int hos_raw2outputs_bwd(const float* g_rgb, const float* g_weights, const float* rgbs, int rgb_ld,
+                        const float* sigma, int sigma_ld, const float* z_vals, const float* rays_d,
+                        const float* mask, const float* bgcolor, float last_dist, int B, int S,
+                        float* g_rgbs, int g_rgb_ld, float* g_sigma, int g_sigma_ld, float* g_mask,
+                        hos_stream_t stream);
+
+/* Stage-3 composite of one ray batch (M:1524-1596, the inline block of LitMipNeRF360.training_step):
+ *   C1  z_h = mean_xyz((A[p,1] - o_b)/(d_b + 1e-10))   (first non-tiny component when *tiny_d_flag != 0)
+ *   C2  fg = sum(mask) > thre_fg; stable z-sort of [bkg tdist[:-1] (Sb) | human z_h (Sh)] -> total_order
+ *   C3  masked _raw2outputs over the merged samples (fg rays) or the Sb background samples (bg rays)
+ * Outputs: rgb [B,3]; idx_fg [B] (0/1); total_order [B,Sb+Sh] int32 (-1 on bg rays) -- the bit-exact
+ * index target; human_weights_sorted [B,Sh] = composite weights of the human samples in sorted order
+ * (rows of bg rays are 0) = `human_weights_onlyfg` of M:1588 after row selection; z_human [B,Sh].
+ * All optional outputs may be NULL. */
+int hos_merge_composite_fwd(const float* bkg_tdist, const float* bkg_rgb, const float* bkg_density,
+                            const float* human_rgbsigma, const float* newsmpl_pts, const float* pts_mask,
+                            const float* rays_o_bkg, const float* rays_d_bkg, const float* smpl_to_world,
+                            const int32_t* tiny_d_flag, int B, int Sb, int Sh, float thre_fg,
+                            float* rgb, int32_t* idx_fg, int32_t* total_order, float* human_weights_sorted,
+                            float* z_human, hos_stream_t stream);
+int hos_merge_composite_bwd(const float* g_rgb, const float* g_human_weights_sorted,
+                            const float* bkg_tdist, const float* bkg_rgb, const float* bkg_density,
+                            const float* human_rgbsigma, const float* newsmpl_pts, const float* pts_mask,
+                            const float* rays_o_bkg, const float* rays_d_bkg, const float* smpl_to_world,
+                            const int32_t* tiny_d_flag, int B, int Sb, int Sh, float thre_fg,
+                            float* g_bkg_rgb, float* g_bkg_density, float* g_human_rgbsigma, float* g_pts_mask,
+                            hos_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimiser over flat buffers (torch.optim.Adam semantics, M1:536-539; PL norm clipping,
  * S1/run.py:155 gradient_clip_val).
