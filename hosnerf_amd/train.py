@@ -46,6 +46,19 @@ def stage1_lr(step: int, max_steps: int, lr_init: float = 2.0e-3, lr_final: floa
     return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+def allreduce_flat_grad(module: FlatModule, group=None) -> int:
+    """Sum the flat gradient over the data-parallel group (RCCL on MI355X, gloo in the CPU tests) and return
+    the world size; the 1/world averaging is folded into the Adam kernel's grad_scale.
+    ONE collective per step over the whole gradient: xGMI is point-to-point, so a single large message keeps
+    every link busy (DDP's default 25 MB buckets would split the 38 MB stage-1 gradient in two)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(module.flat_grad, group=group)
+    return world
+
+
 class FusedAdam:
     """torch.optim.Adam semantics over the flat parameter buffer of a FlatModule: one sum-of-squares
     launch (norm clipping), one RCCL all-reduce of the whole gradient (multi-GPU) and one Adam launch."""
@@ -69,11 +82,7 @@ class FusedAdam:
 
     def step(self, lr: Optional[float] = None):
         g = self.module.flat_grad
-        world = self.world_size()
-        if world > 1:
-            # ONE collective per step over the whole 38 MB gradient: xGMI is point-to-point, so a
-            # single large message keeps every link busy (DDP's 25 MB buckets would split it in two).
-            dist.all_reduce(g, group=self.group)
+        world = allreduce_flat_grad(self.module, self.group)
         self.step_count += 1
         sumsq = None
         if self.max_grad_norm > 0:
