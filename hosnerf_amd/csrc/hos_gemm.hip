@@ -32,6 +32,7 @@ struct GemmArgs {
     float* C; int ldc;
     int M, N;                // store extents (rows i, cols j)
     int Mload, Nload;        // operand extents (may include zero padding)
+    int red_limit;           // valid reduction rows for reduction-row operands (WGRAD with M % 32 != 0)
     int nk;                  // K tiles in total
     int kt_per_split;
     int tiles_m, tiles_n;
@@ -72,14 +73,14 @@ __device__ __forceinline__ void store_kc(const float4 (&v)[BMN / 32], float* __r
 // reduction-row operand P[red][i]: 32 rows, BMN contiguous floats.  thread -> (i4 = t % (BMN/4), row = t/(BMN/4) + RP*r)
 template <int BMN>
 __device__ __forceinline__ void load_rc(float4 (&v)[BMN / 32], const float* __restrict__ P, int ld,
-                                        int i0, int limit, int k0, int t) {
+                                        int i0, int limit, int k0, int t, int row_limit) {
     constexpr int C4 = BMN / 4, RP = NT / C4;
     const int i4 = t % C4, rr = t / C4;
     const int gi = i0 + i4 * 4;
 #pragma unroll
     for (int r = 0; r < BMN / 32; ++r) {
         const int row = k0 + rr + RP * r;
-        v[r] = gi < limit ? ldg4(P + (size_t)row * ld + gi) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r] = (gi < limit && row < row_limit) ? ldg4(P + (size_t)row * ld + gi) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 template <int BMN, int LD>
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
             if (MODE == MODE_FWD && kt >= a.kt0) { P = a.A1; ld = a.lda1; k0 = (kt - a.kt0) * BK; }
             load_kc<BM>(ra, P, ld, i0, a.Mload, k0, t);
         } else {
-            load_rc<BM>(ra, a.A0, a.lda0, i0, a.Mload, kt * BK, t);
+            load_rc<BM>(ra, a.A0, a.lda0, i0, a.Mload, kt * BK, t, a.red_limit);
             if (do_db) {
 #pragma unroll
                 for (int r = 0; r < BM / 32; ++r) { bsum.x += ra[r].x; bsum.y += ra[r].y; bsum.z += ra[r].z; bsum.w += ra[r].w; }
             }
         }
         if constexpr (B_KC) load_kc<BN>(rb, a.B, a.ldb, j0, a.Nload, kt * BK, t);
-        else                load_rc<BN>(rb, a.B, a.ldb, j0, a.Nload, kt * BK, t);
+        else                load_rc<BN>(rb, a.B, a.ldb, j0, a.Nload, kt * BK, t, a.red_limit);
     };
     auto sstore = [&](int buf) {
         if constexpr (A_KC) store_kc<BM, LDA>(ra, As + buf * BK * LDA, t);
@@ -291,7 +292,7 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
     a.A0 = A0; a.lda0 = lda0; a.kt0 = K0 / BK; a.A1 = A1; a.lda1 = lda1;
     a.B = W; a.ldb = ldw; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.Mload = M; a.Nload = N;
-    a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk;
+    a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.bias = bias; a.aux = aux; a.aux_col = aux_col; a.p0 = p0; a.p1 = p1; a.epi = epilogue;
     if (epilogue == HOS_EPI_RESIDUAL) { a.mask = aux; a.ldmask = aux_col; }   // residual [M, ld=aux_col]
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -314,7 +315,7 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     a.A0 = dY; a.lda0 = lddy; a.kt0 = Npad / BK;
     a.B = W; a.ldb = ldw; a.C = dX; a.ldc = lddx;
     a.M = M; a.N = K; a.Mload = M; a.Nload = K;
-    a.nk = Npad / BK; a.kt_per_split = a.nk;
+    a.nk = Npad / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
     a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(K, 128);
     return launch<128, 128, MODE_DGRAD>(a, 1, static_cast<hipStream_t>(stream));
@@ -323,7 +324,6 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
 extern "C" int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
                                 float* db, int M, int N, int K, int splits, hos_stream_t stream) {
     if (!dY || !X || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
-    if (M % BK) return HOS_E_SHAPE;
     if ((lddy & 3) || (ldx & 3) || (K & 3)) return HOS_E_ALIGN;
     if (!al16(dY) || !al16(X)) return HOS_E_ALIGN;
     GemmArgs a{};
@@ -332,7 +332,8 @@ extern "C" int hos_linear_wgrad(const float* dY, int lddy, const float* X, int l
     a.Mload = (N + 3) & ~3;          // dY is zero-padded to a multiple of 32 columns by contract
     if (a.Mload > lddy) a.Mload = lddy & ~3;
     a.Nload = K;
-    a.nk = M / BK;
+    a.nk = hos_cdiv(M, BK);          // rows >= M are zero-filled by the loaders (red_limit)
+    a.red_limit = M;
     a.db = db;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool narrow = (N <= 32);

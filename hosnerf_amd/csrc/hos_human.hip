@@ -246,3 +246,342 @@ extern "C" int hos_embed_fourier(const float* x, int num_freqs, const float* sta
                        x, num_freqs, state, state_size, (long)P, E, lde, E2, lde2);
     return hos_launch_status();
 }
+
+// ================================================================================================
+// Backward kernels of the human branch (training stages 2/3).
+// ================================================================================================
+namespace {
+
+// value and spatial gradient (w.r.t. the *normalised* grid coordinate) of the zero-padded trilinear tap;
+// optionally scatters g_out * tapweight into g_vol (same geometry as trilinear_zero).
+__device__ __forceinline__ float trilinear_zero_grad(const float* __restrict__ vol, float* __restrict__ g_vol, int V,
+                                                     float gx, float gy, float gz, float g_out, float (&dgrid)[3]) {
+    const float half = 0.5f * (float)(V - 1);
+    const float ix = ((gx + 1.f) / 2.f) * (float)(V - 1);
+    const float iy = ((gy + 1.f) / 2.f) * (float)(V - 1);
+    const float iz = ((gz + 1.f) / 2.f) * (float)(V - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    dgrid[0] = dgrid[1] = dgrid[2] = 0.f;
+    if (!(fx >= -1.f && fx <= (float)V && fy >= -1.f && fy <= (float)V && fz >= -1.f && fz <= (float)V)) return 0.f;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+    const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+    float out = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
+                    const float wx = dx ? wx1 : wx0, wy = dy ? wy1 : wy0, wz = dz ? wz1 : wz0;
+                    const size_t idx = ((size_t)z * V + y) * V + x;
+                    const float v = vol[idx];
+                    out += v * (wx * wy * wz);
+                    dgrid[0] += v * (dx ? 1.f : -1.f) * wy * wz;
+                    dgrid[1] += v * wx * (dy ? 1.f : -1.f) * wz;
+                    dgrid[2] += v * wx * wy * (dz ? 1.f : -1.f);
+                    if (g_vol != nullptr && g_out != 0.f)
+                        __hip_atomic_fetch_add(g_vol + idx, g_out * (wx * wy * wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+    dgrid[0] *= half; dgrid[1] *= half; dgrid[2] *= half;
+    return out;
+}
+
+// x_skel = sum_i w_i q_i / max(sum w, 1e-4), mask = sum w;  q_i = R_i p + T_i;  w_i = tap(vol_i, g(q_i)).
+// Gradients: g_vol (atomics), g_R [K,9], g_T [K,3] (wave reduce -> LDS -> one atomic per block and entry).
+__global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
+    const float* __restrict__ pts, const float* __restrict__ R, const float* __restrict__ T,
+    const float* __restrict__ vol, int V, const float* __restrict__ bbox_min, const float* __restrict__ bbox_scale,
+    long P, int K, const float* __restrict__ g_xskel, const float* __restrict__ g_mask,
+    float* __restrict__ g_vol, float* __restrict__ g_R, float* __restrict__ g_T) {
+    __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6], sAcc[KMAX * 12];
+    for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
+    for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
+    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) sAcc[i] = 0.f;
+    if (threadIdx.x < 3) { sB[threadIdx.x] = bbox_min[threadIdx.x]; sB[3 + threadIdx.x] = bbox_scale[threadIdx.x]; }
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    const long pp = live ? p : P - 1;
+    const int lane = threadIdx.x & 63;
+    const float px = pts[pp * 3], py = pts[pp * 3 + 1], pz = pts[pp * 3 + 2];
+    const size_t V3 = (size_t)V * V * V;
+    // pass 1: recompute wsum and x_skel
+    float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int i = 0; i < K; ++i) {
+        const float* r = sR + i * 9;
+        const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
+        const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
+        const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
+        const float w = trilinear_zero(vol + i * V3, V, (qx - sB[0]) * sB[3] - 1.f, (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f);
+        wsum += w; ax += w * qx; ay += w * qy; az += w * qz;
+    }
+    const float den = fmaxf(wsum, 1e-4f);
+    const float xs = ax / den, ys = ay / den, zs = az / den;
+    const float clampg = (wsum >= 1e-4f) ? 1.f : 0.f;        // clamp(min) passes the gradient at >=
+    const float gx_ = live ? g_xskel[pp * 3] : 0.f, gy_ = live ? g_xskel[pp * 3 + 1] : 0.f, gz_ = live ? g_xskel[pp * 3 + 2] : 0.f;
+    const float gm = live ? g_mask[pp] : 0.f;
+    const float gdot_xs = gx_ * xs + gy_ * ys + gz_ * zs;
+    // pass 2: per-bone gradients
+    for (int i = 0; i < K; ++i) {
+        const float* r = sR + i * 9;
+        const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
+        const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
+        const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
+        // d loss / d w_i
+        const float gw = ((gx_ * qx + gy_ * qy + gz_ * qz) - clampg * gdot_xs) / den + gm;
+        float dg[3];
+        const float w = trilinear_zero_grad(vol + i * V3, live ? g_vol + i * V3 : nullptr, V, (qx - sB[0]) * sB[3] - 1.f,
+                                            (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f, gw, dg);
+        // d loss / d q_i = g_xs * w/den + gw * dw/dq
+        float gq[3] = {gx_ * w / den + gw * dg[0] * sB[3], gy_ * w / den + gw * dg[1] * sB[4], gz_ * w / den + gw * dg[2] * sB[5]};
+        float contrib[12] = {gq[0] * px, gq[0] * py, gq[0] * pz, gq[1] * px, gq[1] * py, gq[1] * pz,
+                             gq[2] * px, gq[2] * py, gq[2] * pz, gq[0], gq[1], gq[2]};
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const float s = wave_sum(contrib[c]);
+            if (lane == 0) atomicAdd(&sAcc[i * 12 + c], s);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) {
+        const int b = i / 12, c = i % 12;
+        const float v = sAcc[i];
+        if (v != 0.f) {
+            if (c < 9) __hip_atomic_fetch_add(g_R + b * 9 + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(g_T + b * 3 + (c - 9), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// forward-LBS backward: x_def = sum_i w_i(c) (R_i c + T_i) / max(sum w, 1e-4)
+__global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
+    const float* __restrict__ cnl, const float* __restrict__ R, const float* __restrict__ T,
+    const float* __restrict__ vol_cl, int V, int CL, const float* __restrict__ bbox_min,
+    const float* __restrict__ bbox_scale, long P, int K, const float* __restrict__ g_xdef,
+    float* __restrict__ g_cnl, float* __restrict__ g_vol_cl, float* __restrict__ g_R, float* __restrict__ g_T) {
+    __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6], sAcc[KMAX * 12];
+    for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
+    for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
+    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) sAcc[i] = 0.f;
+    if (threadIdx.x < 3) { sB[threadIdx.x] = bbox_min[threadIdx.x]; sB[3 + threadIdx.x] = bbox_scale[threadIdx.x]; }
+    __syncthreads();
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = p < P;
+    const long pp = live ? p : P - 1;
+    const int lane = threadIdx.x & 63;
+    const float px = cnl[pp * 3], py = cnl[pp * 3 + 1], pz = cnl[pp * 3 + 2];
+    const float gx = (px - sB[0]) * sB[3] - 1.f, gy = (py - sB[1]) * sB[4] - 1.f, gz = (pz - sB[2]) * sB[5] - 1.f;
+    const float half = 0.5f * (float)(V - 1);
+    const float ix = ((gx + 1.f) / 2.f) * (float)(V - 1), iy = ((gy + 1.f) / 2.f) * (float)(V - 1), iz = ((gz + 1.f) / 2.f) * (float)(V - 1);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const bool inside = (fx >= -1.f && fx <= (float)V && fy >= -1.f && fy <= (float)V && fz >= -1.f && fz <= (float)V);
+    const int x0 = inside ? (int)fx : 0, y0 = inside ? (int)fy : 0, z0 = inside ? (int)fz : 0;
+    const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+    const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+    // pass 1: weights, wsum, x_def
+    float w[KMAX];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) w[i] = 0.f;
+    if (inside) {
+        for (int t = 0; t < 8; ++t) {
+            const int dx = t & 1, dy = (t >> 1) & 1, dz = t >> 2;
+            const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+            if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
+                const float tw = (dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0);
+                const float4* vp = reinterpret_cast<const float4*>(vol_cl + (((size_t)z * V + y) * V + x) * CL);
+#pragma unroll
+                for (int q = 0; q < KMAX / 4; ++q) {
+                    if (q * 4 < K) { const float4 v = vp[q]; w[q * 4] += v.x * tw; w[q * 4 + 1] += v.y * tw; w[q * 4 + 2] += v.z * tw; w[q * 4 + 3] += v.w * tw; }
+                }
+            }
+        }
+    }
+    float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+        if (i < K) {
+            const float* r = sR + i * 9;
+            wsum += w[i];
+            ax += w[i] * ((r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0]);
+            ay += w[i] * ((r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1]);
+            az += w[i] * ((r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2]);
+        }
+    }
+    const float den = fmaxf(wsum, 1e-4f);
+    const float xd = ax / den, yd = ay / den, zd = az / den;
+    const float clampg = (wsum >= 1e-4f) ? 1.f : 0.f;
+    const float g0 = live ? g_xdef[pp * 3] : 0.f, g1 = live ? g_xdef[pp * 3 + 1] : 0.f, g2 = live ? g_xdef[pp * 3 + 2] : 0.f;
+    const float gdot = g0 * xd + g1 * yd + g2 * zd;
+    // pass 2: g_w_i, g wrt c through q_i, R/T grads
+    float gw[KMAX];
+    float gc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i) {
+        gw[i] = 0.f;
+        if (i < K) {
+            const float* r = sR + i * 9;
+            const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
+            const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
+            const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
+            gw[i] = ((g0 * qx + g1 * qy + g2 * qz) - clampg * gdot) / den;
+            const float s = w[i] / den;
+            const float gq[3] = {g0 * s, g1 * s, g2 * s};
+            gc[0] += r[0] * gq[0] + r[3] * gq[1] + r[6] * gq[2];
+            gc[1] += r[1] * gq[0] + r[4] * gq[1] + r[7] * gq[2];
+            gc[2] += r[2] * gq[0] + r[5] * gq[1] + r[8] * gq[2];
+            float contrib[12] = {gq[0] * px, gq[0] * py, gq[0] * pz, gq[1] * px, gq[1] * py, gq[1] * pz,
+                                 gq[2] * px, gq[2] * py, gq[2] * pz, gq[0], gq[1], gq[2]};
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                const float sm = wave_sum(contrib[c]);
+                if (lane == 0) atomicAdd(&sAcc[i * 12 + c], sm);
+            }
+        }
+    }
+    // pass 3: through the taps: g_vol and d w / d c
+    if (inside && live) {
+        float dgx = 0.f, dgy = 0.f, dgz = 0.f;
+        for (int t = 0; t < 8; ++t) {
+            const int dx = t & 1, dy = (t >> 1) & 1, dz = t >> 2;
+            const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+            if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
+                const float wx = dx ? wx1 : wx0, wy = dy ? wy1 : wy0, wz = dz ? wz1 : wz0;
+                const size_t base = (((size_t)z * V + y) * V + x) * CL;
+                float dot = 0.f;    // sum_i gw_i * v_i(tap)
+                for (int i = 0; i < K; ++i) {
+                    dot += gw[i] * vol_cl[base + i];
+                    if (g_vol_cl != nullptr && gw[i] != 0.f)
+                        __hip_atomic_fetch_add(g_vol_cl + base + i, gw[i] * (wx * wy * wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                dgx += dot * (dx ? 1.f : -1.f) * wy * wz;
+                dgy += dot * wx * (dy ? 1.f : -1.f) * wz;
+                dgz += dot * wx * wy * (dz ? 1.f : -1.f);
+            }
+        }
+        gc[0] += dgx * half * sB[3]; gc[1] += dgy * half * sB[4]; gc[2] += dgz * half * sB[5];
+    }
+    if (live && g_cnl) { g_cnl[pp * 3] = gc[0]; g_cnl[pp * 3 + 1] = gc[1]; g_cnl[pp * 3 + 2] = gc[2]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * 12; i += blockDim.x) {
+        const int b = i / 12, c = i % 12;
+        const float v = sAcc[i];
+        if (v != 0.f) {
+            if (c < 9) __hip_atomic_fetch_add(g_R + b * 9 + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_fetch_add(g_T + b * 3 + (c - 9), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// g_x[p, ax] (+)= [identity] + sum_j w_j 2^j (cos(2^j x) dS_j - sin(2^j x) dC_j), features gathered from up to
+// two gradient matrices (first-layer input gradient and skip-concat gradient).
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ band_w, int F,
+                                                        int identity, const float* __restrict__ dA, int lda, int colA,
+                                                        const float* __restrict__ dB, int ldb, int colB, long P,
+                                                        float* __restrict__ g_x, int accumulate) {
+    const long total = P * 3;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / 3;
+        const int ax = (int)(it % 3);
+        const float xv = x[it];
+        auto feat = [&](int c) {
+            float v = dA[p * lda + colA + c];
+            if (dB) v += dB[p * ldb + colB + c];
+            return v;
+        };
+        float g = 0.f;
+        int base = 0;
+        if (identity) { g += feat(ax); base = 3; }
+        for (int j = 0; j < F; ++j) {
+            const float fr = (float)(1 << j);
+            const float a = xv * fr;
+            const float wj = band_w ? band_w[j] : 1.f;
+            g += wj * fr * (cosf(a) * feat(base + j * 6 + ax) - sinf(a) * feat(base + j * 6 + 3 + ax));
+        }
+        g_x[it] = accumulate ? g_x[it] + g : g;
+    }
+}
+
+// out[p, c] = src[p*lds + col0 + c] * (mask_src[p*ldm + mcol0 + c] > 0)   (c < width); used to pull the
+// h-part out of the canonical skip-concat gradient, and (mask NULL) for plain strided slices.
+__global__ __launch_bounds__(256) void slice_mask_kernel(const float* __restrict__ src, int lds, int col0,
+                                                         const float* __restrict__ msk, int ldm, int mcol0, long P,
+                                                         int width, float* __restrict__ out, int ldo) {
+    const long total = P * width;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / width;
+        const int c = (int)(it % width);
+        float v = src[p * lds + col0 + c];
+        if (msk && !(msk[p * ldm + mcol0 + c] > 0.f)) v = 0.f;
+        out[p * ldo + c] = v;
+    }
+}
+
+// d(pre-activation) of the canonical head: cols 0..2 sigmoid' = s(1-s), col 3 relu' ; written zero-padded [P, ldo]
+__global__ __launch_bounds__(256) void rgbsigma_grad_kernel(const float* __restrict__ g, const float* __restrict__ y, long P,
+                                                            float* __restrict__ out, int ldo) {
+    const long total = P * 4;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long p = it >> 2;
+        const int c = (int)(it & 3);
+        const float yv = y[it], gv = g[it];
+        out[p * ldo + c] = (c < 3) ? gv * yv * (1.f - yv) : (yv > 0.f ? gv : 0.f);
+    }
+}
+
+}  // namespace
+
+extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, const float* vol, int V,
+                                         const float* bbox_min, const float* bbox_scale, int64_t P, int K,
+                                         const float* g_x_skel, const float* g_mask, float* g_vol, float* g_R,
+                                         float* g_T, hos_stream_t stream) {
+    if (!pts || !R || !T || !vol || !bbox_min || !bbox_scale || !g_x_skel || !g_mask || !g_vol || !g_R || !g_T || P <= 0)
+        return HOS_E_ARG;
+    if (K <= 0 || K > KMAX || V < 2) return HOS_E_SHAPE;
+    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K, g_x_skel,
+                       g_mask, g_vol, g_R, g_T);
+    return hos_launch_status();
+}
+
+extern "C" int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
+                                   int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
+                                   const float* g_x_deform, float* g_cnl, float* g_vol_cl, float* g_R, float* g_T,
+                                   hos_stream_t stream) {
+    if (!cnl_pts || !R_fwd || !T_fwd || !vol_cl || !bbox_min || !bbox_scale || !g_x_deform || !g_R || !g_T || P <= 0)
+        return HOS_E_ARG;
+    if (K <= 0 || K > KMAX || CL < K || (CL & 3) || V < 2) return HOS_E_SHAPE;
+    hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), cnl_pts, R_fwd, T_fwd, vol_cl, V, CL, bbox_min, bbox_scale,
+                       (long)P, K, g_x_deform, g_cnl, g_vol_cl, g_R, g_T);
+    return hos_launch_status();
+}
+
+extern "C" int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
+                             int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
+                             hos_stream_t stream) {
+    if (!x || !dA || !g_x || P <= 0) return HOS_E_ARG;
+    if (num_freqs < 1 || num_freqs > 16) return HOS_E_SHAPE;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(P * 3)), dim3(256), 0, static_cast<hipStream_t>(stream), x, band_w,
+                       num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate);
+    return hos_launch_status();
+}
+
+extern "C" int hos_slice_mask(const float* src, int lds, int col0, const float* mask_src, int ldm, int mcol0, int64_t P,
+                              int width, float* out, int ldo, hos_stream_t stream) {
+    if (!src || !out || P <= 0 || width <= 0) return HOS_E_ARG;
+    hipLaunchKernelGGL(slice_mask_kernel, dim3(grid_for(P * width)), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds,
+                       col0, mask_src, ldm, mcol0, (long)P, width, out, ldo);
+    return hos_launch_status();
+}
+
+extern "C" int hos_rgbsigma_grad(const float* g_rgbsigma, const float* rgbsigma, int64_t P, float* dz, int ldz,
+                                 hos_stream_t stream) {
+    if (!g_rgbsigma || !rgbsigma || !dz || P <= 0 || ldz < 4) return HOS_E_ARG;
+    hipLaunchKernelGGL(rgbsigma_grad_kernel, dim3(grid_for(P * 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       g_rgbsigma, rgbsigma, (long)P, dz, ldz);
+    return hos_launch_status();
+}

@@ -368,6 +368,90 @@ class Network(FlatModule):
         ops.linear_fwd(h, 256, Wt, bt, 4, raw, ops.EPI_SIGMOID_RELU4)
         return raw, ((E, acts) if save else None)
 
+    # ------------------------------------------------------------------ HIP MLP chains (backward)
+    def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor):
+        """Parameter gradients into the flat buffer; returns d loss / d x  ([P,3])."""
+        E, PE, acts = saved
+        Pn, dev = x.shape[0], x.device
+        dz6 = torch.zeros(Pn, 32, device=dev)
+        ops.slice_mask(g_xyz, 0, None, 0, 3, dz6)
+        Wt, _ = self._w(specs[6])
+        gW, gb = self._w(specs[6], grad=True)
+        ops.linear_wgrad(dz6, acts[5], gW, gb, 3, 128)
+        dz = torch.empty(Pn, 128, device=dev)
+        ops.linear_dgrad(dz6, Wt, 32, 128, dz, mask_src=acts[5])
+        dPE = dE = None
+        for i in range(5, -1, -1):
+            Wt, _ = self._w(specs[i])
+            gW, gb = self._w(specs[i], grad=True)
+            if i == 4:
+                ops.linear_wgrad(dz, acts[3], gW, gb, 128, 128)
+                ops.linear_wgrad(dz, PE, gW, None, 128, NR_LDPE, w_col0=128)
+                dPE = torch.empty(Pn, NR_LDPE, device=dev)
+                ops.linear_dgrad(dz, Wt, 128, NR_LDPE, dPE, w_col0=128)
+                nxt = torch.empty(Pn, 128, device=dev)
+                ops.linear_dgrad(dz, Wt, 128, 128, nxt, mask_src=acts[3])
+                dz = nxt
+            elif i == 0:
+                ops.linear_wgrad(dz, E, gW, gb, 128, NR_LDE)
+                dE = torch.empty(Pn, NR_LDE, device=dev)
+                ops.linear_dgrad(dz, Wt, 128, NR_LDE, dE)
+            else:
+                ops.linear_wgrad(dz, acts[i - 1], gW, gb, 128, 128)
+                nxt = torch.empty(Pn, 128, device=dev)
+                ops.linear_dgrad(dz, Wt, 128, 128, nxt, mask_src=acts[i - 1])
+                dz = nxt
+        g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
+        ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True)
+        return g_x
+
+    def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):
+        E, acts = saved
+        CAT = acts[4]
+        Pn, dev = cnl.shape[0], cnl.device
+        dz8 = torch.zeros(Pn, 32, device=dev)
+        ops.rgbsigma_grad(g_raw.contiguous(), raw, dz8)
+        Wt, _ = self._w(self._cnl[8])
+        gW, gb = self._w(self._cnl[8], grad=True)
+        ops.linear_wgrad(dz8, acts[7], gW, gb, 4, 256)
+        dz = torch.empty(Pn, 256, device=dev)
+        ops.linear_dgrad(dz8, Wt, 32, 256, dz, mask_src=acts[7])
+        dCAT = dE = None
+        tmp_b = {}
+        for i in range(7, -1, -1):
+            L = self._cnl[i]
+            Wt, _ = self._w(L)
+            gW, gb = self._w(L, grad=True)
+            if i == 5:
+                tmp_b[5] = torch.zeros(L.Npad, device=dev)
+                ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
+                dCAT = torch.empty(Pn, CNL_CAT, device=dev)
+                ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
+                nxt = torch.empty(Pn, 256, device=dev)
+                ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)                 # h-part of the concat, through layer 4's ReLU
+                dz = nxt
+            elif i == 0:
+                tmp_b[0] = torch.zeros(L.Npad, device=dev)
+                ops.linear_wgrad(dz, E, gW, tmp_b[0], 256, CNL_LDE)
+                dE = torch.empty(Pn, CNL_LDE, device=dev)
+                ops.linear_dgrad(dz, Wt, 256, CNL_LDE, dE)
+            else:
+                inp = acts[i - 1]
+                ops.linear_wgrad(dz, inp, gW, gb, 256, 256)
+                nxt = torch.empty(Pn, 256, device=dev)
+                ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp)
+                dz = nxt
+        # state embedding: its 64 columns are constant over samples -> d embed = db @ W[:, 63:127] (layers 0 and 5)
+        g_embed = self._embeds.view(self.store.grad)[state]
+        for i in (0, 5):
+            Wt, _ = self._w(self._cnl[i])
+            _, gb = self._w(self._cnl[i], grad=True)
+            gb += tmp_b[i]
+            g_embed += tmp_b[i][:256] @ Wt[:256, 63:127]
+        g_cnl = torch.empty(Pn, 3, device=dev)
+        ops.embed_bwd(cnl, None, 10, True, dE, 0, dCAT, 0, g_cnl, False)
+        return g_cnl
+
     # ------------------------------------------------------------------ reference-style forward
     def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None, near=None, far=None,
                 iter_val=1e7, t_rand=None, **kwargs):
@@ -413,27 +497,35 @@ class Network(FlatModule):
         for c0 in range(0, B, chunk):
             sl = slice(c0, min(B, c0 + chunk))
             tr = None if t_rand is None else t_rand[sl].contiguous()
-            z, pts, x_skel, mask = ops.human_sample_warp(rays_o[sl], rays_d[sl], near[sl].contiguous(), far[sl].contiguous(),
-                                                         N, R_b, T_b, vol, bmin, bscale, tr, K)
-            cnl, _ = self._nonrigid_fwd(self._nr, x_skel, cond, band_w, save=False)
-            raw, _ = self._canonical_fwd(cnl, state, save=False)
+            grad = torch.is_grad_enabled()
+            if grad:
+                z, pts, x_skel, mask = ops.human_sample_warp_ad(vol, R_b, T_b, rays_o[sl], rays_d[sl], near[sl].contiguous(),
+                                                                far[sl].contiguous(), N, bmin, bscale, tr, K)
+                cnl = _NonRigidFn.apply(self._token, self, "nr", x_skel, cond, band_w)
+                raw = _CanonicalFn.apply(self._token, self, cnl, state)
+            else:
+                z, pts, x_skel, mask = ops.human_sample_warp(rays_o[sl], rays_d[sl], near[sl].contiguous(), far[sl].contiguous(),
+                                                             N, R_b, T_b, vol, bmin, bscale, tr, K)
+                cnl, _ = self._nonrigid_fwd(self._nr, x_skel, cond, band_w, save=False)
+                raw, _ = self._canonical_fwd(cnl, state, save=False)
             b = z.shape[0]
             ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
                    "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
-            if flow or True:
-                if vol_cl is None:   # channel-last copy of the K bone channels for the K-channel forward tap
-                    vol_cl = torch.zeros(vol.shape[1], vol.shape[2], vol.shape[3], 32, device=dev)
-                    vol_cl[..., :K] = vol[:K].permute(1, 2, 3, 0)
+            if vol_cl is None:   # channel-last copy of the K bone channels for the K-channel forward tap
+                vol_cl = F.pad(vol[:K].permute(1, 2, 3, 0), (0, 32 - K)).contiguous()
+
+            def fwd_branch(c_pts, Rf_, Tf_, cond_):
+                if grad:
+                    d_ = ops.lbs_forward_ad(c_pts, vol_cl, Rf_, Tf_, bmin, bscale, K)
+                    return _NonRigidFn.apply(self._token, self, "nrf", d_, cond_, band_w)
+                d_ = ops.lbs_forward(c_pts, Rf_, Tf_, vol_cl, bmin, bscale, K)
+                return self._nonrigid_fwd(self._nrf, d_, cond_, band_w, save=False)[0]
+
             if flow:                                                               # N:474-502
-                d_prev = ops.lbs_forward(cnl, R_fp, T_fp, vol_cl, bmin, bscale, K)
-                dp, _ = self._nonrigid_fwd(self._nrf, d_prev, cond_prev, band_w, save=False)
-                ret["deform_pts_prev_final"] = dp.view(b, N, 3)
-            sel = torch.nonzero(mask > 0.005).reshape(-1)                          # N:505-536 (data-dependent size)
+                ret["deform_pts_prev_final"] = fwd_branch(cnl, R_fp, T_fp, cond_prev).view(b, N, 3)
+            sel = torch.nonzero(mask.detach() > 0.005).reshape(-1)                 # N:505-536 (data-dependent size)
             if sel.numel() > 0:
-                cnl_sel = cnl.index_select(0, sel)
-                d_cur = ops.lbs_forward(cnl_sel, R_f, T_f, vol_cl, bmin, bscale, K)
-                dc, _ = self._nonrigid_fwd(self._nrf, d_cur, cond, band_w, save=False)
-                ret["deform_pts_final"] = dc
+                ret["deform_pts_final"] = fwd_branch(cnl.index_select(0, sel), R_f, T_f, cond)
                 ret["observe_pts"] = pts.view(-1, 3).index_select(0, sel)
             else:
                 ret["deform_pts_final"] = pts[0, 0][None]
@@ -446,3 +538,36 @@ class Network(FlatModule):
         all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}
         all_ret["bgcolor"] = kwargs.get("bgcolor")
         return all_ret
+
+
+class _NonRigidFn(torch.autograd.Function):
+    """xyz = x + NonRigidMLP([cond | hann(x)]); parameter gradients go straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, token, net: Network, which: str, x, cond, band_w):
+        specs = net._nr if which == "nr" else net._nrf
+        x = x.contiguous()
+        xyz, saved = net._nonrigid_fwd(specs, x, cond, band_w, save=True)
+        ctx.net, ctx.specs, ctx.saved, ctx.x, ctx.band_w = net, specs, saved, x, band_w
+        return xyz
+
+    @staticmethod
+    def backward(ctx, g):
+        g_x = ctx.net._nonrigid_bwd(ctx.specs, ctx.saved, ctx.x, ctx.band_w, g.contiguous())
+        ctx.saved = None
+        return None, None, None, g_x, None, None
+
+
+class _CanonicalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, token, net: Network, cnl, state):
+        cnl = cnl.contiguous()
+        raw, saved = net._canonical_fwd(cnl, state, save=True)
+        ctx.net, ctx.saved, ctx.cnl, ctx.raw, ctx.state = net, saved, cnl, raw, state
+        return raw
+
+    @staticmethod
+    def backward(ctx, g):
+        g_cnl = ctx.net._canonical_bwd(ctx.saved, ctx.cnl, ctx.raw, g.contiguous(), ctx.state)
+        ctx.saved = None
+        return None, None, g_cnl, None

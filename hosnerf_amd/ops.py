@@ -414,3 +414,73 @@ def merge_composite(bkg_tdist, bkg_rgb, bkg_density, human_rgbsigma, newsmpl_pts
     return _MergeComposite.apply(bkg_rgb.contiguous(), bkg_density.contiguous(), human_rgbsigma.contiguous(),
                                  pts_mask.contiguous(), bkg_tdist.contiguous(), newsmpl_pts.contiguous(),
                                  rays_o_bkg.contiguous(), rd, newsmpl_to_scale_world.contiguous().float(), tiny, thre_fg)
+
+
+# ------------------------------------------------------------------------------------------ human branch, backward
+class _SampleWarp(torch.autograd.Function):
+    """(z, pts, x_skel, mask) with gradients to the motion-weight volume and the backward motion basis."""
+
+    @staticmethod
+    def forward(ctx, vol, R, T, rays_o, rays_d, near, far, N, bmin, bscale, t_rand, K):
+        z, pts, x_skel, mask = human_sample_warp(rays_o, rays_d, near, far, N, R, T, vol, bmin, bscale, t_rand, K)
+        ctx.save_for_backward(vol, R, T, pts, bmin, bscale)
+        ctx.K = K
+        ctx.mark_non_differentiable(z, pts)
+        return z, pts, x_skel, mask
+
+    @staticmethod
+    def backward(ctx, gz, gpts, g_xskel, g_mask):
+        vol, R, T, pts, bmin, bscale = ctx.saved_tensors
+        K = ctx.K
+        P = pts.shape[0] * pts.shape[1]
+        g_vol = torch.zeros_like(vol)
+        g_R = torch.zeros_like(R)
+        g_T = torch.zeros_like(T)
+        gx = torch.zeros(P, 3, device=pts.device) if g_xskel is None else g_xskel.contiguous()
+        gm = torch.zeros(P, device=pts.device) if g_mask is None else g_mask.contiguous()
+        call("hos_human_sample_warp_bwd", ptr(pts), ptr(R), ptr(T), ptr(vol), vol.shape[-1], ptr(bmin), ptr(bscale), P, K,
+             ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T))
+        return g_vol, g_R, g_T, None, None, None, None, None, None, None, None, None
+
+
+def human_sample_warp_ad(vol, R, T, rays_o, rays_d, near, far, N, bmin, bscale, t_rand=None, K: int = 26):
+    return _SampleWarp.apply(vol.contiguous(), R.contiguous(), T.contiguous(), rays_o, rays_d, near, far, N, bmin, bscale, t_rand, K)
+
+
+class _LbsForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cnl, vol_cl, R_f, T_f, bmin, bscale, K):
+        out = lbs_forward(cnl, R_f, T_f, vol_cl, bmin, bscale, K)
+        ctx.save_for_backward(cnl, vol_cl, R_f, T_f, bmin, bscale)
+        ctx.K = K
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cnl, vol_cl, R_f, T_f, bmin, bscale = ctx.saved_tensors
+        P = cnl.shape[0]
+        g_cnl = torch.empty_like(cnl)
+        g_vol = torch.zeros_like(vol_cl)
+        g_R = torch.zeros_like(R_f)
+        g_T = torch.zeros_like(T_f)
+        call("hos_lbs_forward_bwd", ptr(cnl), ptr(R_f), ptr(T_f), ptr(vol_cl), vol_cl.shape[0], vol_cl.shape[-1], ptr(bmin),
+             ptr(bscale), P, ctx.K, ptr(g.contiguous()), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T))
+        return g_cnl, g_vol, g_R, g_T, None, None, None
+
+
+def lbs_forward_ad(cnl, vol_cl, R_f, T_f, bmin, bscale, K: int = 26):
+    return _LbsForward.apply(cnl.contiguous(), vol_cl.contiguous(), R_f.contiguous(), T_f.contiguous(), bmin, bscale, K)
+
+
+def embed_bwd(x, band_w, num_freqs, identity, dA, colA, dB, colB, g_x, accumulate):
+    call("hos_embed_bwd", ptr(x), ptr(band_w), num_freqs, int(identity), ptr(dA), dA.stride(0), colA,
+         ptr(dB), 0 if dB is None else dB.stride(0), colB, x.shape[0], ptr(g_x), int(accumulate))
+
+
+def slice_mask(src, col0, mask_src, mcol0, width, out):
+    call("hos_slice_mask", ptr(src), src.stride(0), col0, ptr(mask_src), 0 if mask_src is None else mask_src.stride(0), mcol0,
+         src.shape[0], width, ptr(out), out.stride(0))
+
+
+def rgbsigma_grad(g, y, dz):
+    call("hos_rgbsigma_grad", ptr(g), ptr(y), y.shape[0], ptr(dz), dz.stride(0))

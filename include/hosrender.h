@@ -70,7 +70,7 @@ int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npa
                      int accumulate, hos_stream_t stream);
 
 /* dW[N,K] += dY[M,N]^T @ X[M,K]   and, if db != NULL, db[N] += column sums of dY.
- * M (the reduction dim = number of sample points) multiple of 32.  Accumulates with fp32
+ * M (the reduction dim = number of sample points) is arbitrary (tail rows are zero-filled).  Accumulates with fp32
  * atomics over `splits` partitions of M (splits <= 0: chosen by the library). */
 int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
                      float* db, int M, int N, int K, int splits, hos_stream_t stream);
@@ -175,6 +175,30 @@ int hos_embed_hannw(const float* x, const float* band_w, int num_freqs, const fl
  * (the skip-concat buffer of mlp_rgb_sigma.py:52-53). */
 int hos_embed_fourier(const float* x, int num_freqs, const float* state, int state_size, int64_t P,
                       float* E, int lde, float* E2, int lde2, hos_stream_t stream);
+
+/* Backward of hos_human_sample_warp w.r.t. the motion-weight volume (atomics into g_vol [K,V,V,V]) and the
+ * backward motion basis (g_R [K,9], g_T [K,3], accumulated with atomics -- caller zeroes them):
+ * the autograd of N:318-340 incl. grid_sample's gradient w.r.t. the grid (bone transforms move the tap). */
+int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, const float* vol, int V,
+                              const float* bbox_min, const float* bbox_scale, int64_t P, int K,
+                              const float* g_x_skel, const float* g_mask, float* g_vol, float* g_R, float* g_T,
+                              hos_stream_t stream);
+/* Backward of hos_lbs_forward: g_cnl [P,3] (written), g_vol_cl / g_R / g_T accumulated with atomics. */
+int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
+                        int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
+                        const float* g_x_deform, float* g_cnl, float* g_vol_cl, float* g_R, float* g_T,
+                        hos_stream_t stream);
+/* Backward of both positional embedders w.r.t. x: feature gradients are read from dA[:, colA:] (+ dB[:, colB:]
+ * if not NULL); band_w NULL = plain Fourier (weights 1); identity != 0 = features start with x itself. */
+int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
+                  int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
+                  hos_stream_t stream);
+/* out[p,c] = src[p*lds+col0+c] * (mask_src[p*ldm+mcol0+c] > 0), c < width (mask_src may be NULL). */
+int hos_slice_mask(const float* src, int lds, int col0, const float* mask_src, int ldm, int mcol0, int64_t P,
+                   int width, float* out, int ldo, hos_stream_t stream);
+/* dz[p, 0..3] = g * (sigmoid' | relu') evaluated from the activated outputs (N:539-540); dz is [P, ldz] zero-padded by the caller. */
+int hos_rgbsigma_grad(const float* g_rgbsigma, const float* rgbsigma, int64_t P, float* dz, int ldz,
+                      hos_stream_t stream);
 
 /* NeRF-style composite `_raw2outputs` (M:73-99; S2 form N2:273-299 with the activations applied by
  * the MLP epilogue): dists = [dz..., last_dist]*|d|; alpha = (1-exp(-sigma*dists))*mask;

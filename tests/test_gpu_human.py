@@ -167,3 +167,37 @@ def test_forward_vs_golden(dev, net, tag):
     else:
         assert "deform_pts_prev_final" not in out
         assert maxerr(out["z_vals"], hf[p + "z_vals"]) < 1e-6
+
+
+def test_gradients_vs_oracle(dev, net):
+    """Backward of the whole human branch (LBS warp incl. grid gradients, embedders, MLP chains, prologue through
+    torch autograd) against the oracle's autograd on the same random cotangents."""
+    b = synth.human_batch(8, seed=21, time=0.5, is_train=True, iter_val=3e5)
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.human_state_dict(777, 2).items()}
+    out_o = oh.human_forward(sd, b, transitions_times=[0.4])
+    g = torch.Generator().manual_seed(123)
+    cot = {k: torch.randn(out_o[k].shape, generator=g) for k in ("human_rgb", "human_density", "pts_mask", "deform_pts_prev_final", "deform_pts_final")}
+    loss_o = sum((out_o[k] * cot[k]).sum() for k in cot)
+    loss_o.backward()
+
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    net.zero_grad()
+    out = net(**gb)
+    assert out["deform_pts_final"].shape == out_o["deform_pts_final"].shape
+    loss = sum((out[k] * cot[k].to(dev)).sum() for k in cot)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_o.detach())) < 2e-3 * max(1.0, abs(float(loss_o.detach())))
+    params = dict(net.named_parameters())
+    worst = []
+    for n, p_o in sd.items():
+        go = p_o.grad
+        if go is None or float(go.abs().max()) == 0:
+            continue
+        gg = params[n].grad
+        a, bb = gg.detach().double().cpu().reshape(-1), go.double().reshape(-1)
+        cos = float((a @ bb) / (a.norm() * bb.norm() + 1e-30))
+        rel = float((a - bb).norm() / (bb.norm() + 1e-30))
+        worst.append((rel, cos, n))
+        assert cos > 0.999 and rel < 3e-2, (n, cos, rel)
+    assert len(worst) >= 70, len(worst)      # every trainable tensor received a gradient
+    net.zero_grad()
