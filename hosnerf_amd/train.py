@@ -64,8 +64,11 @@ class FusedAdam:
     launch (norm clipping), one RCCL all-reduce of the whole gradient (multi-GPU) and one Adam launch."""
 
     def __init__(self, module: FlatModule, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_grad_norm: float = 0.0, process_group=None):
+                 max_grad_norm: float = 0.0, process_group=None, lr_ranges=None):
+        """`lr_ranges`: optional [(offset, numel, lr_multiplier), ...] over the flat buffer for per-module learning
+        rates (the reference's name-keyed param groups, core/train/optimizers/human_nerf/optimizer.py:19-60)."""
         self.module = module
+        self.lr_ranges = lr_ranges
         self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
         self.group = process_group
         p = module.flat_param
@@ -89,8 +92,11 @@ class FusedAdam:
             self._sumsq.zero_()
             ops.sumsq(g, self._sumsq)
             sumsq = self._sumsq
-        ops.adam_step(self.module.flat_param, g, self.exp_avg, self.exp_avg_sq, self.lr if lr is None else lr,
-                      self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world, sumsq, self.max_grad_norm)
+        lr = self.lr if lr is None else lr
+        p = self.module.flat_param
+        for off, n, mult in (self.lr_ranges or [(0, p.numel(), 1.0)]):
+            ops.adam_step(p[off:off + n], g[off:off + n], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n], lr * mult,
+                          self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world, sumsq, self.max_grad_norm)
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
@@ -119,4 +125,55 @@ def train_step_stage1(model, opt: FusedAdam, batch: Dict[str, torch.Tensor], tra
     loss, parts = stage1_loss(renderings[-1]["rgb"], batch["target"], hist)
     loss.backward()
     opt.step(lr)
+    return loss.detach(), parts
+
+
+# ------------------------------------------------------------------------------------------ stage 3 (C4)
+def human_lr_ranges(net, lr_cnl: float = 6.667e-5, lr_other: float = 6.667e-6):
+    """configs/default.yaml train.lr_*: cnl_mlp and human_stateembeds train at lr_cnl, every other human module
+    (mweight_vol_decoder, pose_decoder, non_rigid_mlp, non_rigid_forward_mlp) at lr_other.  The flat layout puts
+    the canonical MLP and the state embeddings last, so two contiguous ranges cover it (multipliers of lr_cnl)."""
+    start = net._cnl[0].W.offset
+    start -= start % 4
+    return [(0, start, lr_other / lr_cnl), (start, net.flat_param.numel() - start, 1.0)]
+
+
+def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
+                  w_flow: float = 0.01, w_cycle: float = 0.01):
+    """M:1690-1716 get_loss without the LPIPS term (third-party VGG, out of scope): 0.2*MSE + 0.01*flow + 0.01*cycle.
+    Torch elementwise ops on [B,3] / [B_fg,128,2] tensors -- fusing them into the composite is a listed next step."""
+    rgb = out["rgb"]
+    target = batch["target_rgbs"] if "target_rgbs" in batch else batch["target_patches"].reshape(-1, 3)
+    losses = {"mse": torch.mean((rgb - target) ** 2)}
+    flow = rgb.new_zeros(())
+    if "deform_pts_prev_final" in out and "ray_grid" in batch:                  # M:1680-1688 flow_func
+        fg = out["idx_fg"].bool()
+        if bool(fg.any()):
+            pts = out["deform_pts_prev_final"][fg]
+            hom = torch.cat([pts, torch.ones_like(pts[..., :1])], -1)
+            cam = torch.einsum("ji,bni->bnj", batch["newsmpl_to_camera_prev"], hom)[..., :3]
+            uvw = torch.einsum("ji,bni->bnj", batch["intrinsics_prev"], cam)
+            uv = uvw[..., :-1] / uvw[..., -1:]
+            grid = batch["ray_grid"][fg][:, None, :]
+            M = grid[..., -1:]
+            w = out["human_weights_sorted"][fg]
+            flow = torch.sum(torch.abs(uv - grid[..., :2] - grid[..., 2:4]) * w[..., None] * M) / (torch.sum(M.expand(-1, pts.shape[1], -1)) + 1e-8) / 2
+    losses["flow"] = flow
+    dis = out["observe_pts"] - out["deform_pts_final"]
+    losses["cycle"] = torch.mean(torch.sum(dis**2, 1) / 2.0)
+    total = w_mse * losses["mse"] + w_flow * losses["flow"] + w_cycle * losses["cycle"]
+    return total, {k: v.detach() for k, v in losses.items()}
+
+
+def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
+    """One stage-3 optimisation step (M:1501-1629 + optimizer_step :1631-1656): background forward (3 levels, only
+    the NeRF level trains -- the proposal MLPs get no gradient in stage 3) + human branch + merge composite +
+    losses + backward + the two flat Adam updates."""
+    opt_bkgd.zero_grad()
+    opt_human.zero_grad()
+    out = hos.render(batch, randomized=True, is_train=True)
+    loss, parts = stage3_losses(out, batch)
+    loss.backward()
+    opt_bkgd.step(lr)
+    opt_human.step(lr)
     return loss.detach(), parts

@@ -152,3 +152,36 @@ def test_merge_backward_vs_oracle(dev):
     for got, want, name in zip(dl, leaves, ("bkg_rgb", "bkg_density", "human_rgbsigma", "pts_mask")):
         scale = max(1.0, float(want.grad.abs().max()))
         assert maxerr(got.grad, want.grad) < 3e-5 * scale, name
+
+
+def test_stage3_train_step(dev, hos):
+    """Full stage-3 step: both branches + merge composite + mse/flow/cycle losses + backward + two flat Adams."""
+    from hosnerf_amd.train import FusedAdam, human_lr_ranges, train_step_stage3
+    b = synth.human_batch(64, seed=5, time=0.5, is_train=True, iter_val=3e5)
+    b["ray_grid"] = torch.cat([torch.rand(64, 2) * 100, torch.randn(64, 2), torch.ones(64, 1)], -1)
+    b["newsmpl_to_camera_prev"] = torch.eye(4)
+    b["newsmpl_to_camera_prev"][2, 3] = 3.0
+    b["intrinsics_prev"] = torch.tensor([[500.0, 0, 50], [0, 500.0, 50], [0, 0, 1]])
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    hos.human.cfg.perturb = 1.0
+    before = hos.human.flat_param.clone(), hos.model.flat_param.clone()
+    try:
+        ob_ = FusedAdam(hos.model, lr=6.667e-5)
+        oh_ = FusedAdam(hos.human, lr=6.667e-5, lr_ranges=human_lr_ranges(hos.human))
+        losses = []
+        for _ in range(3):
+            loss, parts = train_step_stage3(hos, ob_, oh_, gb)
+            losses.append(float(loss))
+        assert np.isfinite(losses).all()
+        assert float(parts["cycle"]) >= 0 and float(parts["mse"]) > 0
+        # proposal MLPs get no gradient in stage 3 (SURVEY section 5): their parameters must not move
+        prop0 = hos.model.mlps[0].pts_linear[0].weight
+        off = prop0.data_ptr() - hos.model.flat_param.data_ptr()
+        assert torch.equal(hos.model.flat_param[off // 4: off // 4 + 100], before[1][off // 4: off // 4 + 100])
+        assert not torch.equal(hos.human.flat_param, before[0])
+        nerf = hos.model.mlps[2].pts_linear[3].weight
+        assert float(nerf.grad.abs().max()) > 0
+    finally:
+        hos.human.cfg.perturb = 0.0
+        hos.human.flat_param.copy_(before[0])
+        hos.model.flat_param.copy_(before[1])
