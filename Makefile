@@ -8,7 +8,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-
 
 all: $(LIB)
 
-build/%.o: hosnerf_amd/csrc/%.hip hosnerf_amd/csrc/hos_common.h include/hosrender.h
+build/%.o: hosnerf_amd/csrc/%.hip hosnerf_amd/csrc/hos_common.h hosnerf_amd/csrc/hos_gemm_common.h include/hosrender.h
 	@mkdir -p build
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

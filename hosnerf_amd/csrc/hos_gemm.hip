@@ -16,33 +16,13 @@
 // RGB budget, so this path is the parity-safe one.
 #include "hos_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "hos_gemm_common.h"
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int NT = 256;
 
-enum Mode { MODE_FWD = 0, MODE_DGRAD = 1, MODE_WGRAD = 2 };
-
-struct GemmArgs {
-    const float* A0; int lda0; int kt0;   // A segment 0, number of K tiles in it
-    const float* A1; int lda1;            // optional A segment 1 (fwd skip-concat)
-    const float* B;  int ldb;
-    float* C; int ldc;
-    int M, N;                // store extents (rows i, cols j)
-    int Mload, Nload;        // operand extents (may include zero padding)
-    int red_limit;           // valid reduction rows for reduction-row operands (WGRAD with M % 32 != 0)
-    int nk;                  // K tiles in total
-    int kt_per_split;
-    int tiles_m, tiles_n;
-    const float* bias;
-    const float* mask; int ldmask;
-    float* aux; int aux_col; float p0, p1;
-    float* db;
-    int accumulate;
-    int epi;
-};
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -194,42 +174,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
 
     // ---- epilogue -------------------------------------------------------------------------
 #pragma unroll
-    for (int x = 0; x < TM; ++x) {
+    for (int x = 0; x < TM; ++x)
 #pragma unroll
-        for (int y = 0; y < TN; ++y) {
-            const int col = j0 + wn * (TN * 32) + y * 32 + l31;
-            if (col >= a.N) continue;
-            float bcol = 0.f;
-            if (MODE == MODE_FWD && a.bias != nullptr) bcol = a.bias[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * (TM * 32) + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row >= a.M) continue;
-                float v = acc[x][y][r];
-                if constexpr (MODE == MODE_FWD) {
-                    v += bcol;
-                    switch (a.epi) {
-                        case HOS_EPI_RELU: v = fmaxf(v, 0.f); break;
-                        case HOS_EPI_DENSITY: a.aux[row] = softplus_f(v + a.p0); continue;
-                        case HOS_EPI_RGB: v = sigmoid_f(v) * (1.f + 2.f * a.p0) - a.p0; break;
-                        case HOS_EPI_NERF_HEAD:
-                            if (col == a.aux_col) { a.aux[row] = softplus_f(v + a.p0); continue; }
-                            break;
-                        case HOS_EPI_SIGMOID_RELU4: v = (col < 3) ? sigmoid_f(v) : fmaxf(v, 0.f); break;
-                        case HOS_EPI_RESIDUAL: v += a.mask[(size_t)row * a.ldmask + col]; break;
-                        default: break;
-                    }
-                    a.C[(size_t)row * a.ldc + col] = v;
-                } else if constexpr (MODE == MODE_DGRAD) {
-                    if (a.mask != nullptr && !(a.mask[(size_t)row * a.ldmask + col] > 0.f)) v = 0.f;
-                    float* dst = a.C + (size_t)row * a.ldc + col;
-                    *dst = a.accumulate ? (*dst + v) : v;
-                } else {
-                    __hip_atomic_fetch_add(a.C + (size_t)row * a.ldc + col, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-    }
+        for (int y = 0; y < TN; ++y)
+            gemm_epilogue_tile<MODE>(a, acc[x][y], i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
 
     if constexpr (MODE == MODE_WGRAD) {
         if (do_db) {
@@ -271,7 +219,16 @@ int launch(const GemmArgs& a, int splits, hipStream_t stream) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+int g_gemm_mode = HOS_GEMM_BF16X3;
+
 }  // namespace
+
+extern "C" int hos_set_gemm_mode(int mode) {
+    if (mode != HOS_GEMM_FP32 && mode != HOS_GEMM_BF16X3) return HOS_E_ARG;
+    g_gemm_mode = mode;
+    return HOS_OK;
+}
+extern "C" int hos_get_gemm_mode(void) { return g_gemm_mode; }
 
 extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
                               const float* W, int ldw, const float* bias, float* C, int ldc,
@@ -300,6 +257,7 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
         a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 32);
         return launch<128, 32, MODE_FWD>(a, 1, s);
     }
+    if (g_gemm_mode == HOS_GEMM_BF16X3) return hos_gemm3_launch(a, MODE_FWD, 1, s);
     a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 128);
     return launch<128, 128, MODE_FWD>(a, 1, s);
 }
@@ -317,6 +275,7 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     a.M = M; a.N = K; a.Mload = M; a.Nload = K;
     a.nk = Npad / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
+    if (g_gemm_mode == HOS_GEMM_BF16X3 && K > 32) return hos_gemm3_launch(a, MODE_DGRAD, 1, static_cast<hipStream_t>(stream));
     a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(K, 128);
     return launch<128, 128, MODE_DGRAD>(a, 1, static_cast<hipStream_t>(stream));
 }
@@ -337,6 +296,7 @@ extern "C" int hos_linear_wgrad(const float* dY, int lddy, const float* X, int l
     a.db = db;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool narrow = (N <= 32);
+    if (!narrow && g_gemm_mode == HOS_GEMM_BF16X3) return hos_gemm3_launch(a, MODE_WGRAD, splits, s);
     a.tiles_m = hos_cdiv(N, narrow ? 32 : 128);
     a.tiles_n = hos_cdiv(K, 128);
     if (splits <= 0) {

@@ -69,6 +69,18 @@ def _timed(key, flops, launch):
 
 
 # ------------------------------------------------------------------------------------------ GEMMs
+GEMM_FP32, GEMM_BF16X3 = 0, 1
+
+
+def set_gemm_mode(mode: int):
+    """0 = exact fp32 MFMA, 1 = bf16x3 split precision (default).  Process-wide."""
+    _lib.check(_lib.load().hos_set_gemm_mode(int(mode)), "hos_set_gemm_mode")
+
+
+def get_gemm_mode() -> int:
+    return int(_lib.load().hos_get_gemm_mode())
+
+
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
                out: Optional[torch.Tensor], epilogue: int = EPI_NONE, A1: Optional[torch.Tensor] = None,
                K1: int = 0, aux: Optional[torch.Tensor] = None, aux_col: int = -1, p0: float = 0.0,

@@ -46,6 +46,16 @@ const char* hos_error_string(int code);
  * All reduction dimensions must be multiples of 32 (buffers are zero-padded by the host side).
  * ------------------------------------------------------------------------------------------ */
 
+/* Arithmetic mode of the three linear entry points (process-wide):
+ *   HOS_GEMM_FP32   v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain (peak 157 TFLOP/s)
+ *   HOS_GEMM_BF16X3 (default) bf16 hi/lo split of both operands, 3 bf16 MFMAs per product, fp32 accumulate:
+ *                   fp32-grade results (2.9e-5 RGB L-inf) at 1/3 of the bf16 matrix rate (peak 833 TFLOP/s).
+ * Layers with N <= 32 always use the fp32 kernel. */
+#define HOS_GEMM_MODE_FP32 0
+#define HOS_GEMM_MODE_BF16X3 1
+int hos_set_gemm_mode(int mode);
+int hos_get_gemm_mode(void);
+
 /* epilogues for hos_linear_fwd */
 #define HOS_EPI_NONE 0       /* C = acc + bias                                                */
 #define HOS_EPI_RELU 1       /* C = relu(acc + bias)                                          */
