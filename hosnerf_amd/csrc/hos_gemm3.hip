@@ -22,6 +22,7 @@
 // A 256-wide tile needs (256+BN)*128 B of L2 traffic per 3072 (BN=256) matrix cycles per SIMD = 21 B/clk/CU,
 // inside the ~56 B/clk/CU the L2 delivers; a 128x128 tile would need 42 B/clk/CU and starve.
 #include "hos_gemm_common.h"
+#include <cstdlib>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -204,15 +205,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
         }
     };
 
-    gload(kt_begin);
-    sstore(0);
-    __syncthreads();
-
+    // Ping-pong schedule: waves 0-3 ("A") and 4-7 ("B") share the four SIMDs pairwise (wave w and w+4 sit on the
+    // same SIMD).  Per K tile there are two phases separated by barriers; in each phase one wave of a SIMD runs
+    // its 48 MFMAs while its partner converts/stores its share of the NEXT tile (VALU + LDS), so the matrix
+    // pipe and the VALU work overlap instead of alternating in lockstep (measured before this change:
+    // MFMA busy 28 %, waves parked 49 % of the time):
+    //   A:  issue loads(kt+1) | MFMA(kt)          | barrier | convert+store(kt+1) | barrier
+    //   B:  convert+store(kt+1)                    | barrier | issue loads(kt+2) | MFMA(kt) | barrier
+    // Every wave issues its global loads right before its own MFMA phase and consumes them right after it.
+    const bool grpB = __builtin_amdgcn_readfirstlane(t >> 6) >= 4;
     const int l31 = lane & 31, lhi = lane >> 5;
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) gload(kt + 1);
+
+    auto compute = [&](int buf) {
         const char* base = smem3 + buf * STAGE;
         const char* Ah = base, *Al = base + A_PLANE, *Bh = base + 2 * A_PLANE, *Bl = base + 2 * A_PLANE + B_PLANE;
 #pragma unroll
@@ -242,10 +246,31 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[x], bh[y], acc[x][y], 0, 0, 0);
                 }
         }
-        if (more) sstore(buf ^ 1);
-        __syncthreads();
+    };
+
+    gload(kt_begin);
+    sstore(0);
+    if (grpB && kt_begin + 1 < kt_end) gload(kt_begin + 1);
+    __syncthreads();
+
+    int buf = 0;
+    const int ahead = grpB ? 2 : 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (grpB) {                      // B, phase 1: convert/store its share of tile kt+1 (loaded one iteration ago)
+            if (more && !(a.ablate & 2)) sstore(buf ^ 1);
+            __syncthreads();             // B's barrier #1  <->  A's barrier #1 (the common one below)
+        }
+        if (kt + ahead < kt_end && !(a.ablate & 1)) gload(kt + ahead);    // single call site: A fetches tile kt+1, B tile kt+2
+        if (!(a.ablate & 4)) compute(buf);                                  // single call site: A runs it in phase 1, B in phase 2
+        __syncthreads();                 // A's barrier #1 / B's barrier #2
+        if (!grpB) {                     // A, phase 2: convert/store its share of tile kt+1
+            if (more && !(a.ablate & 2)) sstore(buf ^ 1);
+            __syncthreads();             // A's barrier #2  <->  B's barrier #2 (the common one)
+        }
         buf ^= 1;
     }
+    // (both groups have executed exactly two barriers per iteration: no drain needed)
 
 #pragma unroll
     for (int x = 0; x < TM; ++x)
@@ -302,6 +327,8 @@ int launch3(GemmArgs& a, int splits, hipStream_t stream) {
 }  // namespace
 
 int hos_gemm3_launch(GemmArgs a, int mode, int splits, hipStream_t stream) {
+    static const int ablate = getenv("HOS_GEMM_ABLATE") ? atoi(getenv("HOS_GEMM_ABLATE")) : 0;
+    a.ablate = ablate;
     const bool wide = a.N > 128;
     switch (mode) {
         case MODE_FWD:   return wide ? launch3<256, MODE_FWD>(a, 1, stream) : launch3<128, MODE_FWD>(a, 1, stream);
