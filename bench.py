@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SPLIT_MFMA_PEAK_TFLOPS = 2500.0 / 3   # 3 bf16/fp16 MFMAs (dense peak ~2.5 PFLOP/s) per algorithmic product
 S1_TRAIN_FLOP_PER_RAY = 1841e6     # 2*(128*881408 + 32*25242496)
 
 
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--gemm", choices=["split", "fp32"], default="split",
+                    help="split = fp16/bf16 hi-lo split MFMA (3 products, fp32 accumulate); fp32 = exact fp32 MFMA")
     return ap.parse_args()
 
 
@@ -107,6 +111,7 @@ def main():
     from hosnerf_amd.mipnerf360 import MipNeRF360
     from hosnerf_amd.train import FusedAdam, stage1_loss, stage1_lr
 
+    ops.set_gemm_mode(ops.GEMM_BF16X3 if args.gemm == "split" else ops.GEMM_FP32)
     model = MipNeRF360(basedir(), opaque_background=True)
     model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
     model = model.to(dev)
@@ -114,13 +119,18 @@ def main():
     batch = {k: v.to(dev) for k, v in synth.stage1_batch(args.rays, seed=777 + rank).items()}
     max_steps = 500000
 
-    def step(i):
+    batch["times"] = 0.5          # python float: no host sync inside the step (the reference syncs on `time` every call)
+
+    def step(i, dynamic=False, frac=None):
         opt.zero_grad()
-        rend, hist = model(batch, i / max_steps, True, True, 0.1, 1e6)
+        rend, hist = model(batch, (i / max_steps) if frac is None else frac, True, True, 0.1, 1e6)
         loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
         loss.backward()
-        opt.step(stage1_lr(i, max_steps))
-        return loss
+        if dynamic:
+            opt.step(dynamic=True)
+        else:
+            opt.step(stage1_lr(i, max_steps))
+        return loss.detach()
 
     def barrier():
         if world > 1:
@@ -130,13 +140,44 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+
+    # ---- optional: capture ONE full training step in a hipGraph and replay it (removes ~150 host launches/step).
+    # Per-step scalars that change (lr, Adam bias corrections) live in a 12-byte device block refreshed before each
+    # replay; train_frac (only the resampling anneal scalar) is frozen at its capture value.
+    graph = None
+    if world == 1 and not args.no_graph:
+        try:
+            opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    step(args.warmup, dynamic=True, frac=0.5)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step(args.warmup, dynamic=True, frac=0.5)
+            for _ in range(2):
+                opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
+                graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:      # fall back to eager launches, and say so in the JSON
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+    barrier()
     prof = None
-    if rank == 0 and not args.no_kernel_events:
+    if graph is None and rank == 0 and not args.no_kernel_events:
         prof = ops.KernelEvents()
         ops.set_kernel_events(prof)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = step(args.warmup + i)
+        if graph is not None:
+            opt.set_step_hyper(stage1_lr(args.warmup + i, max_steps))
+            graph.replay()
+            loss = static_loss
+        else:
+            loss = step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     ops.set_kernel_events(None)
@@ -145,6 +186,15 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     final_loss = float(loss.detach())
+    if graph is not None and rank == 0 and not args.no_kernel_events:
+        # per-kernel HIP-event timing cannot be recorded inside a captured graph: time the same steps eagerly
+        # right after the timed region (same kernels, same shapes; rocprofv3 --stats of this command agrees)
+        prof = ops.KernelEvents()
+        ops.set_kernel_events(prof)
+        for i in range(min(args.steps, 5)):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        ops.set_kernel_events(None)
 
     if rank == 0:
         rays_total = args.rays * world * args.steps
@@ -152,7 +202,8 @@ def main():
             "metric": "train rays/sec (stage-1 state-conditional mip-NeRF-360, fwd+loss+bwd+clip+Adam)",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
+            "dtype": "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)" if args.gemm == "split" else "f32",
+            "launch": "hipGraph replay" if graph is not None else "eager", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
             "config": {"workload": "BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, "
                                    "64/64/32 samples, PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states",
                        "rays_per_gpu": args.rays, "global_rays": args.rays * world, "parallelism": f"dp{world} (ray shards, 1 flat-gradient all-reduce/step)"},
@@ -163,8 +214,9 @@ def main():
             table = prof.summary()
             dom = max(table, key=lambda r: r["total_ms"]) if table else None
             if dom is not None:
-                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": dom["tflops"] / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                peak = SPLIT_MFMA_PEAK_TFLOPS if args.gemm == "split" else FP32_MFMA_PEAK_TFLOPS
+                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
+                                   "frac": dom["tflops"] / peak, "traffic": None,
                                    "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
                                    "flop_per_launch": dom["flop_per_launch"]}
             out["kernels"] = table

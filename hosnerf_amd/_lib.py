@@ -59,6 +59,7 @@ PROTOTYPES = {
     "hos_merge_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
     "hos_sumsq": [_P, _L, _P, _P],
     "hos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _F, _P],
+    "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
 }
 _RESTYPES = {"hos_error_string": c_char_p}
 

@@ -24,8 +24,17 @@
 #include "hos_gemm_common.h"
 #include <cstdlib>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// Split element type: __bf16 (8-bit exponent: safe for gradients of any magnitude, ~2^-17 relative error per
+// product) for DGRAD/WGRAD, _Float16 (11-bit mantissa: hi+lo carry 22 bits, ~2^-21 relative error -- fp32 grade)
+// for the FORWARD GEMMs whose operands (features, activations, weights) are O(1e-3..1e3) by construction.
+template <typename E> struct Vec { typedef E x8 __attribute__((ext_vector_type(8))); typedef E x4 __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ f32x16 mfma16(const Vec<__bf16>::x8& a, const Vec<__bf16>::x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma16(const Vec<_Float16>::x8& a, const Vec<_Float16>::x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 
 namespace {
 
@@ -36,10 +45,15 @@ constexpr int ROWB = 64;          // bytes per LDS row per plane (32 bf16)
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+template <typename E> __device__ __forceinline__ float hi_src(float x) { return x; }
+// fp16 hi part saturates at +-65504 instead of overflowing to inf; the residual then lands in lo (exact up to 131008)
+template <> __device__ __forceinline__ float hi_src<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+
+template <typename E>
+__device__ __forceinline__ void split4(const float4& v, typename Vec<E>::x4& hi, typename Vec<E>::x4& lo) {
+    hi[0] = (E)hi_src<E>(v.x); hi[1] = (E)hi_src<E>(v.y); hi[2] = (E)hi_src<E>(v.z); hi[3] = (E)hi_src<E>(v.w);
+    lo[0] = (E)(v.x - (float)hi[0]); lo[1] = (E)(v.y - (float)hi[1]);
+    lo[2] = (E)(v.z - (float)hi[2]); lo[3] = (E)(v.w - (float)hi[3]);
 }
 
 // byte offset of the 8-byte group holding k = kq*4 .. kq*4+3 of `row` inside one plane
@@ -59,17 +73,17 @@ __device__ __forceinline__ void load_kc3(float4 (&v)[ROWS / 64], const float* __
         v[r] = gi < limit ? ldg4(P + (size_t)gi * ld + k0 + kq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
-template <int ROWS>
+template <int ROWS, typename E>
 __device__ __forceinline__ void store_kc3(const float4 (&v)[ROWS / 64], char* __restrict__ hi_plane, char* __restrict__ lo_plane, int t) {
     const int kq = t & 7, ir = t >> 3;
 #pragma unroll
     for (int r = 0; r < ROWS / 64; ++r) {
         const int row = ir + 64 * r;
-        bf16x4 h, l;
-        split4(v[r], h, l);
+        typename Vec<E>::x4 h, l;
+        split4<E>(v[r], h, l);
         const int off = lds_off(row, kq);
-        *reinterpret_cast<bf16x4*>(hi_plane + off) = h;
-        *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
+        *reinterpret_cast<typename Vec<E>::x4*>(hi_plane + off) = h;
+        *reinterpret_cast<typename Vec<E>::x4*>(lo_plane + off) = l;
     }
 }
 // ---- staging: reduction-row operand P[red][i]: thread owns 4 red rows x 4 columns, ROWS/256 column groups ----
@@ -87,7 +101,7 @@ __device__ __forceinline__ void load_rc3(float4 (&v)[ROWS / 256][4], const float
         }
     }
 }
-template <int ROWS>
+template <int ROWS, typename E>
 __device__ __forceinline__ void store_rc3(const float4 (&v)[ROWS / 256][4], char* __restrict__ hi_plane, char* __restrict__ lo_plane, int t) {
     const int kg = t >> 6, ig = t & 63;
 #pragma unroll
@@ -100,17 +114,19 @@ __device__ __forceinline__ void store_rc3(const float4 (&v)[ROWS / 256][4], char
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int row = g * 256 + ig * 4 + ii;
-            bf16x4 h, l;
-            split4(cols[ii], h, l);
+            typename Vec<E>::x4 h, l;
+            split4<E>(cols[ii], h, l);
             const int off = lds_off(row, kg);
-            *reinterpret_cast<bf16x4*>(hi_plane + off) = h;
-            *reinterpret_cast<bf16x4*>(lo_plane + off) = l;
+            *reinterpret_cast<typename Vec<E>::x4*>(hi_plane + off) = h;
+            *reinterpret_cast<typename Vec<E>::x4*>(lo_plane + off) = l;
         }
     }
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, typename E>
 __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
+    typedef typename Vec<E>::x8 ex8;
+    typedef typename Vec<E>::x4 ex4;
     constexpr bool A_KC = (MODE != MODE_WGRAD);
     constexpr bool B_KC = (MODE == MODE_FWD);
     constexpr int WM = 4, WN = 2;
@@ -182,11 +198,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
     auto sstore = [&](int buf) {
         char* base = smem3 + buf * STAGE;
         char* Ah = base, *Al = base + A_PLANE, *Bh = base + 2 * A_PLANE, *Bl = base + 2 * A_PLANE + B_PLANE;
-        if constexpr (A_KC) store_kc3<BM>(ra_kc, Ah, Al, t);
-        else                store_rc3<BM>(ra_rc, Ah, Al, t);
-        if constexpr (B_KC) store_kc3<BN>(rb_kc, Bh, Bl, t);
+        if constexpr (A_KC) store_kc3<BM, E>(ra_kc, Ah, Al, t);
+        else                store_rc3<BM, E>(ra_rc, Ah, Al, t);
+        if constexpr (B_KC) store_kc3<BN, E>(rb_kc, Bh, Bl, t);
         else {
-            if constexpr (BN >= 256) store_rc3<BN>(rb_rc, Bh, Bl, t);
+            if constexpr (BN >= 256) store_rc3<BN, E>(rb_rc, Bh, Bl, t);
             else if ((t & 63) < 32) {
                 const int kg = t >> 6, ig = t & 63;
                 const float4 cols[4] = {make_float4(rb_rc[0][0].x, rb_rc[0][1].x, rb_rc[0][2].x, rb_rc[0][3].x),
@@ -195,11 +211,11 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
                                         make_float4(rb_rc[0][0].w, rb_rc[0][1].w, rb_rc[0][2].w, rb_rc[0][3].w)};
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    bf16x4 h, l;
-                    split4(cols[ii], h, l);
+                    ex4 h, l;
+                    split4<E>(cols[ii], h, l);
                     const int off = lds_off(ig * 4 + ii, kg);
-                    *reinterpret_cast<bf16x4*>(Bh + off) = h;
-                    *reinterpret_cast<bf16x4*>(Bl + off) = l;
+                    *reinterpret_cast<ex4*>(Bh + off) = h;
+                    *reinterpret_cast<ex4*>(Bl + off) = l;
                 }
             }
         }
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
     //   A:  issue loads(kt+1) | MFMA(kt)          | barrier | convert+store(kt+1) | barrier
     //   B:  convert+store(kt+1)                    | barrier | issue loads(kt+2) | MFMA(kt) | barrier
     // Every wave issues its global loads right before its own MFMA phase and consumes them right after it.
-    const bool grpB = __builtin_amdgcn_readfirstlane(t >> 6) >= 4;
+    const bool grpB = !(a.ablate & 8) && __builtin_amdgcn_readfirstlane(t >> 6) >= 4;   // ablate&8: lockstep schedule
     const int l31 = lane & 31, lhi = lane >> 5;
 
     auto compute = [&](int buf) {
@@ -222,28 +238,28 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int c = 2 * s + lhi;                  // 16-byte k chunk: k = 8c .. 8c+7
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+            ex8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int x = 0; x < TM; ++x) {
                 const int row = wm * (TM * 32) + x * 32 + l31;
                 const int off = row * ROWB + ((c ^ ((row >> 2) & 3)) * 16);
-                ah[x] = *reinterpret_cast<const bf16x8*>(Ah + off);
-                al[x] = *reinterpret_cast<const bf16x8*>(Al + off);
+                ah[x] = *reinterpret_cast<const ex8*>(Ah + off);
+                al[x] = *reinterpret_cast<const ex8*>(Al + off);
             }
 #pragma unroll
             for (int y = 0; y < TN; ++y) {
                 const int row = wn * (TN * 32) + y * 32 + l31;
                 const int off = row * ROWB + ((c ^ ((row >> 2) & 3)) * 16);
-                bh[y] = *reinterpret_cast<const bf16x8*>(Bh + off);
-                bl[y] = *reinterpret_cast<const bf16x8*>(Bl + off);
+                bh[y] = *reinterpret_cast<const ex8*>(Bh + off);
+                bl[y] = *reinterpret_cast<const ex8*>(Bl + off);
             }
 #pragma unroll
             for (int x = 0; x < TM; ++x)
 #pragma unroll
                 for (int y = 0; y < TN; ++y) {
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[x], bh[y], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[x], bl[y], acc[x][y], 0, 0, 0);
-                    acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[x], bh[y], acc[x][y], 0, 0, 0);
+                    acc[x][y] = mfma16(al[x], bh[y], acc[x][y]);
+                    acc[x][y] = mfma16(ah[x], bl[y], acc[x][y]);
+                    acc[x][y] = mfma16(ah[x], bh[y], acc[x][y]);
                 }
         }
     };
@@ -295,12 +311,12 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
     }
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, typename E>
 int launch3(GemmArgs& a, int splits, hipStream_t stream) {
     constexpr size_t smem = 2 * (2 * BM * ROWB + 2 * BN * ROWB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BN, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<BN, MODE, E>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -320,7 +336,7 @@ int launch3(GemmArgs& a, int splits, hipStream_t stream) {
         splits = 1;
         a.kt_per_split = a.nk;
     }
-    hipLaunchKernelGGL((gemm3_kernel<BN, MODE>), dim3(a.tiles_m * a.tiles_n * splits), dim3(NT3), smem, stream, a);
+    hipLaunchKernelGGL((gemm3_kernel<BN, MODE, E>), dim3(a.tiles_m * a.tiles_n * splits), dim3(NT3), smem, stream, a);
     return hos_launch_status();
 }
 
@@ -331,8 +347,8 @@ int hos_gemm3_launch(GemmArgs a, int mode, int splits, hipStream_t stream) {
     a.ablate = ablate;
     const bool wide = a.N > 128;
     switch (mode) {
-        case MODE_FWD:   return wide ? launch3<256, MODE_FWD>(a, 1, stream) : launch3<128, MODE_FWD>(a, 1, stream);
-        case MODE_DGRAD: return wide ? launch3<256, MODE_DGRAD>(a, 1, stream) : launch3<128, MODE_DGRAD>(a, 1, stream);
-        default:         return wide ? launch3<256, MODE_WGRAD>(a, splits, stream) : launch3<128, MODE_WGRAD>(a, splits, stream);
+        case MODE_FWD:   return wide ? launch3<256, MODE_FWD, _Float16>(a, 1, stream) : launch3<128, MODE_FWD, _Float16>(a, 1, stream);
+        case MODE_DGRAD: return wide ? launch3<256, MODE_DGRAD, __bf16>(a, 1, stream) : launch3<128, MODE_DGRAD, __bf16>(a, 1, stream);
+        default:         return wide ? launch3<256, MODE_WGRAD, __bf16>(a, splits, stream) : launch3<128, MODE_WGRAD, __bf16>(a, splits, stream);
     }
 }

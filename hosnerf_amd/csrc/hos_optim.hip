@@ -35,7 +35,9 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float bc1, float rsbc2,
-                                                   float grad_scale, const float* __restrict__ sumsq, float max_norm) {
+                                                   float grad_scale, const float* __restrict__ sumsq, float max_norm,
+                                                   const float* __restrict__ hyper) {
+    if (hyper != nullptr) { lr = hyper[0]; bc1 = hyper[1]; rsbc2 = hyper[2]; }   // per-step values from device memory (graph replay)
     float gs = grad_scale;
     if (sumsq != nullptr && max_norm > 0.f) {
         // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to 1
@@ -85,7 +87,20 @@ extern "C" int hos_adam_step(float* p, const float* g, float* m, float* v, int64
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, lr,
-                       beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm);
+                       beta1, beta2, eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, sumsq, max_norm, (const float*)nullptr);
+    return hos_launch_status();
+}
+
+extern "C" int hos_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                 float beta1, float beta2, float eps, float grad_scale, const float* sumsq,
+                                 float max_norm, hos_stream_t stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) return HOS_E_ARG;
+    HOS_CHECK_ALIGN16(p); HOS_CHECK_ALIGN16(g); HOS_CHECK_ALIGN16(m); HOS_CHECK_ALIGN16(v);
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, 0.f,
+                       beta1, beta2, eps, 1.f, 1.f, grad_scale, sumsq, max_norm, hyper);
     return hos_launch_status();
 }
 

@@ -414,9 +414,10 @@ class MipNeRF360(FlatModule):
         B = rays_o.shape[0]
         dev = rays_o.device
         times = batch["times"]
-        time = float(times.reshape(-1)[0]) if isinstance(times, torch.Tensor) else float(times)   # host sync, as in M:230
+        # the reference branches on `time` in python (M:230) = one host sync per call; pass a python float to avoid it
+        time = float(times.reshape(-1)[0]) if isinstance(times, torch.Tensor) else float(times)
 
-        sdist = torch.tensor([0.0, 1.0], device=dev).repeat(B, 1)
+        sdist = torch.cat([torch.zeros(B, 1, device=dev), torch.ones(B, 1, device=dev)], dim=-1)
         weights = torch.ones(B, 1, device=dev)
         prod = 1
         anneal = (self.anneal_slope * train_frac) / ((self.anneal_slope - 1) * train_frac + 1) if self.anneal_slope > 0 else 1.0

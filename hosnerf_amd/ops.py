@@ -496,3 +496,9 @@ def slice_mask(src, col0, mask_src, mcol0, width, out):
 
 def rgbsigma_grad(g, y, dz):
     call("hos_rgbsigma_grad", ptr(g), ptr(y), y.shape[0], ptr(dz), dz.stride(0))
+
+
+def adam_step_dyn(p, g, m, v, hyper, beta1, beta2, eps, grad_scale=1.0, sumsq_buf=None, max_norm=0.0):
+    """Adam with (lr, bias corrections) read from the device tensor `hyper` [3] -- graph-replay friendly."""
+    call("hos_adam_step_dyn", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), float(beta1), float(beta2),
+         float(eps), float(grad_scale), ptr(sumsq_buf), float(max_norm))

@@ -76,6 +76,18 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(p)
         self._sumsq = torch.zeros(1, device=p.device)
         self.step_count = 0
+        self._hyper = None      # device [lr, 1-b1^t, 1/sqrt(1-b2^t)] for graph-captured steps
+
+    def set_step_hyper(self, lr: Optional[float] = None):
+        """Advance the step counter and refresh the 12-byte device hyper-parameter block (call OUTSIDE a captured
+        graph, before each replay).  `step(dynamic=True)` then reads lr / bias corrections from device memory."""
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        vals = [lr, 1.0 - self.betas[0] ** self.step_count, 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)]
+        host = torch.tensor(vals, dtype=torch.float32).pin_memory()
+        if self._hyper is None:
+            self._hyper = torch.empty(3, device=self.module.flat_param.device)
+        self._hyper.copy_(host, non_blocking=True)
 
     def zero_grad(self):
         self.module.store.zero_grad()
@@ -83,9 +95,21 @@ class FusedAdam:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def step(self, lr: Optional[float] = None):
+    def step(self, lr: Optional[float] = None, dynamic: bool = False):
         g = self.module.flat_grad
         world = allreduce_flat_grad(self.module, self.group)
+        if dynamic:
+            sumsq = None
+            if self.max_grad_norm > 0:
+                self._sumsq.zero_()
+                ops.sumsq(g, self._sumsq)
+                sumsq = self._sumsq
+            p = self.module.flat_param
+            for off, n, mult in (self.lr_ranges or [(0, p.numel(), 1.0)]):
+                assert mult == 1.0, "per-range LR multipliers need one hyper block per range"
+                ops.adam_step_dyn(p[off:off + n], g[off:off + n], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n],
+                                  self._hyper, self.betas[0], self.betas[1], self.eps, 1.0 / world, sumsq, self.max_grad_norm)
+            return
         self.step_count += 1
         sumsq = None
         if self.max_grad_norm > 0:

@@ -260,6 +260,12 @@ int hos_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float beta2, float eps, int step, float grad_scale, const float* sumsq,
                   float max_norm, hos_stream_t stream);
 
+/* Same update with the per-step scalars read from device memory: hyper = {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}.
+ * Lets a whole training step be captured once in a hipGraph and replayed (the host only refreshes 12 bytes). */
+int hos_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                      float beta1, float beta2, float eps, float grad_scale, const float* sumsq,
+                      float max_norm, hos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
