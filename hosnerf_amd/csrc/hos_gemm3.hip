@@ -90,7 +90,9 @@ __device__ __forceinline__ void store_kc3(const float4 (&v)[ROWS / 64], char* __
 template <int ROWS>
 __device__ __forceinline__ void load_rc3(float4 (&v)[ROWS / 256][4], const float* __restrict__ P, int ld, int i0, int limit,
                                          int k0, int t, int row_limit) {
-    const int kg = t >> 6, ig = t & 63;
+    // lane -> (k group = t&7, column group = t>>3): a 16-lane LDS-store group then covers 8 k-groups x 2 rows
+    // (2-way conflicts); the previous (t>>6, t&63) mapping put all 64 lanes of a wave on 4 bank slots (16-way).
+    const int kg = t & 7, ig = t >> 3;
 #pragma unroll
     for (int g = 0; g < ROWS / 256; ++g) {
         const int gi = i0 + g * 256 + ig * 4;
@@ -103,7 +105,7 @@ __device__ __forceinline__ void load_rc3(float4 (&v)[ROWS / 256][4], const float
 }
 template <int ROWS, typename E>
 __device__ __forceinline__ void store_rc3(const float4 (&v)[ROWS / 256][4], char* __restrict__ hi_plane, char* __restrict__ lo_plane, int t) {
-    const int kg = t >> 6, ig = t & 63;
+    const int kg = t & 7, ig = t >> 3;
 #pragma unroll
     for (int g = 0; g < ROWS / 256; ++g) {
         const float4 c0 = make_float4(v[g][0].x, v[g][1].x, v[g][2].x, v[g][3].x);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
         } else {
             if constexpr (BN >= 256) load_rc3<BN>(rb_rc, a.B, a.ldb, j0, a.Nload, kt * BK, t, a.red_limit);
             else {   // BN = 128: half of the threads (column groups 0..31) own a micro-tile
-                const int kg = t >> 6, ig = t & 63;
+                const int kg = t & 7, ig = t >> 3;
                 const int gi = j0 + ig * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
         if constexpr (B_KC) store_kc3<BN, E>(rb_kc, Bh, Bl, t);
         else {
             if constexpr (BN >= 256) store_rc3<BN, E>(rb_rc, Bh, Bl, t);
-            else if ((t & 63) < 32) {
-                const int kg = t >> 6, ig = t & 63;
+            else if ((t >> 3) < 32) {
+                const int kg = t & 7, ig = t >> 3;
                 const float4 cols[4] = {make_float4(rb_rc[0][0].x, rb_rc[0][1].x, rb_rc[0][2].x, rb_rc[0][3].x),
                                         make_float4(rb_rc[0][0].y, rb_rc[0][1].y, rb_rc[0][2].y, rb_rc[0][3].y),
                                         make_float4(rb_rc[0][0].z, rb_rc[0][1].z, rb_rc[0][2].z, rb_rc[0][3].z),
@@ -296,16 +298,18 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
 
     if constexpr (MODE == MODE_WGRAD) {
         if (do_db) {
-            // thread (kg, ig) holds column sums of rows kg*4.. for columns ig*4..+3 -> reduce over the 8 kg groups
-            float* red = reinterpret_cast<float*>(smem3);
-            const int kg = t >> 6, ig = t & 63;
-            *reinterpret_cast<float4*>(red + kg * BM + ig * 4) = bsum;
-            __syncthreads();
-            if (t < BM) {
-                float s = 0.f;
+            // thread (kg = t&7, ig = t>>3) holds column sums of its 4 rows for columns ig*4..+3: reduce over the 8 kg lanes
 #pragma unroll
-                for (int r = 0; r < 8; ++r) s += red[r * BM + t];
-                if (i0 + t < a.M) __hip_atomic_fetch_add(a.db + i0 + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int o = 1; o < 8; o <<= 1) {
+                bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+                bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+            }
+            if ((t & 7) == 0 && i0 + (t >> 3) * 4 < a.M) {
+                const int c0 = i0 + (t >> 3) * 4;
+                const float vals[4] = {bsum.x, bsum.y, bsum.z, bsum.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c0 + k < a.M) __hip_atomic_fetch_add(a.db + c0 + k, vals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -324,6 +328,8 @@ int launch3(GemmArgs& a, int splits, hipStream_t stream) {
     a.tiles_m = hos_cdiv(a.M, BM);
     a.tiles_n = hos_cdiv(a.N, BN);
     if (MODE == MODE_WGRAD) {
+        static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
+        if (env_splits > 0) splits = env_splits;
         if (splits <= 0) {
             const int tiles = a.tiles_m * a.tiles_n;
             splits = hos_cdiv(512, tiles);                       // ~2 workgroups per CU
