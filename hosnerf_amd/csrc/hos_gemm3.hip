@@ -273,21 +273,35 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
 
     int buf = 0;
     const int ahead = grpB ? 2 : 1;
+    // debug timeline (HOS_GEMM_ABLATE & 16): lane 0 of every wave of tile 0 stamps s_memtime at the phase
+    // boundaries of K tiles 8..11 into a.aux (as long long[8 waves][4 iters][8 stamps])
+    const bool trace = (a.ablate & 16) && bid == 0 && lane == 0 && a.aux != nullptr;
+    long long* tr = reinterpret_cast<long long*>(a.aux);
+#define HOS_STAMP(slot) do { if (trace && kt >= kt_begin + 8 && kt < kt_begin + 12) tr[(wave * 4 + (kt - kt_begin - 8)) * 8 + (slot)] = clock64(); } while (0)
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = kt + 1 < kt_end;
+        HOS_STAMP(0);
         if (grpB) {                      // B, phase 1: convert/store its share of tile kt+1 (loaded one iteration ago)
             if (more && !(a.ablate & 2)) sstore(buf ^ 1);
+            HOS_STAMP(1);
             __syncthreads();             // B's barrier #1  <->  A's barrier #1 (the common one below)
         }
+        HOS_STAMP(2);
         if (kt + ahead < kt_end && !(a.ablate & 1)) gload(kt + ahead);    // single call site: A fetches tile kt+1, B tile kt+2
+        HOS_STAMP(3);
         if (!(a.ablate & 4)) compute(buf);                                  // single call site: A runs it in phase 1, B in phase 2
+        HOS_STAMP(4);
         __syncthreads();                 // A's barrier #1 / B's barrier #2
+        HOS_STAMP(5);
         if (!grpB) {                     // A, phase 2: convert/store its share of tile kt+1
             if (more && !(a.ablate & 2)) sstore(buf ^ 1);
+            HOS_STAMP(6);
             __syncthreads();             // A's barrier #2  <->  B's barrier #2 (the common one)
         }
+        HOS_STAMP(7);
         buf ^= 1;
     }
+#undef HOS_STAMP
     // (both groups have executed exactly two barriers per iteration: no drain needed)
 
 #pragma unroll

@@ -502,3 +502,89 @@ def adam_step_dyn(p, g, m, v, hyper, beta1, beta2, eps, grad_scale=1.0, sumsq_bu
     """Adam with (lr, bias corrections) read from the device tensor `hyper` [3] -- graph-replay friendly."""
     call("hos_adam_step_dyn", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper), float(beta1), float(beta2),
          float(eps), float(grad_scale), ptr(sumsq_buf), float(max_norm))
+
+
+# ------------------------------------------------------------------------------------------ planes GEMMs
+class Planes:
+    """A matrix stored as two 16-bit planes (hi, lo) in one [2, R, ld] tensor; value = hi + lo.
+    dtype torch.float16 for forward operands, torch.bfloat16 for gradient-side operands."""
+
+    __slots__ = ("t", "rows", "cols")
+
+    def __init__(self, t: torch.Tensor, rows: int, cols: int):
+        self.t, self.rows, self.cols = t, rows, cols
+
+    @staticmethod
+    def empty(rows: int, ld: int, dtype, device, cols: Optional[int] = None):
+        return Planes(torch.empty(2, rows, ld, dtype=dtype, device=device), rows, ld if cols is None else cols)
+
+    @property
+    def hi(self):
+        return self.t[0]
+
+    @property
+    def lo(self):
+        return self.t[1]
+
+    @property
+    def ld(self) -> int:
+        return self.t.shape[2]
+
+    def float(self) -> torch.Tensor:
+        return (self.t[0].float() + self.t[1].float())[:, :self.cols]
+
+
+def _pp(x):
+    """device pointer of a plane (contiguous 2-D 16-bit tensor) or 0."""
+    if x is None:
+        return 0
+    if not (x.is_cuda and x.is_contiguous() and x.element_size() == 2):
+        raise _lib.HosLibraryError("expected a contiguous 16-bit HIP tensor plane")
+    return x.data_ptr()
+
+
+def split_planes(src: torch.Tensor, C: Optional[int] = None, dtype=torch.float16, ldo: Optional[int] = None,
+                 transposed: bool = False, ldt: Optional[int] = None, row_major: bool = True):
+    """fp32 [R, lds] -> (row-major Planes [R][ldo] | None, transposed Planes [C][ldt] | None)."""
+    R = src.shape[0]
+    C = src.shape[1] if C is None else C
+    dev = src.device
+    out = outT = None
+    if row_major:
+        ldo = round_up(C, 32) if ldo is None else ldo
+        out = Planes.empty(R, ldo, dtype, dev, C)
+    if transposed:
+        ldt = round_up(R, 32) if ldt is None else ldt
+        outT = Planes.empty(C, ldt, dtype, dev, R)
+    call("hos_split_planes", ptr(src), src.stride(0), R, C, 0 if dtype == torch.float16 else 1,
+         _pp(None if out is None else out.hi), _pp(None if out is None else out.lo), 0 if out is None else out.ld,
+         _pp(None if outT is None else outT.hi), _pp(None if outT is None else outT.lo), 0 if outT is None else outT.ld)
+    return out, outT
+
+
+def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool = True, Y: Optional[Planes] = None,
+                YT: Optional[Planes] = None, A1: Optional[Planes] = None, K1: int = 0, C: Optional[torch.Tensor] = None,
+                epilogue: int = EPI_NONE, aux=None, aux_col: int = -1, p0: float = 0.0):
+    if epilogue == EPI_RESIDUAL:
+        aux_col = aux.stride(0)
+    _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
+        "hos_linearp_fwd", _pp(A.hi), _pp(A.lo), A.ld, K0, _pp(None if A1 is None else A1.hi), _pp(None if A1 is None else A1.lo),
+        0 if A1 is None else A1.ld, K1, _pp(W.hi), _pp(W.lo), W.ld, ptr(bias), M, N, int(relu),
+        _pp(None if Y is None else Y.hi), _pp(None if Y is None else Y.lo), 0 if Y is None else Y.ld,
+        _pp(None if YT is None else YT.hi), _pp(None if YT is None else YT.lo), 0 if YT is None else YT.ld,
+        ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
+
+
+def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optional[Planes] = None,
+                  dX: Optional[Planes] = None, dXT: Optional[Planes] = None):
+    _timed(f"gemmp_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
+        "hos_linearp_dgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(WT.hi), _pp(WT.lo), WT.ld, Npad,
+        _pp(None if mask is None else mask.hi), 0 if mask is None else mask.ld, M, K,
+        _pp(None if dX is None else dX.hi), _pp(None if dX is None else dX.lo), 0 if dX is None else dX.ld,
+        _pp(None if dXT is None else dXT.hi), _pp(None if dXT is None else dXT.lo), 0 if dXT is None else dXT.ld))
+
+
+def linearp_wgrad(dZT: Planes, XT: Planes, dW: torch.Tensor, db, M: int, N: int, K: int, w_col0: int = 0, splits: int = 0):
+    _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
+        "hos_linearp_wgrad", _pp(dZT.hi), _pp(dZT.lo), dZT.ld, _pp(XT.hi), _pp(XT.lo), XT.ld,
+        ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits))
