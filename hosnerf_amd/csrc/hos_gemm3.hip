@@ -266,6 +266,42 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
         }
     };
 
+    // Software L2 prefetch.  A tile's operand loads miss L2 (the row operand is streamed from HBM, the weight
+    // panel is evicted by it) and a wave has only one MFMA phase (~0.6 us) between issuing a tile's loads and
+    // needing them -- less than the loaded HBM latency, which made the kernel latency-bound at ~10 B/clk/CU
+    // (scripts/probe/*: the same access pattern streams at 23 B/clk/CU when enough requests are in flight).
+    // Each thread therefore touches ONE dword of one 128-byte line of the tile `pf_dist` tiles ahead
+    // (512 threads = the 256 + 256 lines of an A and a B tile); the value is only "used" by an empty asm one
+    // iteration later, so the real loads that follow find their lines in L2.  (pf_dist = 0 degenerates to touching
+    // the current, already resident tile.)
+    float pfv = 0.f;
+    auto prefetch = [&](int kt) {
+        const int line = t & 255;
+        const float* p = a.B;                  // always-valid fallback: the load below must be unconditional, or the
+                                               // compiler has to drain it (vmcnt(0)) before the next tile's LDS stores
+        if (t < 256) {
+            if constexpr (A_KC) {
+                const float* P = a.A0; int ld = a.lda0; int k0 = kt * BK;
+                if (MODE == MODE_FWD && kt >= a.kt0) { P = a.A1; ld = a.lda1; k0 = (kt - a.kt0) * BK; }
+                const int gi = i0 + line;
+                if (gi < a.Mload) p = P + (size_t)gi * ld + k0;
+            } else {
+                const int row = kt * BK + (line >> 3), gi = i0 + (line & 7) * 32;
+                if (row < a.red_limit && gi < a.Mload) p = a.A0 + (size_t)row * a.lda0 + gi;
+            }
+        } else {
+            if constexpr (B_KC) {
+                const int gj = j0 + line;
+                if (line < BN && gj < a.Nload) p = a.B + (size_t)gj * a.ldb + kt * BK;
+            } else {
+                const int row = kt * BK + (line >> 3), cj = (line & 7) * 32;
+                if (cj < BN && row < a.red_limit && j0 + cj < a.Nload) p = a.B + (size_t)row * a.ldb + j0 + cj;
+            }
+        }
+        pfv = *p;
+    };
+    const int pf = a.pf_dist;
+
     gload(kt_begin);
     sstore(0);
     if (grpB && kt_begin + 1 < kt_end) gload(kt_begin + 1);
@@ -287,7 +323,9 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
             __syncthreads();             // B's barrier #1  <->  A's barrier #1 (the common one below)
         }
         HOS_STAMP(2);
-        if (kt + ahead < kt_end && !(a.ablate & 1)) gload(kt + ahead);    // single call site: A fetches tile kt+1, B tile kt+2
+        asm volatile("" :: "v"(pfv));                                       // retire the previous prefetch
+        if (kt + ahead < kt_end && !(a.ablate & 1)) gload(kt + ahead);
+        prefetch(min(kt + pf, kt_end - 1));    // single call site: A fetches tile kt+1, B tile kt+2
         HOS_STAMP(3);
         if (!(a.ablate & 4)) compute(buf);                                  // single call site: A runs it in phase 1, B in phase 2
         HOS_STAMP(4);
@@ -365,6 +403,8 @@ int launch3(GemmArgs& a, int splits, hipStream_t stream) {
 int hos_gemm3_launch(GemmArgs a, int mode, int splits, hipStream_t stream) {
     static const int ablate = getenv("HOS_GEMM_ABLATE") ? atoi(getenv("HOS_GEMM_ABLATE")) : 0;
     a.ablate = ablate;
+    static const int pf_dist = getenv("HOS_GEMM_PF") ? atoi(getenv("HOS_GEMM_PF")) : 3;
+    a.pf_dist = pf_dist;
     const bool wide = a.N > 128;
     switch (mode) {
         case MODE_FWD:   return wide ? launch3<256, MODE_FWD, _Float16>(a, 1, stream) : launch3<128, MODE_FWD, _Float16>(a, 1, stream);

@@ -26,6 +26,7 @@ struct GemmArgs {
     int accumulate;
     int epi;
     int ablate;              // debug only (HOS_GEMM_ABLATE): 1 = skip global loads, 2 = skip convert/store, 4 = skip MFMA
+    int pf_dist;             // split kernels: software L2 prefetch distance in K tiles (0 = off; HOS_GEMM_PF)
 };
 
 

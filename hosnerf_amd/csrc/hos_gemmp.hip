@@ -118,17 +118,26 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int g_row0 = isB ? j0 : i0;
     const int g_limit = isB ? a.N : a.M;
 
+    // Source planes of this wave, selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc
+    // build a pointer table in scratch; every scratch_load result was then waited for with vmcnt(0), which drained
+    // the LDS-DMA queue before EACH global_load_lds and serialised the eight requests of a tile.)
+    const uint16_t* P0; const uint16_t* P1; int ld0, ld1;
+    if (plane == 0)      { P0 = a.Ahi; P1 = a.A1hi; ld0 = a.lda; ld1 = a.lda1; }
+    else if (plane == 1) { P0 = a.Alo; P1 = a.A1lo; ld0 = a.lda; ld1 = a.lda1; }
+    else if (plane == 2) { P0 = a.Bhi; P1 = a.Bhi;  ld0 = a.ldb; ld1 = a.ldb; }
+    else                 { P0 = a.Blo; P1 = a.Blo;  ld0 = a.ldb; ld1 = a.ldb; }
+    const int kt0 = isB ? 0x7fffffff : a.kt0;
+    char* const lds_wave = smemp + lds_plane_off + lds_row0 * PROWB;
+
     auto issue_dma = [&](int q, int kt, int stage) {
-        // source plane / leading dimension (A may switch to its second K segment)
-        const uint16_t* P; int ld; int k0 = kt * PBK;
-        if (isB) { P = (plane == 2) ? a.Bhi : a.Blo; ld = a.ldb; }
-        else if (kt >= a.kt0) { P = (plane == 0) ? a.A1hi : a.A1lo; ld = a.lda1; k0 = (kt - a.kt0) * PBK; }
-        else { P = (plane == 0) ? a.Ahi : a.Alo; ld = a.lda; }
+        const bool seg1 = kt >= kt0;                                     // A may switch to its second K segment
+        const uint16_t* P = seg1 ? P1 : P0;
+        const int ld = seg1 ? ld1 : ld0;
+        const int k0 = (seg1 ? kt - kt0 : kt) * PBK;
         int gr = g_row0 + row_l + 16 * q;
         gr = gr < g_limit ? gr : g_limit - 1;                          // clamp: out-of-range rows are never stored
-        const uint16_t* src = P + (size_t)gr * ld + k0 + clog * 8;
-        char* dst = smemp + stage * STAGE + lds_plane_off + (lds_row0 + 16 * q) * PROWB;   // wave-uniform
-        dma16(src, dst);
+        const unsigned off = (unsigned)gr * (unsigned)ld + (unsigned)(k0 + clog * 8);      // planes are < 2^32 elements
+        dma16(P + off, lds_wave + stage * STAGE + q * 16 * PROWB);      // LDS address is wave-uniform
     };
 
     f32x16 acc[TM][TN];
@@ -143,70 +152,101 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     float dbsum = 0.f;
     const bool do_db = (EPI == PEPI_WGRAD) && a.f32.db != nullptr && tn_i == 0;
 
+    // ---- main loop: software-pipelined over QUARTER tiles (k half s = 0/1  x  column half yh = 0/1) -----------
+    // Two A fragment sets (one per k half) and two B fragment sets (one per quarter) rotate so that every
+    // quarter's ds_reads fly under the previous quarter's MFMAs; two LDS stages; the DMA runs one tile ahead:
+    //     read B1=(s0,yh1)              | MFMA (A0,B0)
+    //     read A1=(s1), B0=(s1,yh0)     | MFMA (A0,B1)
+    //     read B1=(s1,yh1)              | MFMA (A1,B0)
+    //     wait DMA(kt+1) + own reads, barrier        <- one barrier per K tile
+    //     DMA(kt+2) -> stage(kt) | read A0,B0 of kt+1 | MFMA (A1,B1)
+    // All waits are explicit (counted asm s_waitcnt + raw s_barrier): __syncthreads() would drain the LDS-DMA
+    // queue (vmcnt(0)) at every barrier, which serialises DMA and MFMA at one workgroup per CU.
+    constexpr int TH = TN / 2;
+    ex8 a0h[TM], a0l[TM], a1h[TM], a1l[TM], b0h[TH], b0l[TH], b1h[TH], b1l[TH];
+    auto read_a = [&](const char* base, int s, ex8 (&ah)[TM], ex8 (&al)[TM]) {
+        const int c = 2 * s + lhi;
 #pragma unroll
-    for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt_begin, 0);
+        for (int x = 0; x < TM; ++x) {
+            const int row = wm * (TM * 32) + x * 32 + l31;
+            const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
+            ah[x] = *reinterpret_cast<const ex8*>(base + off);
+            al[x] = *reinterpret_cast<const ex8*>(base + A_PLANE + off);
+        }
+    };
+    auto read_b = [&](const char* base, int s, int yh, ex8 (&bh)[TH], ex8 (&bl)[TH]) {
+        const int c = 2 * s + lhi;
+#pragma unroll
+        for (int y = 0; y < TH; ++y) {
+            const int row = wn * (TN * 32) + (yh * TH + y) * 32 + l31;
+            const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
+            bh[y] = *reinterpret_cast<const ex8*>(base + 2 * A_PLANE + off);
+            bl[y] = *reinterpret_cast<const ex8*>(base + 2 * A_PLANE + B_PLANE + off);
+        }
+    };
+#define HOS_MMA(AH, AL, BH, BL, YH)                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        __builtin_amdgcn_s_setprio(1);                                                   \
+        if (!(a.ablate & 4)) {                                                           \
+            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
+            _Pragma("unroll") for (int y = 0; y < TH; ++y) {                             \
+                acc[x][(YH) * TH + y] = pmfma(AL[x], BH[y], acc[x][(YH) * TH + y]);      \
+                acc[x][(YH) * TH + y] = pmfma(AH[x], BL[y], acc[x][(YH) * TH + y]);      \
+                acc[x][(YH) * TH + y] = pmfma(AH[x], BH[y], acc[x][(YH) * TH + y]);      \
+            }                                                                            \
+        }                                                                                \
+        __builtin_amdgcn_s_setprio(0);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+    auto issue_tile = [&](int kt, int stage) {
+        if (a.ablate & 1) return;
+#pragma unroll
+        for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt, stage);
+    };
+
+    issue_tile(kt_begin, 0);
+    if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_barrier" ::: "memory");
+    read_a(smemp, 0, a0h, a0l);
+    read_b(smemp, 0, 0, b0h, b0l);
 
     int stage = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
         const char* base = smemp + stage * STAGE;
-        const char* Ah = base, *Al = base + A_PLANE, *Bh = base + 2 * A_PLANE, *Bl = base + 2 * A_PLANE + B_PLANE;
-        int qn = 0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int c = 2 * s + lhi;
-            ex8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int x = 0; x < TM; ++x) {
-                const int row = wm * (TM * 32) + x * 32 + l31;
-                const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
-                ah[x] = *reinterpret_cast<const ex8*>(Ah + off);
-                al[x] = *reinterpret_cast<const ex8*>(Al + off);
-            }
-#pragma unroll
-            for (int y = 0; y < TN; ++y) {
-                const int row = wn * (TN * 32) + y * 32 + l31;
-                const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
-                bh[y] = *reinterpret_cast<const ex8*>(Bh + off);
-                bl[y] = *reinterpret_cast<const ex8*>(Bl + off);
-            }
-#pragma unroll
-            for (int x = 0; x < TM; ++x)
-#pragma unroll
-                for (int y = 0; y < TN; ++y) {
-                    if (!(a.ablate & 4)) {
-                        acc[x][y] = pmfma(al[x], bh[y], acc[x][y]);
-                        acc[x][y] = pmfma(ah[x], bl[y], acc[x][y]);
-                        acc[x][y] = pmfma(ah[x], bh[y], acc[x][y]);
-                    } else {
-                        asm volatile("" :: "v"(ah[x]), "v"(al[x]), "v"(bh[y]), "v"(bl[y]));
-                    }
-                    // one DMA instruction of the NEXT tile after every (x,y) block: the vector-memory path drains
-                    // while the matrix pipe works, instead of 8 back-to-back requests stalling the issue
-                    if (more && qn < nq && !(a.ablate & 1)) { issue_dma(qn, kt + 1, stage ^ 1); }
-                    ++qn;
-                }
-        }
-#pragma unroll
-        for (int q = 2 * TM * TN; q < QMAX; ++q) if (more && q < nq) issue_dma(q, kt + 1, stage ^ 1);
+        read_b(base, 0, 1, b1h, b1l);
         if constexpr (EPI == PEPI_WGRAD) {
             if (do_db && t < PBM) {      // bias gradient: row sums of the dZt tile (hi + lo planes), 32 m values per K tile
                 const int sw = (t >> 2) & 3;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const ex8 h = *reinterpret_cast<const ex8*>(Ah + t * PROWB + ((c ^ sw) * 16));
-                    const ex8 l = *reinterpret_cast<const ex8*>(Al + t * PROWB + ((c ^ sw) * 16));
+                    const ex8 h = *reinterpret_cast<const ex8*>(base + t * PROWB + ((c ^ sw) * 16));
+                    const ex8 l = *reinterpret_cast<const ex8*>(base + A_PLANE + t * PROWB + ((c ^ sw) * 16));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) dbsum += (float)h[e] + (float)l[e];
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        HOS_MMA(a0h, a0l, b0h, b0l, 0);
+        read_a(base, 1, a1h, a1l);
+        read_b(base, 1, 0, b0h, b0l);
+        HOS_MMA(a0h, a0l, b1h, b1l, 1);
+        read_b(base, 1, 1, b1h, b1l);
+        HOS_MMA(a1h, a1l, b0h, b0l, 0);
+        // this wave's share of tile kt+1 has landed and its reads of `stage` are complete; after the barrier that
+        // holds for every wave, so `stage` may be refilled and stage^1 read
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + 2 < kt_end) issue_tile(kt + 2, stage);
+        if (kt + 1 < kt_end) {
+            read_a(smemp + (stage ^ 1) * STAGE, 0, a0h, a0l);
+            read_b(smemp + (stage ^ 1) * STAGE, 0, 0, b0h, b0l);
+        }
+        HOS_MMA(a1h, a1l, b1h, b1l, 1);
         stage ^= 1;
     }
+#undef HOS_MMA
 
     // ---------------------------------------------------------------------------------------- epilogues
     if constexpr (EPI == PEPI_F32 || EPI == PEPI_WGRAD) {

@@ -435,3 +435,37 @@ def test_no_cpu_fallback(dev):
     from hosnerf_amd import _lib, ops
     with pytest.raises(_lib.HosLibraryError):
         ops.alpha_weights(torch.ones(2, 4), torch.ones(2, 5), torch.ones(2, 3), True)
+
+
+@pytest.mark.gpu
+def test_planes_gemm_matches_fp64():
+    """hos_split_planes + hos_linearp_{fwd,dgrad,wgrad}: the pre-split (hi/lo 16-bit planes, LDS-DMA staged) GEMM
+    family kept as a measured alternative to the on-the-fly split kernels.  fp32-grade accuracy."""
+    from hosnerf_amd import ops
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 1024, 512, 256
+    X = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+    dY = torch.randn(M, N, device=dev, generator=g)
+    Xp, _ = ops.split_planes(X, dtype=torch.float16)
+    _, XTb = ops.split_planes(X, dtype=torch.bfloat16, transposed=True, row_major=False)
+    Wp, _ = ops.split_planes(W, dtype=torch.float16)
+    _, WTb = ops.split_planes(W, dtype=torch.bfloat16, transposed=True, row_major=False)
+    dZ, dZT = ops.split_planes(dY, dtype=torch.bfloat16, transposed=True)
+    Y = ops.Planes.empty(M, N, torch.float16, dev)
+    YT = ops.Planes.empty(N, M, torch.bfloat16, dev)
+    ops.linearp_fwd(Xp, K, Wp, b, M, N, True, Y, YT)
+    ref = torch.relu(X.double() @ W.double().T + b.double())
+    assert (Y.float().double() - ref).abs().max().item() < 2e-5
+    assert (YT.float().double().T - ref).abs().max().item() < 2e-4           # bf16 hi/lo planes: 2^-17 relative
+    dX = ops.Planes.empty(M, K, torch.bfloat16, dev)
+    ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xp, dX=dX, dXT=None)
+    refd = (dY.double() @ W.double()) * (X > 0)
+    assert (dX.float().double() - refd).abs().max().item() < 2e-4 * refd.abs().max().item() + 1e-5
+    dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    ops.linearp_wgrad(dZT, XTb, dW, db, M, N, K)
+    refw = dY.double().T @ X.double()
+    assert (dW.double() - refw).abs().max().item() < 2e-4 * refw.abs().max().item()
+    assert (db.double() - dY.double().sum(0)).abs().max().item() < 1e-3
