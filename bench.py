@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--gemm", choices=["split", "fp32"], default="split",
+    ap.add_argument("--gemm", choices=["planes", "split", "fp32"], default="planes",
                     help="split = fp16/bf16 hi-lo split MFMA (3 products, fp32 accumulate); fp32 = exact fp32 MFMA")
     return ap.parse_args()
 
@@ -111,7 +111,7 @@ def main():
     from hosnerf_amd.mipnerf360 import MipNeRF360
     from hosnerf_amd.train import FusedAdam, stage1_loss, stage1_lr
 
-    ops.set_gemm_mode(ops.GEMM_BF16X3 if args.gemm == "split" else ops.GEMM_FP32)
+    ops.set_gemm_mode({"planes": ops.GEMM_PLANES, "split": ops.GEMM_BF16X3, "fp32": ops.GEMM_FP32}[args.gemm])
     model = MipNeRF360(basedir(), opaque_background=True)
     model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
     model = model.to(dev)
@@ -202,7 +202,8 @@ def main():
             "metric": "train rays/sec (stage-1 state-conditional mip-NeRF-360, fwd+loss+bwd+clip+Adam)",
             "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)" if args.gemm == "split" else "f32",
+            "dtype": "f32" if args.gemm == "fp32" else "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)",
+            "gemm": args.gemm,
             "launch": "hipGraph replay" if graph is not None else "eager", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
             "config": {"workload": "BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, "
                                    "64/64/32 samples, PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states",
@@ -214,7 +215,7 @@ def main():
             table = prof.summary()
             dom = max(table, key=lambda r: r["total_ms"]) if table else None
             if dom is not None:
-                peak = SPLIT_MFMA_PEAK_TFLOPS if args.gemm == "split" else FP32_MFMA_PEAK_TFLOPS
+                peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "fp32" else SPLIT_MFMA_PEAK_TFLOPS
                 out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
                                    "frac": dom["tflops"] / peak, "traffic": None,
                                    "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],

@@ -13,7 +13,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhosrender.so")
+LIB_PATH = os.environ.get("HOS_LIB_PATH", os.path.join(_HERE, "lib", "libhosrender.so"))   # override: timing experiments only
 
 
 class HosLibraryError(RuntimeError):
@@ -34,7 +34,8 @@ PROTOTYPES = {
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_split_planes": [_P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P],
     "hos_linearp_fwd": [_P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _I, _F, _P],
-    "hos_linearp_dgrad": [_P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P],
+    "hos_split_planes2": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P],
+    "hos_linearp_dgrad": [_P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _P, _P, _I, _P],
     "hos_linearp_wgrad": [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],
     "hos_encode_ipe": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],

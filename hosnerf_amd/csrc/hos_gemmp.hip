@@ -1,25 +1,41 @@
 // "Planes" GEMM: operands pre-split into 16-bit hi/lo planes in HBM, staged by LDS-DMA, 3 MFMAs per product.
 //
-// Why: the phase timeline of the on-the-fly split kernel (hos_gemm3.hip, scripts/trace_gemm.py) showed that per
-// K tile the eight global-load instructions take ~1000 cycles to get through the CU's 64 B/clk vector-memory path
-// and the fp32 -> (hi,lo) conversion + LDS store 1300 (alone) .. 2900 (next to a partner wave's MFMAs) cycles,
-// against 1536 cycles of MFMA work -- the matrix pipe sat at 28-44 %.  Here the split is done ONCE per element by
-// the producer (GEMM epilogues, hos_split_planes for weights / boundary tensors), so a K tile is
-//     8 x global_load_lds_dwordx4 per wave (no VGPRs, no VALU)  +  24 x ds_read_b128  +  48 x MFMA.
+// Why: in the on-the-fly split kernel (hos_gemm3.hip) every K tile costs, per CU, 64 KB through registers, ~160
+// VALU conversions and 16 LDS stores per thread next to 1536 cycles of MFMA work per wave -- the matrix pipe sat
+// at 28-44 %.  Here the split is done ONCE per element by the producer (GEMM epilogues, hos_split_planes for
+// weights and boundary tensors), so a K tile is
+//     8 x global_load_lds_dwordx4 per wave (no VGPRs, no VALU)  +  24 fragment reads  +  48 x MFMA.
+// scripts/probe/dma_probe.hip: this DMA pattern alone streams the whole operand set of a [32768,1024,1024] GEMM in
+// 66-87 us at one workgroup per CU (20-26 B/clk/CU), i.e. under the 82 us the MFMAs need.
 //
-// One kernel, NT form for all three passes (both operands have the reduction index contiguous):
-//   FWD    C[m][n]  = sum_k  X[m][k]    W[n][k]      X, W   : fp16 planes (22 mantissa bits -> fp32-grade)
-//   DGRAD  dX[m][k] = sum_n  dZ[m][n]   Wt[k][n]     dZ, Wt : bf16 planes (8-bit exponent: gradients of any size)
-//   WGRAD  dW[n][k] = sum_m  dZt[n][m]  Xt[k][m]     dZt,Xt : bf16 planes, transposed copies written by producers
-// Element (r,c) of a split matrix is hi[r*ld+c] + lo[r*ld+c]; every reduction extent is a multiple of 32.
+// One kernel for the three passes; element (r,c) of a split matrix is hi[r*ld+c] + lo[r*ld+c]:
+//   FWD    Y[m][n]  = sum_k X[m][k]  W[n][k]     X, W   fp16 planes (22 mantissa bits: fp32-grade), k contiguous
+//   DGRAD  dX[m][k] = sum_n dZ[m][n] Wt[k][n]    dZ, Wt bf16 planes (8-bit exponent: gradients of any size)
+//   WGRAD  dW[n][k] = sum_m dZ[m][n] X[m][k]     dZ, X  bf16 planes, ROW-MAJOR (reduction index = row): the MFMA
+//          fragments (8 consecutive reduction values per lane) are gathered with ds_read_b64_tr_b16, the gfx950
+//          LDS transpose read, so no transposed copy of any activation is ever written to HBM.
 //
-// Tile 256 x BN x 32, 512 threads (8 wave64 as 4x2), LDS = 2 stages x {A hi, A lo, B hi, B lo} x (rows x 64 B)
-// = 128 KB at BN=256; 16-byte chunks XOR-swizzled by (row>>2)&3 exactly like hos_gemm3.hip.  Because
-// global_load_lds writes LDS linearly (wave base + lane*16), the swizzle is applied on the per-lane SOURCE address.
-// Wave pair p (waves 2p, 2p+1) owns plane p of the stage; each wave issues rows/32 DMA instructions per K tile,
-// interleaved between the MFMAs of the current tile.  One barrier per K tile.
+// Tile 256 x BN x 32, 512 threads (8 wave64 as 4(M) x 2(N)), LDS = 2 stages x {A hi, A lo, B hi, B lo}:
+//   * k-contiguous operands: plane tile [rows][32 k] = 64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3 so
+//     the ds_read_b128 fragment reads are conflict free;
+//   * reduction-row operands (WGRAD): plane tile [32 m][R cols], byte column XOR-swizzled by (m&3)<<6 so the four
+//     rows a transpose read touches sit in four different 64-byte bank groups.
+//   global_load_lds writes LDS linearly (wave base + lane*16), so both swizzles are applied on the per-lane SOURCE
+//   address.  Wave pair p (waves 2p, 2p+1) owns plane p of a stage.
+// Main loop: software-pipelined over quarter tiles with explicit counted waits and raw s_barrier (see below).
+// Epilogue: plane outputs go through a wave-private LDS staging buffer so that every global store instruction
+// writes whole 128-byte lines (the MFMA C layout gives a lane one column of 16 rows).
 #include "hos_gemm_common.h"
 #include <cstdlib>
+
+// compile-time ablation switches for timing experiments (a run-time test inside the K loop splits the basic block and
+// makes hipcc fall back to lgkmcnt(0) before every MFMA group, which serialises LDS reads and MFMAs)
+#ifndef HOS_ABLATE_MFMA
+#define HOS_ABLATE_MFMA 0
+#endif
+#ifndef HOS_ABLATE_DMA
+#define HOS_ABLATE_DMA 0
+#endif
 
 namespace {
 
@@ -29,6 +45,9 @@ constexpr int PNT = 512;
 constexpr int PROWB = 64;
 
 template <typename E> struct PVec { typedef E x8 __attribute__((ext_vector_type(8))); typedef E x4 __attribute__((ext_vector_type(4))); };
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
 __device__ __forceinline__ f32x16 pmfma(const PVec<__bf16>::x8& a, const PVec<__bf16>::x8& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -39,50 +58,58 @@ __device__ __forceinline__ f32x16 pmfma(const PVec<_Float16>::x8& a, const PVec<
 enum PEpi { PEPI_F32 = 0, PEPI_PLANES_FWD = 1, PEPI_PLANES_DGRAD = 2, PEPI_WGRAD = 3 };
 
 struct PArgs {
-    // operands (16-bit planes); A may have a second K segment (skip concat)
+    // operands (16-bit planes); A may have a second K segment (skip concat, k-contiguous form only)
     const uint16_t* Ahi; const uint16_t* Alo; int lda; int kt0;
     const uint16_t* A1hi; const uint16_t* A1lo; int lda1;
     const uint16_t* Bhi; const uint16_t* Blo; int ldb;
-    int M, N;            // output extents (rows i of A, rows j of B)
+    int M, N;            // output extents (rows i of the A side, rows j of the B side)
     int nk, kt_per_split, tiles_m, tiles_n;
-    // fp32 output path (reuses the fused epilogues of hos_gemm_common.h)
-    GemmArgs f32;
-    // plane outputs
+    GemmArgs f32;        // fp32 output path (fused epilogues of hos_gemm_common.h) and WGRAD accumulation
     const float* bias;   // FWD
     int relu;            // FWD: apply ReLU
-    const uint16_t* mask_hi; int ldmask;    // DGRAD: fp16 hi plane of the layer input; gradient passes where > 0
-    uint16_t* Yhi; uint16_t* Ylo; int ldy;        // row-major planes [M][ldy]   (fp16 for FWD, bf16 for DGRAD)
-    uint16_t* YThi; uint16_t* YTlo; int ldyt;     // transposed bf16 planes [N][ldyt] (optional)
-    float out_scale;
-    int ablate;          // debug (HOS_GEMM_ABLATE): 1 skip DMA, 4 skip MFMA, 32 skip LDS fragment reads
+    const uint16_t* mask_hi; int ldmask;          // DGRAD: fp16 hi plane of the layer input; gradient passes where > 0
+    uint16_t* Yhi; uint16_t* Ylo; int ldy;        // row-major planes [M][ldy]: fp16 for FWD, bf16 for DGRAD
+    uint16_t* Ybhi; uint16_t* Yblo; int ldyb;     // FWD only: the same values as bf16 planes (WGRAD operand)
 };
 
 template <typename E> __device__ __forceinline__ uint16_t to_bits(E v) { return __builtin_bit_cast(uint16_t, v); }
 template <typename E> __device__ __forceinline__ float clampE(float x) { return x; }
 template <> __device__ __forceinline__ float clampE<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
 
+// (hi, lo) of x packed as lo16 = hi bits, hi16 = lo bits
+template <typename E>
+__device__ __forceinline__ uint32_t split_pack(float x) {
+    const E h = (E)clampE<E>(x);
+    const E l = (E)(x - (float)h);
+    return (uint32_t)to_bits<E>(h) | ((uint32_t)to_bits<E>(l) << 16);
+}
 template <typename E>
 __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
-    const E h = (E)clampE<E>(x);
-    hi = to_bits<E>(h);
-    lo = to_bits<E>((E)(x - (float)h));
+    const uint32_t p = split_pack<E>(x);
+    hi = (uint16_t)(p & 0xffffu); lo = (uint16_t)(p >> 16);
 }
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* ldst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
+__device__ __forceinline__ s16x4 lds_tr(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
 
-template <int BN, int EPI, typename EIN>
+// TR = false: both operands k-contiguous (FWD, DGRAD).  TR = true: both operands reduction-row-major (WGRAD).
+template <int BN, int EPI, typename EIN, bool TR>
 __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     typedef typename PVec<EIN>::x8 ex8;
     constexpr int WN = 2;
     constexpr int TM = PBM / (4 * 32);       // 2
     constexpr int TN = BN / (WN * 32);       // 4 or 2
-    constexpr int A_PLANE = PBM * PROWB, B_PLANE = BN * PROWB;
+    constexpr int TH = TN / 2;
+    constexpr int A_PLANE = PBM * PROWB, B_PLANE = BN * PROWB;      // 32 x rows x 2 bytes in either form
     constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
     constexpr int QA = PBM / 32, QB = BN / 32;      // DMA instructions per wave per K tile for an A / B plane
     constexpr int QMAX = QA > QB ? QA : QB;
+    constexpr int A_PITCH = PBM * 2, B_PITCH = BN * 2;              // TR form: bytes per reduction row
 
     extern __shared__ __attribute__((aligned(16))) char smemp[];
 
@@ -105,39 +132,56 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;
 
-    // ---- DMA plan of this wave: plane (wave>>1), half (wave&1) of its rows --------------------------------
+    // ---- DMA plan of this wave: plane (wave>>1), half (wave&1) of its tile ------------------------------------
     const int plane = wave >> 1;                 // 0: A hi, 1: A lo, 2: B hi, 3: B lo
     const bool isB = plane >= 2;
     const int nq = isB ? QB : QA;                // instructions per K tile
-    const int rows_half = (isB ? BN : PBM) / 2;
-    const int row_l = (wave & 1) * rows_half + (lane >> 2);           // + 16*q
-    const int cphys = lane & 3;
-    const int clog = cphys ^ ((lane >> 4) & 3);                         // logical 16-byte k chunk this lane fetches
     const int lds_plane_off = isB ? (2 * A_PLANE + (plane - 2) * B_PLANE) : plane * A_PLANE;
-    const int lds_row0 = (wave & 1) * rows_half;
-    const int g_row0 = isB ? j0 : i0;
+#ifdef HOS_EXP_SAME_A      // timing experiment: every workgroup streams the SAME A panel (all L2 hits)
+    const int g_row0 = isB ? j0 : 0;
+#else
+    const int g_row0 = isB ? j0 : i0;            // first output row (k-contiguous) / first column (TR) of this side
+#endif
     const int g_limit = isB ? a.N : a.M;
-
-    // Source planes of this wave, selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc
-    // build a pointer table in scratch; every scratch_load result was then waited for with vmcnt(0), which drained
-    // the LDS-DMA queue before EACH global_load_lds and serialised the eight requests of a tile.)
+    // Source planes selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc build a pointer
+    // table in scratch; every scratch_load result was then waited for with vmcnt(0), which drained the LDS-DMA
+    // queue before EACH global_load_lds and serialised the eight requests of a tile.)
     const uint16_t* P0; const uint16_t* P1; int ld0, ld1;
     if (plane == 0)      { P0 = a.Ahi; P1 = a.A1hi; ld0 = a.lda; ld1 = a.lda1; }
     else if (plane == 1) { P0 = a.Alo; P1 = a.A1lo; ld0 = a.lda; ld1 = a.lda1; }
     else if (plane == 2) { P0 = a.Bhi; P1 = a.Bhi;  ld0 = a.ldb; ld1 = a.ldb; }
     else                 { P0 = a.Blo; P1 = a.Blo;  ld0 = a.ldb; ld1 = a.ldb; }
-    const int kt0 = isB ? 0x7fffffff : a.kt0;
-    char* const lds_wave = smemp + lds_plane_off + lds_row0 * PROWB;
+    const int kt0 = (isB || TR) ? 0x7fffffff : a.kt0;
+    const int plane_bytes = isB ? B_PLANE : A_PLANE;
+    char* const lds_wave = smemp + lds_plane_off + (wave & 1) * (plane_bytes / 2);
+
+    // k-contiguous form: instruction q covers rows 16q..16q+15 of this wave's half, lane -> (row, swizzled chunk)
+    const int kc_row = (wave & 1) * ((isB ? BN : PBM) / 2) + (lane >> 2);
+    const int kc_chunk = (lane & 3) ^ ((lane >> 4) & 3);
+    // TR form: instruction q covers 1 KB of this wave's 16 reduction rows; pitch = 2 * (columns of the tile)
+    const int tr_pitch = isB ? B_PITCH : A_PITCH;
 
     auto issue_dma = [&](int q, int kt, int stage) {
-        const bool seg1 = kt >= kt0;                                     // A may switch to its second K segment
-        const uint16_t* P = seg1 ? P1 : P0;
-        const int ld = seg1 ? ld1 : ld0;
-        const int k0 = (seg1 ? kt - kt0 : kt) * PBK;
-        int gr = g_row0 + row_l + 16 * q;
-        gr = gr < g_limit ? gr : g_limit - 1;                          // clamp: out-of-range rows are never stored
-        const unsigned off = (unsigned)gr * (unsigned)ld + (unsigned)(k0 + clog * 8);      // planes are < 2^32 elements
-        dma16(P + off, lds_wave + stage * STAGE + q * 16 * PROWB);      // LDS address is wave-uniform
+        unsigned off;
+        const uint16_t* P;
+        if constexpr (!TR) {
+            const bool seg1 = kt >= kt0;                                 // A may switch to its second K segment
+            P = seg1 ? P1 : P0;
+            const int ld = seg1 ? ld1 : ld0;
+            const int k0 = (seg1 ? kt - kt0 : kt) * PBK;
+            int gr = g_row0 + kc_row + 16 * q;
+            gr = gr < g_limit ? gr : g_limit - 1;                       // clamp: out-of-range rows are never stored
+            off = (unsigned)gr * (unsigned)ld + (unsigned)(k0 + kc_chunk * 8);
+        } else {
+            P = P0;
+            const int pos = q * 1024 + lane * 16;                       // byte position inside this wave's half plane
+            const int m = (wave & 1) * 16 + pos / tr_pitch;             // reduction row inside the K tile
+            const int bcol = (pos % tr_pitch) ^ ((m & 3) << 6);         // source byte column (swizzle on the source)
+            int gc = g_row0 + (bcol >> 1);
+            gc = gc < ((g_limit + 7) & ~7) ? gc : 0;                    // clamp: columns past the operand are never stored
+            off = (unsigned)(kt * PBK + m) * (unsigned)ld0 + (unsigned)gc;
+        }
+        dma16(P + off, lds_wave + stage * STAGE + q * 1024);             // LDS address is wave-uniform
     };
 
     f32x16 acc[TM][TN];
@@ -149,58 +193,137 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
     const int l31 = lane & 31, lhi = lane >> 5;
-    float dbsum = 0.f;
-    const bool do_db = (EPI == PEPI_WGRAD) && a.f32.db != nullptr && tn_i == 0;
+    float dbsum[TM];
+#pragma unroll
+    for (int x = 0; x < TM; ++x) dbsum[x] = 0.f;
+    const bool do_db = (EPI == PEPI_WGRAD) && a.f32.db != nullptr && tn_i == 0 && wn == 0;
+
+    // ---- fragment reads: opaque asm loads + explicit counted waits ---------------------------------------------
+    // hipcc's own waitcnt insertion puts lgkmcnt(0) in front of every MFMA group of this loop (it stops counting
+    // once an LDS-DMA is in flight), i.e. it would also wait for the reads just issued for the NEXT quarter.  The
+    // reads are therefore asm statements the compiler does not count, every MFMA group is preceded by an asm
+    // s_waitcnt lgkmcnt(N), N = LDS reads issued after the ones the group needs (LDS returns in order), and the
+    // fragments pass through that statement as "+v" operands so no MFMA can be scheduled above its wait
+    // (cdna_hip_programming.md 5.7, form (ii)).
+    //   k-contiguous: lane (row = l31, k half = lhi) reads the 16-byte chunk (2s + lhi) ^ ((l31>>2)&3) of its row.
+    //   TR: 16-lane group g = lane>>4 reads the [4 m][16 col] block (m0 = 16 s + 8 (g>>1) (+4), col0 = 16 (g&1));
+    //       lane p of the group supplies the address of row m0 + (p>>2), columns col0 + 4 (p&3) .. +3 and receives
+    //       column col0 + p of the four rows: two reads give the 8 consecutive reduction values of its MFMA row.
+    // Per-lane byte offsets inside stage 0; everything else of an address is an immediate or the stage offset.
+    constexpr int NOA = 2, NOB = TR ? TN : 2;
+    unsigned offA[NOA], offB[NOB];
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smemp;
+    if constexpr (!TR) {
+        const int swz = (l31 >> 2) & 3;
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int ch = (2 * sx + lhi) ^ swz;
+            offA[sx] = lds_base + (wm * (TM * 32) + l31) * PROWB + ch * 16;
+            offB[sx] = lds_base + 2 * A_PLANE + (wn * (TN * 32) + l31) * PROWB + ch * 16;
+        }
+    } else {
+        const int tr_p = lane & 15, tr_g = lane >> 4;
+        const int m_lane = 8 * (tr_g >> 1) + (tr_p >> 2), sw = tr_p >> 2;
+        const int lcol = (16 * (tr_g & 1) + 4 * (tr_p & 3)) * 2;
+#pragma unroll
+        for (int x = 0; x < TM; ++x) offA[x] = lds_base + m_lane * A_PITCH + (((wm * TM + x) ^ sw) << 6) + lcol;
+#pragma unroll
+        for (int y = 0; y < TN; ++y) offB[y] = lds_base + 2 * A_PLANE + m_lane * B_PITCH + (((wn * TN + y) ^ sw) << 6) + lcol;
+    }
+#define HOS_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define HOS_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+    // fragment storage: k-contiguous form uses .v directly; TR form loads two 64-bit halves and joins them after the wait
+    struct Frag { ex8 v; s16x4 h0, h1; };
+    Frag a0h[TM], a0l[TM], a1h[TM], a1l[TM], b0h[TH], b0l[TH], b1h[TH], b1l[TH];
+
+    // S = k half, X / Y = tile index inside the wave tile: all compile-time so the LDS offsets are immediates
+#define HOS_READ_A1(SET_H, SET_L, STG, S, X)                                                                   \
+    do {                                                                                                       \
+        if constexpr (!TR) {                                                                                   \
+            HOS_RD128(SET_H[X].v, offA[S] + (STG), (X) * 32 * PROWB);                                          \
+            HOS_RD128(SET_L[X].v, offA[S] + (STG), A_PLANE + (X) * 32 * PROWB);                                \
+        } else {                                                                                               \
+            HOS_RDTR(SET_H[X].h0, offA[X] + (STG), (S) * 16 * A_PITCH);                                        \
+            HOS_RDTR(SET_H[X].h1, offA[X] + (STG), (S) * 16 * A_PITCH + 4 * A_PITCH);                          \
+            HOS_RDTR(SET_L[X].h0, offA[X] + (STG), A_PLANE + (S) * 16 * A_PITCH);                              \
+            HOS_RDTR(SET_L[X].h1, offA[X] + (STG), A_PLANE + (S) * 16 * A_PITCH + 4 * A_PITCH);                \
+        }                                                                                                      \
+    } while (0)
+#define HOS_READ_A(SET_H, SET_L, STG, S) do { HOS_READ_A1(SET_H, SET_L, STG, S, 0); HOS_READ_A1(SET_H, SET_L, STG, S, 1); } while (0)
+#define HOS_READ_B1(SET_H, SET_L, STG, S, YH, Y)                                                               \
+    do {                                                                                                       \
+        if constexpr ((Y) < TH) {                                                                              \
+            if constexpr (!TR) {                                                                               \
+                HOS_RD128(SET_H[Y].v, offB[S] + (STG), ((YH) * TH + (Y)) * 32 * PROWB);                        \
+                HOS_RD128(SET_L[Y].v, offB[S] + (STG), B_PLANE + ((YH) * TH + (Y)) * 32 * PROWB);              \
+            } else {                                                                                           \
+                HOS_RDTR(SET_H[Y].h0, offB[((YH) * TH + (Y)) % NOB] + (STG), (S) * 16 * B_PITCH);              \
+                HOS_RDTR(SET_H[Y].h1, offB[((YH) * TH + (Y)) % NOB] + (STG), (S) * 16 * B_PITCH + 4 * B_PITCH); \
+                HOS_RDTR(SET_L[Y].h0, offB[((YH) * TH + (Y)) % NOB] + (STG), B_PLANE + (S) * 16 * B_PITCH);    \
+                HOS_RDTR(SET_L[Y].h1, offB[((YH) * TH + (Y)) % NOB] + (STG), B_PLANE + (S) * 16 * B_PITCH + 4 * B_PITCH); \
+            }                                                                                                  \
+        }                                                                                                      \
+    } while (0)
+#define HOS_READ_B(SET_H, SET_L, STG, S, YH) do { HOS_READ_B1(SET_H, SET_L, STG, S, YH, 0); HOS_READ_B1(SET_H, SET_L, STG, S, YH, 1); } while (0)
+    constexpr int RPF = TR ? 2 : 1;                  // LDS read instructions per fragment
+    constexpr int NRA = 2 * TM * RPF;                // ... per A fragment set
+    constexpr int NRB = 2 * TH * RPF;                // ... per B fragment set
+    // wait until at most N LDS reads are outstanding, then make the fragments of one A and one B set visible
+    auto tie = [&](Frag& f) {
+        if constexpr (!TR) { asm volatile("" : "+v"(f.v)); }
+        else {
+            asm volatile("" : "+v"(f.h0), "+v"(f.h1));
+            const s16x8 j = __builtin_shufflevector(f.h0, f.h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            f.v = __builtin_bit_cast(ex8, j);
+        }
+    };
+#define HOS_WAIT(N, AH, AL, BH, BL)                                                      \
+    do {                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((N) > 15 ? 15 : (N)) : "memory");    \
+        _Pragma("unroll") for (int x = 0; x < TM; ++x) { tie(AH[x]); tie(AL[x]); }       \
+        _Pragma("unroll") for (int y = 0; y < TH; ++y) { tie(BH[y]); tie(BL[y]); }       \
+    } while (0)
+    // bias gradient (WGRAD): the A fragments of the wn == 0 waves hold dZ[m][n] for 8 m per lane
+    auto db_acc = [&](const Frag (&ah)[TM], const Frag (&al)[TM]) {
+        if constexpr (EPI == PEPI_WGRAD) {
+            if (do_db) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dbsum[x] += (float)ah[x].v[e] + (float)al[x].v[e];
+            }
+        }
+    };
 
     // ---- main loop: software-pipelined over QUARTER tiles (k half s = 0/1  x  column half yh = 0/1) -----------
     // Two A fragment sets (one per k half) and two B fragment sets (one per quarter) rotate so that every
-    // quarter's ds_reads fly under the previous quarter's MFMAs; two LDS stages; the DMA runs one tile ahead:
+    // quarter's LDS reads fly under the previous quarter's MFMAs; two LDS stages; the DMA runs one tile ahead:
     //     read B1=(s0,yh1)              | MFMA (A0,B0)
     //     read A1=(s1), B0=(s1,yh0)     | MFMA (A0,B1)
     //     read B1=(s1,yh1)              | MFMA (A1,B0)
     //     wait DMA(kt+1) + own reads, barrier        <- one barrier per K tile
     //     DMA(kt+2) -> stage(kt) | read A0,B0 of kt+1 | MFMA (A1,B1)
-    // All waits are explicit (counted asm s_waitcnt + raw s_barrier): __syncthreads() would drain the LDS-DMA
-    // queue (vmcnt(0)) at every barrier, which serialises DMA and MFMA at one workgroup per CU.
-    constexpr int TH = TN / 2;
-    ex8 a0h[TM], a0l[TM], a1h[TM], a1l[TM], b0h[TH], b0l[TH], b1h[TH], b1l[TH];
-    auto read_a = [&](const char* base, int s, ex8 (&ah)[TM], ex8 (&al)[TM]) {
-        const int c = 2 * s + lhi;
-#pragma unroll
-        for (int x = 0; x < TM; ++x) {
-            const int row = wm * (TM * 32) + x * 32 + l31;
-            const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
-            ah[x] = *reinterpret_cast<const ex8*>(base + off);
-            al[x] = *reinterpret_cast<const ex8*>(base + A_PLANE + off);
-        }
-    };
-    auto read_b = [&](const char* base, int s, int yh, ex8 (&bh)[TH], ex8 (&bl)[TH]) {
-        const int c = 2 * s + lhi;
-#pragma unroll
-        for (int y = 0; y < TH; ++y) {
-            const int row = wn * (TN * 32) + (yh * TH + y) * 32 + l31;
-            const int off = row * PROWB + ((c ^ ((row >> 2) & 3)) * 16);
-            bh[y] = *reinterpret_cast<const ex8*>(base + 2 * A_PLANE + off);
-            bl[y] = *reinterpret_cast<const ex8*>(base + 2 * A_PLANE + B_PLANE + off);
-        }
-    };
+    // All waits are explicit (asm s_waitcnt + raw s_barrier): __syncthreads() would drain the LDS-DMA queue
+    // (vmcnt(0)) wherever the compiler places it, which serialises DMA and MFMA at one workgroup per CU.
 #define HOS_MMA(AH, AL, BH, BL, YH)                                                      \
     do {                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                               \
         __builtin_amdgcn_s_setprio(1);                                                   \
-        if (!(a.ablate & 4)) {                                                           \
+        if (!HOS_ABLATE_MFMA) {                                                          \
             _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
-            _Pragma("unroll") for (int y = 0; y < TH; ++y) {                             \
-                acc[x][(YH) * TH + y] = pmfma(AL[x], BH[y], acc[x][(YH) * TH + y]);      \
-                acc[x][(YH) * TH + y] = pmfma(AH[x], BL[y], acc[x][(YH) * TH + y]);      \
-                acc[x][(YH) * TH + y] = pmfma(AH[x], BH[y], acc[x][(YH) * TH + y]);      \
-            }                                                                            \
+            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
+                acc[x][(YH) * TH + y] = pmfma(AL[x].v, BH[y].v, acc[x][(YH) * TH + y]);  \
+            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
+            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
+                acc[x][(YH) * TH + y] = pmfma(AH[x].v, BL[y].v, acc[x][(YH) * TH + y]);  \
+            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
+            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
+                acc[x][(YH) * TH + y] = pmfma(AH[x].v, BH[y].v, acc[x][(YH) * TH + y]);  \
         }                                                                                \
         __builtin_amdgcn_s_setprio(0);                                                   \
         __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
     auto issue_tile = [&](int kt, int stage) {
-        if (a.ablate & 1) return;
+        if (HOS_ABLATE_DMA) return;
 #pragma unroll
         for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt, stage);
     };
@@ -209,44 +332,87 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    read_a(smemp, 0, a0h, a0l);
-    read_b(smemp, 0, 0, b0h, b0l);
+    HOS_READ_A(a0h, a0l, 0u, 0);
+    HOS_READ_B(b0h, b0l, 0u, 0, 0);
 
-    int stage = 0;
+#ifdef HOS_TRACE   // timing experiment: lane 0 of every wave of workgroup 0 stamps the phase boundaries of K tiles 8..11
+    long long* const trbuf = reinterpret_cast<long long*>(a.f32.aux);
+#define HOS_STAMP(slot) do { if (bid == 0 && lane == 0 && trbuf && kt >= kt_begin + 8 && kt < kt_begin + 12) trbuf[(wave * 4 + (kt - kt_begin - 8)) * 8 + (slot)] = clock64(); } while (0)
+#else
+#define HOS_STAMP(slot) do {} while (0)
+#endif
+    unsigned so = 0;                     // byte offset of the stage holding tile kt
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const char* base = smemp + stage * STAGE;
-        read_b(base, 0, 1, b1h, b1l);
-        if constexpr (EPI == PEPI_WGRAD) {
-            if (do_db && t < PBM) {      // bias gradient: row sums of the dZt tile (hi + lo planes), 32 m values per K tile
-                const int sw = (t >> 2) & 3;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const ex8 h = *reinterpret_cast<const ex8*>(base + t * PROWB + ((c ^ sw) * 16));
-                    const ex8 l = *reinterpret_cast<const ex8*>(base + A_PLANE + t * PROWB + ((c ^ sw) * 16));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dbsum += (float)h[e] + (float)l[e];
-                }
-            }
-        }
+        const unsigned sn = STAGE - so;
+        HOS_STAMP(0);
+        HOS_READ_B(b1h, b1l, so, 0, 1);
+        HOS_WAIT(NRB, a0h, a0l, b0h, b0l);
+        db_acc(a0h, a0l);
         HOS_MMA(a0h, a0l, b0h, b0l, 0);
-        read_a(base, 1, a1h, a1l);
-        read_b(base, 1, 0, b0h, b0l);
+        HOS_STAMP(1);
+        HOS_READ_A(a1h, a1l, so, 1);
+        HOS_READ_B(b0h, b0l, so, 1, 0);
+        HOS_WAIT(NRA + NRB, a0h, a0l, b1h, b1l);
         HOS_MMA(a0h, a0l, b1h, b1l, 1);
-        read_b(base, 1, 1, b1h, b1l);
+        HOS_STAMP(2);
+        HOS_READ_B(b1h, b1l, so, 1, 1);
+        HOS_WAIT(NRB, a1h, a1l, b0h, b0l);
+        db_acc(a1h, a1l);
         HOS_MMA(a1h, a1l, b0h, b0l, 0);
-        // this wave's share of tile kt+1 has landed and its reads of `stage` are complete; after the barrier that
-        // holds for every wave, so `stage` may be refilled and stage^1 read
+        HOS_STAMP(3);
+        // this wave's share of tile kt+1 has landed and its reads of this stage are complete; after the barrier
+        // that holds for every wave, so the stage may be refilled and the other one read
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HOS_STAMP(4);
         asm volatile("s_barrier" ::: "memory");
-        if (kt + 2 < kt_end) issue_tile(kt + 2, stage);
-        if (kt + 1 < kt_end) {
-            read_a(smemp + (stage ^ 1) * STAGE, 0, a0h, a0l);
-            read_b(smemp + (stage ^ 1) * STAGE, 0, 0, b0h, b0l);
+        HOS_STAMP(5);
+        // Last quarter: its operands are already in registers, so the MFMAs start right behind the barrier and
+        // the DMA requests of tile kt+2 (first two thirds) and the first fragment reads of tile kt+1 (last third)
+        // are issued BETWEEN them.  Eight back-to-back global_load_lds stalled the issuing wave for 600-1900 cycles
+        // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once), and an
+        // in-order wave cannot issue an MFMA while it waits to issue a DMA (timeline: scripts/trace_gemmp.py).
+        {
+            const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
+            const int dstage = so ? 1 : 0;
+            constexpr int NM = 3 * TM * TH, ND = 2 * TM * TH;
+#pragma unroll
+            for (int y = 0; y < TH; ++y) { tie(b1h[y]); tie(b1l[y]); }      // landed before the barrier (lgkmcnt(0) above)
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;
+                if (!HOS_ABLATE_MFMA) {
+                    if (pr == 0)      acc[x][TH + y] = pmfma(a1l[x].v, b1h[y].v, acc[x][TH + y]);
+                    else if (pr == 1) acc[x][TH + y] = pmfma(a1h[x].v, b1l[y].v, acc[x][TH + y]);
+                    else              acc[x][TH + y] = pmfma(a1h[x].v, b1h[y].v, acc[x][TH + y]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!HOS_ABLATE_DMA && more2 && i < ND) {
+#pragma unroll
+                    for (int q = i * QMAX / ND; q < (i + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 2, dstage);
+                }
+                if (more1) {
+                    if (i == NM - 4) HOS_READ_A1(a0h, a0l, sn, 0, 0);
+                    if (i == NM - 3) HOS_READ_A1(a0h, a0l, sn, 0, 1);
+                    if (i == NM - 2) HOS_READ_B1(b0h, b0l, sn, 0, 0, 0);
+                    if (i == NM - 1) HOS_READ_B1(b0h, b0l, sn, 0, 0, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
         }
-        HOS_MMA(a1h, a1l, b1h, b1l, 1);
-        stage ^= 1;
+        HOS_STAMP(7);
+        so = sn;
     }
+#undef HOS_STAMP
 #undef HOS_MMA
+#undef HOS_WAIT
+#undef HOS_READ_A
+#undef HOS_READ_A1
+#undef HOS_READ_B
+#undef HOS_READ_B1
+#undef HOS_RD128
+#undef HOS_RDTR
 
     // ---------------------------------------------------------------------------------------- epilogues
     if constexpr (EPI == PEPI_F32 || EPI == PEPI_WGRAD) {
@@ -262,95 +428,96 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 }
             }
         if constexpr (EPI == PEPI_WGRAD) {
-            if (do_db && t < PBM && i0 + t < a.M)
-                __hip_atomic_fetch_add(a.f32.db + i0 + t, dbsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (do_db) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x) {
+                    const float sum = dbsum[x] + __shfl_xor(dbsum[x], 32, 64);
+                    const int n = i0 + wm * (TM * 32) + x * 32 + l31;
+                    if (lhi == 0 && n < a.M) __hip_atomic_fetch_add(a.f32.db + n, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     } else {
-        // plane outputs: EOUT = fp16 for FWD (next layer's input), bf16 for DGRAD (next dgrad/wgrad operand)
+        // Plane outputs.  Every wave owns 8 KB of the (now idle) stage memory.  Per (x, pair of y) = 32 rows x 64
+        // columns: each lane packs (hi, lo) of its values into one dword and writes it at [row][col] (ds_write_b32,
+        // 32 consecutive dwords per half wave: conflict free); after the wave's own writes have landed every lane
+        // reads 16 bytes = four consecutive columns of one row and stores 8 bytes to the hi plane and 8 to the lo
+        // plane -- 16 lanes per row, so each store instruction writes four whole 128-byte lines per plane.
+        asm volatile("s_barrier" ::: "memory");                   // all waves are done with the stage memory
+        char* const stg = smemp + wave * 8192;
+        const bool dual = (EPI == PEPI_PLANES_FWD) && a.Ybhi != nullptr;
+        const bool first = a.Yhi != nullptr;
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
-            for (int y = 0; y < TN; ++y) {
-                const int row0 = i0 + wm * (TM * 32) + x * 32, col0 = j0 + wn * (TN * 32) + y * 32;
-                const int colL = col0 + l31;                    // this lane's column in the MFMA layout
-                float bcol = 0.f;
-                if (EPI == PEPI_PLANES_FWD && a.bias != nullptr && colL < a.N) bcol = a.bias[colL];
-                const int q = l31 & 3;
-                const int colb = col0 + (l31 & ~3);
+            for (int yp = 0; yp < TN / 2; ++yp) {
+                const int row0 = i0 + wm * (TM * 32) + x * 32;
+                const int col0 = j0 + wn * (TN * 32) + yp * 64;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
+                for (int fmt = 0; fmt < 2; ++fmt) {
+                    if (fmt == 0 && !first) continue;
+                    if (fmt == 1 && !dual) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[x][y][4 * g + j] + bcol;
-                        if (EPI == PEPI_PLANES_FWD && a.relu) v[j] = fmaxf(v[j], 0.f);
+                    for (int yy = 0; yy < 2; ++yy) {
+                        const int col = col0 + yy * 32 + l31;
+                        float bcol = 0.f;
+                        if (EPI == PEPI_PLANES_FWD && a.bias != nullptr && col < a.N) bcol = a.bias[col];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[x][2 * yp + yy][r] + bcol;
+                            if (EPI == PEPI_PLANES_FWD && a.relu) v = fmaxf(v, 0.f);
+                            if (col >= a.N) v = 0.f;                                   // zero the padding columns
+                            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                            uint32_t p;
+                            if (EPI == PEPI_PLANES_FWD && fmt == 0) p = split_pack<_Float16>(v);
+                            else p = split_pack<__bf16>(v);
+                            *reinterpret_cast<uint32_t*>(stg + (rl * 64 + yy * 32 + l31) * 4) = p;
+                        }
                     }
-                    const int rbase = row0 + 8 * g + 4 * lhi;          // rows rbase .. rbase+3, column colL
-                    if constexpr (EPI == PEPI_PLANES_DGRAD) {
-                        if (a.mask_hi != nullptr && colL < a.N) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    uint16_t* const Ph = fmt == 0 ? a.Yhi : a.Ybhi;
+                    uint16_t* const Pl = fmt == 0 ? a.Ylo : a.Yblo;
+                    const int ldo = fmt == 0 ? a.ldy : a.ldyb;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (rbase + j < a.M) {
-                                    const uint16_t mh = a.mask_hi[(size_t)(rbase + j) * a.ldmask + colL];
-                                    if ((mh & 0x8000u) || (mh & 0x7fffu) == 0) v[j] = 0.f;      // fp16 hi plane: x > 0 ?
-                                }
+                    for (int pass = 0; pass < 8; ++pass) {
+                        const int idx = pass * 64 + lane;
+                        const int rl = idx >> 4, cg = (idx & 15) * 4;
+                        uint4 w = *reinterpret_cast<const uint4*>(stg + idx * 16);
+                        const int row = row0 + rl, col = col0 + cg;
+                        if constexpr (EPI == PEPI_PLANES_DGRAD) {
+                            if (a.mask_hi != nullptr && row < a.M && col < a.ldmask) {
+                                const uint2 mk = *reinterpret_cast<const uint2*>(a.mask_hi + (size_t)row * a.ldmask + col);
+                                const uint32_t m4[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+                                uint32_t* wv = reinterpret_cast<uint32_t*>(&w);
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if ((m4[k] & 0x8000u) || (m4[k] & 0x7fffu) == 0) wv[k] = 0u;      // fp16 hi plane: x > 0 ?
                             }
                         }
-                    }
-                    // (a) transposed bf16 planes [n][m]: four consecutive m of one n = 8 bytes per plane
-                    if (a.YThi != nullptr && colL < a.N && rbase < a.M) {
-                        uint16_t h[4], l[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) split1<__bf16>(v[j], h[j], l[j]);
-                        const size_t o = (size_t)colL * a.ldyt + rbase;
-                        if (rbase + 3 < a.M) {
-                            *reinterpret_cast<uint2*>(a.YThi + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                            *reinterpret_cast<uint2*>(a.YTlo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-                        } else {
-                            for (int j = 0; j < 4 && rbase + j < a.M; ++j) { a.YThi[o + j] = h[j]; a.YTlo[o + j] = l[j]; }
+                        if (row < a.M && col < ldo) {
+                            const uint2 hi2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), __builtin_amdgcn_perm(w.w, w.z, 0x05040100u));
+                            const uint2 lo2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), __builtin_amdgcn_perm(w.w, w.z, 0x07060302u));
+                            const size_t o = (size_t)row * ldo + col;
+                            *reinterpret_cast<uint2*>(Ph + o) = hi2;
+                            *reinterpret_cast<uint2*>(Pl + o) = lo2;
                         }
                     }
-                    // (b) row-major planes: quad transpose so a lane owns four consecutive columns of one row
-                    float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-                    {
-                        const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
-                        const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
-                        if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
-                        const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
-                        const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
-                        if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
-                    }
-                    const int row = row0 + q + 8 * g + 4 * lhi;
-                    if (a.Yhi != nullptr && row < a.M && colb < a.ldy) {
-                        const float w[4] = {v0, v1, v2, v3};
-                        uint16_t h[4], l[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float val = (colb + k < a.N) ? w[k] : 0.f;        // zero the padding columns
-                            if (EPI == PEPI_PLANES_FWD) split1<_Float16>(val, h[k], l[k]);
-                            else split1<__bf16>(val, h[k], l[k]);
-                        }
-                        const size_t o = (size_t)row * a.ldy + colb;
-                        *reinterpret_cast<uint2*>(a.Yhi + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                        *reinterpret_cast<uint2*>(a.Ylo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging reads done before it is rewritten
                 }
             }
     }
 }
 
-template <int BN, int EPI, typename EIN>
+template <int BN, int EPI, typename EIN, bool TR>
 int launchp(PArgs& a, int splits, hipStream_t stream) {
     constexpr size_t smem = 2 * (2 * PBM * PROWB + 2 * BN * PROWB);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmp_kernel<BN, EPI, EIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmp_kernel<BN, EPI, EIN, TR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    static const int ablate = getenv("HOS_GEMM_ABLATE") ? atoi(getenv("HOS_GEMM_ABLATE")) : 0;
-    a.ablate = ablate;
     a.tiles_m = hos_cdiv(a.M, PBM);
     a.tiles_n = hos_cdiv(a.N, BN);
     if (EPI == PEPI_WGRAD) {
@@ -358,7 +525,7 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
         if (env_splits > 0) splits = env_splits;
         if (splits <= 0) {
             const int tiles = a.tiles_m * a.tiles_n;
-            splits = hos_cdiv(512, tiles);
+            splits = hos_cdiv(256, tiles);                         // one workgroup per CU
             if (splits > a.nk / 8) splits = a.nk / 8 > 0 ? a.nk / 8 : 1;
         }
         if (splits > a.nk) splits = a.nk;
@@ -368,7 +535,7 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
         splits = 1;
         a.kt_per_split = a.nk;
     }
-    hipLaunchKernelGGL((gemmp_kernel<BN, EPI, EIN>), dim3(a.tiles_m * a.tiles_n * splits), dim3(PNT), smem, stream, a);
+    hipLaunchKernelGGL((gemmp_kernel<BN, EPI, EIN, TR>), dim3(a.tiles_m * a.tiles_n * splits), dim3(PNT), smem, stream, a);
     return hos_launch_status();
 }
 
@@ -406,6 +573,35 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// fp32 [R][ld] -> fp16 planes and bf16 planes in one pass (row-major, 4 elements per thread)
+__global__ __launch_bounds__(256) void split_planes2_kernel(const float* __restrict__ src, int lds, int R, int C,
+                                                            uint16_t* __restrict__ h16, uint16_t* __restrict__ l16, int ld16,
+                                                            uint16_t* __restrict__ hb, uint16_t* __restrict__ lb, int ldb) {
+    const int ldmax = ld16 > ldb ? ld16 : ldb;
+    const int groups = ldmax >> 2;
+    const size_t total = (size_t)R * groups;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / groups), c = (int)(i % groups) * 4;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (c + k < C) ? src[(size_t)r * lds + c + k] : 0.f;
+        if (h16 != nullptr && c < ld16) {
+            uint32_t p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = split_pack<_Float16>(v[k]);
+            *reinterpret_cast<uint2*>(h16 + (size_t)r * ld16 + c) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
+            *reinterpret_cast<uint2*>(l16 + (size_t)r * ld16 + c) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
+        }
+        if (hb != nullptr && c < ldb) {
+            uint32_t p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = split_pack<__bf16>(v[k]);
+            *reinterpret_cast<uint2*>(hb + (size_t)r * ldb + c) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
+            *reinterpret_cast<uint2*>(lb + (size_t)r * ldb + c) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
+        }
+    }
+}
+
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -426,9 +622,22 @@ extern "C" int hos_split_planes(const float* src, int lds, int R, int C, int dty
     return hos_launch_status();
 }
 
+extern "C" int hos_split_planes2(const float* src, int lds, int R, int C, void* h16, void* l16, int ld16,
+                                 void* hb, void* lb, int ldb, hos_stream_t stream) {
+    if (!src || R <= 0 || C <= 0 || (!h16 && !hb)) return HOS_E_ARG;
+    if ((h16 && (!l16 || (ld16 & 3))) || (hb && (!lb || (ldb & 3)))) return HOS_E_ARG;
+    const int ldmax = (h16 ? ld16 : 0) > (hb ? ldb : 0) ? ld16 : ldb;
+    const size_t total = (size_t)R * (ldmax >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_planes2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, R, C,
+                       (uint16_t*)h16, (uint16_t*)l16, h16 ? ld16 : 0, (uint16_t*)hb, (uint16_t*)lb, hb ? ldb : 0);
+    return hos_launch_status();
+}
+
 extern "C" int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0, const void* A1hi, const void* A1lo,
                                int lda1, int K1, const void* Whi, const void* Wlo, int ldw, const float* bias,
-                               int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* YThi, void* YTlo, int ldyt,
+                               int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* Ybhi, void* Yblo, int ldyb,
                                float* C, int ldc, int epilogue, float* aux, int aux_col, float p0,
                                hos_stream_t stream) {
     if (!Ahi || !Alo || !Whi || !Wlo || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
@@ -436,8 +645,8 @@ extern "C" int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0
     if ((K0 % PBK) || (K1 % PBK)) return HOS_E_SHAPE;
     if ((lda & 7) || (ldw & 7) || (K1 > 0 && (lda1 & 7))) return HOS_E_ALIGN;
     if (!al16p(Ahi) || !al16p(Alo) || !al16p(Whi) || !al16p(Wlo)) return HOS_E_ALIGN;
-    const bool planes_out = (Yhi != nullptr) || (YThi != nullptr);
-    if (planes_out && ((Yhi && (!Ylo || (ldy & 3))) || (YThi && (!YTlo || (ldyt & 3))))) return HOS_E_ARG;
+    const bool planes_out = (Yhi != nullptr) || (Ybhi != nullptr);
+    if (planes_out && ((Yhi && (!Ylo || (ldy & 3))) || (Ybhi && (!Yblo || (ldyb & 3))))) return HOS_E_ARG;
     if (!planes_out && !C && epilogue != HOS_EPI_DENSITY) return HOS_E_ARG;
     PArgs a{};
     a.Ahi = (const uint16_t*)Ahi; a.Alo = (const uint16_t*)Alo; a.lda = lda; a.kt0 = K0 / PBK;
@@ -445,45 +654,45 @@ extern "C" int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0
     a.Bhi = (const uint16_t*)Whi; a.Blo = (const uint16_t*)Wlo; a.ldb = ldw;
     a.M = M; a.N = N; a.nk = (K0 + K1) / PBK;
     a.bias = bias; a.relu = relu;
-    a.Yhi = (uint16_t*)Yhi; a.Ylo = (uint16_t*)Ylo; a.ldy = ldy; a.YThi = (uint16_t*)YThi; a.YTlo = (uint16_t*)YTlo; a.ldyt = ldyt;
+    a.Yhi = (uint16_t*)Yhi; a.Ylo = (uint16_t*)Ylo; a.ldy = ldy; a.Ybhi = (uint16_t*)Ybhi; a.Yblo = (uint16_t*)Yblo; a.ldyb = ldyb;
     a.f32.C = C; a.f32.ldc = ldc; a.f32.M = M; a.f32.N = N; a.f32.bias = bias; a.f32.aux = aux; a.f32.aux_col = aux_col;
     a.f32.p0 = p0; a.f32.epi = epilogue;
     if (epilogue == HOS_EPI_RESIDUAL) { a.f32.mask = aux; a.f32.ldmask = aux_col; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = N > 128;
-    if (planes_out) return wide ? launchp<256, PEPI_PLANES_FWD, _Float16>(a, 1, s) : launchp<128, PEPI_PLANES_FWD, _Float16>(a, 1, s);
-    return wide ? launchp<256, PEPI_F32, _Float16>(a, 1, s) : launchp<128, PEPI_F32, _Float16>(a, 1, s);
+    if (planes_out) return wide ? launchp<256, PEPI_PLANES_FWD, _Float16, false>(a, 1, s) : launchp<128, PEPI_PLANES_FWD, _Float16, false>(a, 1, s);
+    return wide ? launchp<256, PEPI_F32, _Float16, false>(a, 1, s) : launchp<128, PEPI_F32, _Float16, false>(a, 1, s);
 }
 
 extern "C" int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, const void* WThi, const void* WTlo,
                                  int ldwt, int Npad, const void* mask_hi, int ldmask, int M, int K,
-                                 void* dXhi, void* dXlo, int lddx, void* dXThi, void* dXTlo, int lddxt,
-                                 hos_stream_t stream) {
-    if (!dZhi || !dZlo || !WThi || !WTlo || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
-    if (!dXhi && !dXThi) return HOS_E_ARG;
+                                 void* dXhi, void* dXlo, int lddx, hos_stream_t stream) {
+    if (!dZhi || !dZlo || !WThi || !WTlo || !dXhi || !dXlo || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
     if (Npad % PBK) return HOS_E_SHAPE;
-    if ((lddz & 7) || (ldwt & 7) || (dXhi && (lddx & 3)) || (dXThi && (lddxt & 3))) return HOS_E_ALIGN;
+    if ((lddz & 7) || (ldwt & 7) || (lddx & 3) || (mask_hi && (ldmask & 3))) return HOS_E_ALIGN;
+    if (!al16p(dZhi) || !al16p(dZlo) || !al16p(WThi) || !al16p(WTlo)) return HOS_E_ALIGN;
     PArgs a{};
     a.Ahi = (const uint16_t*)dZhi; a.Alo = (const uint16_t*)dZlo; a.lda = lddz; a.kt0 = Npad / PBK;
     a.Bhi = (const uint16_t*)WThi; a.Blo = (const uint16_t*)WTlo; a.ldb = ldwt;
     a.M = M; a.N = K; a.nk = Npad / PBK;
     a.mask_hi = (const uint16_t*)mask_hi; a.ldmask = ldmask;
-    a.Yhi = (uint16_t*)dXhi; a.Ylo = (uint16_t*)dXlo; a.ldy = lddx; a.YThi = (uint16_t*)dXThi; a.YTlo = (uint16_t*)dXTlo; a.ldyt = lddxt;
+    a.Yhi = (uint16_t*)dXhi; a.Ylo = (uint16_t*)dXlo; a.ldy = lddx;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return K > 128 ? launchp<256, PEPI_PLANES_DGRAD, __bf16>(a, 1, s) : launchp<128, PEPI_PLANES_DGRAD, __bf16>(a, 1, s);
+    return K > 128 ? launchp<256, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s) : launchp<128, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s);
 }
 
-extern "C" int hos_linearp_wgrad(const void* dZThi, const void* dZTlo, int lddzt, const void* XThi, const void* XTlo,
-                                 int ldxt, float* dW, int ldw, float* db, int M, int N, int K, int splits,
+extern "C" int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
+                                 int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits,
                                  hos_stream_t stream) {
-    if (!dZThi || !dZTlo || !XThi || !XTlo || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+    if (!dZhi || !dZlo || !Xhi || !Xlo || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
     if (M % PBK) return HOS_E_SHAPE;
-    if ((lddzt & 7) || (ldxt & 7)) return HOS_E_ALIGN;
+    if ((lddz & 7) || (ldx & 7)) return HOS_E_ALIGN;
+    if (!al16p(dZhi) || !al16p(dZlo) || !al16p(Xhi) || !al16p(Xlo)) return HOS_E_ALIGN;
     PArgs a{};
-    a.Ahi = (const uint16_t*)dZThi; a.Alo = (const uint16_t*)dZTlo; a.lda = lddzt; a.kt0 = M / PBK;
-    a.Bhi = (const uint16_t*)XThi; a.Blo = (const uint16_t*)XTlo; a.ldb = ldxt;
+    a.Ahi = (const uint16_t*)dZhi; a.Alo = (const uint16_t*)dZlo; a.lda = lddz; a.kt0 = M / PBK;
+    a.Bhi = (const uint16_t*)Xhi; a.Blo = (const uint16_t*)Xlo; a.ldb = ldx;
     a.M = N; a.N = K; a.nk = M / PBK;
     a.f32.C = dW; a.f32.ldc = ldw; a.f32.M = N; a.f32.N = K; a.f32.db = db;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return K > 128 ? launchp<256, PEPI_WGRAD, __bf16>(a, splits, s) : launchp<128, PEPI_WGRAD, __bf16>(a, splits, s);
+    return K > 128 ? launchp<256, PEPI_WGRAD, __bf16, true>(a, splits, s) : launchp<128, PEPI_WGRAD, __bf16, true>(a, splits, s);
 }

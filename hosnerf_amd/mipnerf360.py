@@ -69,6 +69,15 @@ class _Lin(nn.Module):
         self.bias = bias
 
 
+class _PlanesSaved:
+    """Activations of one planes-mode MLP query kept for the backward pass."""
+
+    __slots__ = ("X16", "Xb", "y16", "yb", "WT")
+
+    def __init__(self, X16, Xb, y16, yb, WT):
+        self.X16, self.Xb, self.y16, self.yb, self.WT = X16, Xb, y16, yb, WT
+
+
 class _LayerSpec:
     __slots__ = ("W", "b", "N", "K", "Kpad", "Npad")
 
@@ -203,6 +212,8 @@ class MipNeRF360MLP(FlatModule):
 
     def _forward_impl(self, X: torch.Tensor, viewdirs: Optional[torch.Tensor], B: int, S: int, save: bool):
         """X [P, X_LD] encoded samples -> density [P], rgb [P,3] | None, saved activations."""
+        if self._use_planes():
+            return self._forward_planes(X, viewdirs, B, S, save)
         P = X.shape[0]
         dev = X.device
         W = self.netwidth
@@ -244,6 +255,8 @@ class MipNeRF360MLP(FlatModule):
 
     def _backward_impl(self, saved, density, rgb, g_density, g_rgb, state: int):
         """Accumulate parameter gradients into the flat grad buffer (fused wgrad accumulation)."""
+        if isinstance(saved[0], _PlanesSaved):
+            return self._backward_planes(saved, density, rgb, g_density, g_rgb, state)
         X, acts = saved[0], saved[1]
         P = X.shape[0]
         dev = X.device
@@ -305,6 +318,144 @@ class MipNeRF360MLP(FlatModule):
                 dz = dz_prev
         # state-embedding gradient: the 64 embedding columns of x are constant over samples, so
         # d embed = (sum_p dZ[p,:]) @ W[:, embed cols] = db @ W[:, embed cols]   (M:295-296)
+        g_embed = self._embeds.view(self.store.grad)[state]
+        for tmp, Wt, c0 in embed_cols:
+            g_embed += tmp[:W] @ Wt[:W, c0:c0 + EMBED]
+
+    # ------------------------------------------------------------------ planes path (ops.GEMM_PLANES)
+    PLANES_MIN_WIDTH = 512
+
+    def _use_planes(self) -> bool:
+        return ops.get_gemm_mode() == ops.GEMM_PLANES and self.netwidth >= self.PLANES_MIN_WIDTH
+
+    def _weight_planes(self, need_t: bool):
+        """fp16 hi/lo planes of every weight (one pass over this MLP's span of the flat buffer: the planes keep the
+        flat layout, so a layer's planes are a view at its region offset) and, for the backward pass, transposed
+        bf16 planes [Kpad][Npad] of the trunk / head weights (dgrad operand)."""
+        st = self.store
+        specs = list(self._layers) + [self._head]
+        lo = min(L.W.offset for L in specs)
+        hi = max(L.W.offset + L.W.numel for L in specs)
+        span = st.param[lo:hi].view(1, -1)
+        w16, _ = ops.split_planes2(span, ld=hi - lo, wantb=False)
+
+        def view16(L):
+            o = L.W.offset - lo
+            return ops.Planes(w16.t[:, 0, o:o + L.W.numel].view(2, L.Npad, L.Kpad), L.Npad, L.Kpad)
+
+        W16 = [view16(L) for L in specs]
+        WT = None
+        if need_t:
+            WT = [ops.split_planes(L.W.view(st.param), dtype=torch.bfloat16, transposed=True, row_major=False)[1]
+                  for L in specs]
+        return W16, WT
+
+    def _forward_planes(self, X: torch.Tensor, viewdirs, B: int, S: int, save: bool):
+        P = X.shape[0]
+        dev = X.device
+        W = self.netwidth
+        W16, WT = self._weight_planes(need_t=save)
+        X16, Xb = ops.split_planes2(X, C=X_LD, ld=X_LD, wantb=save)
+        h = X16
+        kin = X_LD
+        y16: List[ops.Planes] = []
+        yb: List[ops.Planes] = []
+        ping = [None, None]
+        for i, L in enumerate(self._layers):
+            if save:
+                out = ops.Planes.empty(P, W, torch.float16, dev)
+                outb = ops.Planes.empty(P, W, torch.bfloat16, dev)
+            else:
+                if ping[i & 1] is None:
+                    ping[i & 1] = ops.Planes.empty(P, W, torch.float16, dev)
+                out, outb = ping[i & 1], None
+            _, bt = self._w(L)
+            if i in self._skip_consumers:
+                ops.linearp_fwd(h, W, W16[i], bt, P, W, True, out, outb, A1=X16, K1=X_LD)
+            else:
+                ops.linearp_fwd(h, kin, W16[i], bt, P, W, True, out, outb)
+            if save:
+                y16.append(out)
+                yb.append(outb)
+            h, kin = out, W
+        density = torch.empty(P, device=dev)
+        Hs = self._head
+        _, bt = self._w(Hs)
+        saved0 = _PlanesSaved(X16, Xb, y16, yb, WT)
+        if self.disable_rgb:
+            ops.linearp_fwd(h, W, W16[-1], bt, P, 1, False, None, None, epilogue=ops.EPI_DENSITY, aux=density,
+                            p0=self.density_bias)
+            return density, None, (saved0,)
+        bw = self.bottleneck_width
+        Xv = torch.empty(P, XV_LD, device=dev)
+        ops.linearp_fwd(h, W, W16[-1], bt, P, bw + 1, False, None, None, C=Xv, epilogue=ops.EPI_NERF_HEAD,
+                        aux=density, aux_col=bw, p0=self.density_bias)
+        ops.encode_viewdirs(viewdirs, S, Xv, bw)
+        hv = torch.empty(P, self.netwidth_condition, device=dev)
+        Wt, bt = self._w(self._views)
+        ops.linear_fwd(Xv, XV_LD, Wt, bt, self.netwidth_condition, hv, ops.EPI_RELU)
+        rgb = torch.empty(P, 3, device=dev)
+        Wt, bt = self._w(self._rgb)
+        ops.linear_fwd(hv, self.netwidth_condition, Wt, bt, 3, rgb, ops.EPI_RGB, p0=self.rgb_padding)
+        return density, rgb, (saved0, None, Xv, hv)
+
+    def _backward_planes(self, saved, density, rgb, g_density, g_rgb, state: int):
+        sv: _PlanesSaved = saved[0]
+        P = sv.X16.rows
+        dev = density.device
+        W = self.netwidth
+        Hs = self._head
+        nl = len(self._layers)
+        g_density = None if g_density is None else g_density.contiguous().view(-1)
+        if self.disable_rgb:
+            dyh = torch.zeros(P, 32, device=dev)
+            ops.head_grad(g_density, density, None, None, 0.0, dyh, 0, None)
+        else:
+            Xv, hv = saved[2], saved[3]
+            bw = self.bottleneck_width
+            NC = self.netwidth_condition
+            g_rgb = None if g_rgb is None else g_rgb.contiguous().view(-1, 3)
+            dz_rgb = torch.zeros(P, 32, device=dev)
+            dyh = torch.zeros(P, XV_LD, device=dev)
+            ops.head_grad(g_density, density, g_rgb, rgb, self.rgb_padding, dyh, bw, dz_rgb)
+            Wt, _ = self._w(self._rgb)
+            gW, gb = self._w(self._rgb, grad=True)
+            ops.linear_wgrad(dz_rgb, hv, gW, gb, 3, NC)
+            dzv = torch.empty(P, NC, device=dev)
+            ops.linear_dgrad(dz_rgb, Wt, 32, NC, dzv, mask_src=hv)
+            Wt, _ = self._w(self._views)
+            gW, gb = self._w(self._views, grad=True)
+            ops.linear_wgrad(dzv, Xv, gW, gb, NC, XV_LD)
+            ops.linear_dgrad(dzv, Wt, NC, bw, dyh)
+        # head: [bottleneck ; density] (M:305, M:325) -- from here on everything is bf16 planes
+        _, dyhP = ops.split_planes2(dyh, C=dyh.shape[1], ld=dyh.shape[1], want16=False)
+        gW, gb = self._w(Hs, grad=True)
+        ops.linearp_wgrad(dyhP, sv.yb[-1], gW, gb, P, Hs.N, W)
+        dz = ops.Planes.empty(P, W, torch.bfloat16, dev)
+        ops.linearp_dgrad(dyhP, sv.WT[-1], Hs.Npad, P, W, mask=sv.y16[-1], dX=dz)
+        embed_cols = []
+        for i in range(nl - 1, -1, -1):
+            L = self._layers[i]
+            Wt, _ = self._w(L)
+            gW, gb = self._w(L, grad=True)
+            inp_b = sv.yb[i - 1] if i > 0 else sv.Xb
+            if i in self._skip_consumers:
+                tmp = torch.zeros(L.Npad, device=dev)
+                ops.linearp_wgrad(dz, inp_b, gW, tmp, P, W, W)
+                ops.linearp_wgrad(dz, sv.Xb, gW, None, P, W, X_LD, w_col0=W)
+                gb += tmp
+                embed_cols.append((tmp, Wt, W + POS_FEATS))
+            elif i == 0:
+                tmp = torch.zeros(L.Npad, device=dev)
+                ops.linearp_wgrad(dz, sv.Xb, gW, tmp, P, W, X_LD)
+                gb += tmp
+                embed_cols.append((tmp, Wt, POS_FEATS))
+            else:
+                ops.linearp_wgrad(dz, inp_b, gW, gb, P, W, W)
+            if i > 0:
+                dz_prev = ops.Planes.empty(P, W, torch.bfloat16, dev)
+                ops.linearp_dgrad(dz, sv.WT[i], W, P, W, mask=sv.y16[i - 1], dX=dz_prev)
+                dz = dz_prev
         g_embed = self._embeds.view(self.store.grad)[state]
         for tmp, Wt, c0 in embed_cols:
             g_embed += tmp[:W] @ Wt[:W, c0:c0 + EMBED]

@@ -69,16 +69,22 @@ def _timed(key, flops, launch):
 
 
 # ------------------------------------------------------------------------------------------ GEMMs
-GEMM_FP32, GEMM_BF16X3 = 0, 1
+GEMM_FP32, GEMM_BF16X3, GEMM_PLANES = 0, 1, 2
+_planes_mode = False
 
 
 def set_gemm_mode(mode: int):
-    """0 = exact fp32 MFMA, 1 = bf16x3 split precision (default).  Process-wide."""
-    _lib.check(_lib.load().hos_set_gemm_mode(int(mode)), "hos_set_gemm_mode")
+    """0 = exact fp32 MFMA; 1 = split precision (fp16 / bf16 hi-lo, 3 MFMAs per product) on fp32 operands;
+    2 = the same arithmetic, but the wide MLP trunks keep their activations as pre-split 16-bit planes
+    (hos_linearp_*: LDS-DMA staging, no conversion work in the K loop); every other GEMM runs as in mode 1.
+    Process-wide."""
+    global _planes_mode
+    _planes_mode = int(mode) == GEMM_PLANES
+    _lib.check(_lib.load().hos_set_gemm_mode(GEMM_BF16X3 if _planes_mode else int(mode)), "hos_set_gemm_mode")
 
 
 def get_gemm_mode() -> int:
-    return int(_lib.load().hos_get_gemm_mode())
+    return GEMM_PLANES if _planes_mode else int(_lib.load().hos_get_gemm_mode())
 
 
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
@@ -562,29 +568,45 @@ def split_planes(src: torch.Tensor, C: Optional[int] = None, dtype=torch.float16
     return out, outT
 
 
+def split_planes2(src: torch.Tensor, C: Optional[int] = None, ld: Optional[int] = None, want16: bool = True, wantb: bool = True):
+    """fp32 [R, lds] -> (fp16 Planes | None, bf16 Planes | None), both row-major [R][ld], in one pass."""
+    R = src.shape[0]
+    C = src.shape[1] if C is None else C
+    ld = round_up(C, 32) if ld is None else ld
+    p16 = Planes.empty(R, ld, torch.float16, src.device, C) if want16 else None
+    pb = Planes.empty(R, ld, torch.bfloat16, src.device, C) if wantb else None
+    call("hos_split_planes2", ptr(src), src.stride(0), R, C,
+         _pp(None if p16 is None else p16.hi), _pp(None if p16 is None else p16.lo), ld,
+         _pp(None if pb is None else pb.hi), _pp(None if pb is None else pb.lo), ld)
+    return p16, pb
+
+
 def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool = True, Y: Optional[Planes] = None,
-                YT: Optional[Planes] = None, A1: Optional[Planes] = None, K1: int = 0, C: Optional[torch.Tensor] = None,
+                Yb: Optional[Planes] = None, A1: Optional[Planes] = None, K1: int = 0, C: Optional[torch.Tensor] = None,
                 epilogue: int = EPI_NONE, aux=None, aux_col: int = -1, p0: float = 0.0):
+    """Y (fp16 planes) / Yb (bf16 planes) = relu?([A | A1] @ W^T + bias), or the fp32 epilogues into C / aux."""
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
     _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linearp_fwd", _pp(A.hi), _pp(A.lo), A.ld, K0, _pp(None if A1 is None else A1.hi), _pp(None if A1 is None else A1.lo),
         0 if A1 is None else A1.ld, K1, _pp(W.hi), _pp(W.lo), W.ld, ptr(bias), M, N, int(relu),
         _pp(None if Y is None else Y.hi), _pp(None if Y is None else Y.lo), 0 if Y is None else Y.ld,
-        _pp(None if YT is None else YT.hi), _pp(None if YT is None else YT.lo), 0 if YT is None else YT.ld,
+        _pp(None if Yb is None else Yb.hi), _pp(None if Yb is None else Yb.lo), 0 if Yb is None else Yb.ld,
         ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
 
 
 def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optional[Planes] = None,
-                  dX: Optional[Planes] = None, dXT: Optional[Planes] = None):
+                  dX: Optional[Planes] = None):
+    """dX (bf16 planes [M][ld]) = (dZ @ WT^T) masked by mask.hi > 0; WT = transposed weight planes [K][Npad]."""
     _timed(f"gemmp_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
         "hos_linearp_dgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(WT.hi), _pp(WT.lo), WT.ld, Npad,
         _pp(None if mask is None else mask.hi), 0 if mask is None else mask.ld, M, K,
-        _pp(None if dX is None else dX.hi), _pp(None if dX is None else dX.lo), 0 if dX is None else dX.ld,
-        _pp(None if dXT is None else dXT.hi), _pp(None if dXT is None else dXT.lo), 0 if dXT is None else dXT.ld))
+        _pp(dX.hi), _pp(dX.lo), dX.ld))
 
 
-def linearp_wgrad(dZT: Planes, XT: Planes, dW: torch.Tensor, db, M: int, N: int, K: int, w_col0: int = 0, splits: int = 0):
+def linearp_wgrad(dZ: Planes, X: Planes, dW: torch.Tensor, db, M: int, N: int, K: int, w_col0: int = 0, splits: int = 0,
+                  x_col0: int = 0):
+    """dW[:, w_col0:w_col0+K] += dZ^T @ X[:, x_col0:x_col0+K]; db += column sums of dZ (row-major bf16 planes)."""
     _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
-        "hos_linearp_wgrad", _pp(dZT.hi), _pp(dZT.lo), dZT.ld, _pp(XT.hi), _pp(XT.lo), XT.ld,
+        "hos_linearp_wgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(X.hi) + 2 * x_col0, _pp(X.lo) + 2 * x_col0, X.ld,
         ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits))

@@ -98,25 +98,29 @@ int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* 
 int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* hi, void* lo, int ldo,
                      void* hiT, void* loT, int ldt, hos_stream_t stream);
 
+/* fp32 [R][lds] -> fp16 planes [R][ld16] and/or bf16 planes [R][ldb] in one pass (padding columns zeroed). */
+int hos_split_planes2(const float* src, int lds, int R, int C, void* h16, void* l16, int ld16,
+                      void* hb, void* lb, int ldb, hos_stream_t stream);
+
 /* Forward: acc[M,N] = [A | A1][M,K0+K1] @ W[N,K0+K1]^T (fp16 planes) + bias.
- *  - plane outputs (Yhi != NULL and/or YThi != NULL): Y = relu?(acc): row-major fp16 planes [M][ldy]
- *    (input of the next layer; columns [N,ldy) zeroed) and transposed bf16 planes [N][ldyt] (wgrad operand);
+ *  - plane outputs (Yhi != NULL and/or Ybhi != NULL): Y = relu?(acc) as row-major fp16 planes [M][ldy] (input of
+ *    the next layer) and/or as row-major bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed;
  *  - otherwise the fp32 epilogues of hos_linear_fwd (C/ldc/epilogue/aux/aux_col/p0). */
 int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0, const void* A1hi, const void* A1lo,
                     int lda1, int K1, const void* Whi, const void* Wlo, int ldw, const float* bias,
-                    int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* YThi, void* YTlo, int ldyt,
+                    int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* Ybhi, void* Yblo, int ldyb,
                     float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream);
 
 /* Data gradient: dX[M,K] = dZ[M,Npad] @ Wt[K,Npad]^T (bf16 planes; Wt = transposed weight planes), masked by the
- * fp16 hi plane of the layer input (x > 0) if mask_hi != NULL; written as bf16 planes row-major [M][lddx] and/or
- * transposed [K][lddxt]. */
+ * fp16 hi plane of the layer input (x > 0) if mask_hi != NULL; written as row-major bf16 planes [M][lddx]. */
 int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, const void* WThi, const void* WTlo,
                       int ldwt, int Npad, const void* mask_hi, int ldmask, int M, int K,
-                      void* dXhi, void* dXlo, int lddx, void* dXThi, void* dXTlo, int lddxt, hos_stream_t stream);
+                      void* dXhi, void* dXlo, int lddx, hos_stream_t stream);
 
-/* Weight gradient: dW[N,K] += dZt[N,M] @ Xt[K,M]^T (bf16 transposed planes), db[N] += row sums of dZt; fp32 atomics. */
-int hos_linearp_wgrad(const void* dZThi, const void* dZTlo, int lddzt, const void* XThi, const void* XTlo,
-                      int ldxt, float* dW, int ldw, float* db, int M, int N, int K, int splits, hos_stream_t stream);
+/* Weight gradient: dW[N,K] += dZ[M,N]^T @ X[M,K] (both ROW-MAJOR bf16 planes; the reduction-contiguous MFMA
+ * fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ; fp32 atomics.  M % 32 == 0. */
+int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
+                      int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).

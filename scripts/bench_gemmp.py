@@ -9,14 +9,13 @@ dev = torch.device("cuda")
 g = torch.Generator(device="cuda").manual_seed(0)
 X = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K**0.5
 b = torch.randn(N, device=dev, generator=g); dYf = torch.randn(M, N, device=dev, generator=g)
-PAD = int(os.environ.get("PAD", 0))
-Xp, XTp = ops.split_planes(X, dtype=torch.float16, transposed=False, ldo=K + PAD)
-_, XTb = ops.split_planes(X, dtype=torch.bfloat16, transposed=True, row_major=False, ldt=M + PAD)
-Wp, _ = ops.split_planes(W, dtype=torch.float16, ldo=K + PAD)
-_, WTb = ops.split_planes(W, dtype=torch.bfloat16, transposed=True, row_major=False, ldt=N + PAD)      # [K][N]
-dZ, dZT = ops.split_planes(dYf, dtype=torch.bfloat16, transposed=True, ldo=N + PAD, ldt=M + PAD)
-Y = ops.Planes.empty(M, N, torch.float16, dev); YT = ops.Planes.empty(N, M, torch.bfloat16, dev)
-dX = ops.Planes.empty(M, K, torch.bfloat16, dev); dXT = ops.Planes.empty(K, M, torch.bfloat16, dev)
+X16, Xb = ops.split_planes2(X)
+W16, _ = ops.split_planes(W, dtype=torch.float16)
+_, WTb = ops.split_planes(W, dtype=torch.bfloat16, transposed=True, row_major=False)      # [K][N]
+_, dZ = ops.split_planes2(dYf, want16=False)
+Y = ops.Planes.empty(M, N, torch.float16, dev); Yb = ops.Planes.empty(M, N, torch.bfloat16, dev)
+dX = ops.Planes.empty(M, K, torch.bfloat16, dev)
+C = torch.empty(M, N, device=dev)
 dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
 fl = 2.0 * M * N * K
 
@@ -30,19 +29,22 @@ def run(name, fn):
     us = a.elapsed_time(e) * 1e3 / iters
     print(f"planes {name:12s} M={M} N={N} K={K}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s")
 
-run("fwd", lambda: ops.linearp_fwd(Xp, K, Wp, b, M, N, True, Y, YT))
-run("fwd(noT)", lambda: ops.linearp_fwd(Xp, K, Wp, b, M, N, True, Y, None))
-run("dgrad", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xp, dX=dX, dXT=dXT))
-run("dgrad(noT)", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xp, dX=dX, dXT=None))
-run("wgrad", lambda: ops.linearp_wgrad(dZT, XTb, dW, db, M, N, K))
+run("fwd(2fmt)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb))
+run("fwd(f16)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, None))
+run("fwd(f32out)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU))
+run("dgrad", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX))
+run("wgrad", lambda: ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K))
+run("split2", lambda: ops.split_planes2(X))
 # accuracy
-ops.linearp_fwd(Xp, K, Wp, b, M, N, True, Y, YT)
+ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb)
 ref = torch.relu(X[:512].double() @ W.double().T + b.double())
-print("fwd err rowmajor", (Y.float()[:512].double() - ref).abs().max().item(), "transposed", (YT.float()[:, :512].double().T - ref).abs().max().item())
-ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xp, dX=dX, dXT=dXT)
+print("fwd err fp16 planes", (Y.float()[:512].double() - ref).abs().max().item(), "bf16 planes", (Yb.float()[:512].double() - ref).abs().max().item())
+ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU)
+print("fwd err fp32 out", (C[:512].double() - ref).abs().max().item())
+ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX)
 refd = (dYf[:512].double() @ W.double()) * (X[:512] > 0)
-print("dgrad err", (dX.float()[:512].double() - refd).abs().max().item(), (dXT.float()[:, :512].double().T - refd).abs().max().item(), "scale", refd.abs().max().item())
+print("dgrad err", (dX.float()[:512].double() - refd).abs().max().item(), "scale", refd.abs().max().item())
 dW.zero_(); db.zero_()
-ops.linearp_wgrad(dZT, XTb, dW, db, M, N, K)
+ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K)
 refw = dYf.double().T @ X.double()
 print("wgrad err", (dW.double() - refw).abs().max().item(), "scale", refw.abs().max().item(), "db err", (db.double() - dYf.double().sum(0)).abs().max().item())

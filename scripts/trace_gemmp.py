@@ -1,0 +1,23 @@
+"""Phase timeline of the planes forward GEMM (workgroup 0, K tiles 8..11).  Needs a -DHOS_TRACE=1 build:
+   scripts/build_variant.sh trace -DHOS_TRACE=1 && HOS_LIB_PATH=build/variants/trace/libhosrender.so python scripts/trace_gemmp.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hosnerf_amd import ops
+dev = torch.device("cuda")
+M, N, K = 32768, 1024, 1024
+X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) / 32; b = torch.zeros(N, device=dev)
+X16, _ = ops.split_planes2(X, wantb=False); W16, _ = ops.split_planes(W, dtype=torch.float16)
+Y = ops.Planes.empty(M, N, torch.float16, dev)
+tr = torch.zeros(8 * 4 * 8, dtype=torch.int64, device=dev)
+for _ in range(3):
+    ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, None, aux=tr.view(torch.float32))
+torch.cuda.synchronize()
+t = tr.cpu().view(8, 4, 8)
+t0 = int(t[t > 0].min())
+names = ["top", "G1", "G2", "G3", "dma+lds waited", "barrier", "dma issued", "G4"]
+for w in range(8):
+    print(f"wave {w}")
+    for it in range(4):
+        row = t[w, it]
+        print("   tile", it, " ".join(f"{names[k]}={int(row[k]) - t0 if row[k] > 0 else -1:6d}" for k in range(8)))
