@@ -421,8 +421,17 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #pragma unroll
             for (int y = 0; y < TN; ++y) {
                 if constexpr (EPI == PEPI_WGRAD) {
-                    f32x16 v = acc[x][y];
-                    gemm_epilogue_tile<MODE_WGRAD>(a.f32, v, i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
+                    if (a.f32.aux != nullptr) {
+                        // split-K partial tile -> slab `split` of the workspace with plain 16-byte stores; the slabs
+                        // are summed into dW by wgrad_reduce_kernel (fp32 atomics ran at ~1 TB/s: 70 us for 65 MB)
+                        GemmArgs w = a.f32;
+                        w.C = a.f32.aux + (size_t)split * a.f32.M * a.f32.aux_col;
+                        w.ldc = a.f32.aux_col; w.bias = nullptr; w.epi = HOS_EPI_NONE; w.mask = nullptr; w.aux = nullptr;
+                        gemm_epilogue_tile<MODE_FWD>(w, acc[x][y], i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
+                    } else {
+                        f32x16 v = acc[x][y];
+                        gemm_epilogue_tile<MODE_WGRAD>(a.f32, v, i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
+                    }
                 } else {
                     gemm_epilogue_tile<MODE_FWD>(a.f32, acc[x][y], i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
                 }
@@ -521,15 +530,7 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     a.tiles_m = hos_cdiv(a.M, PBM);
     a.tiles_n = hos_cdiv(a.N, BN);
     if (EPI == PEPI_WGRAD) {
-        static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
-        if (env_splits > 0) splits = env_splits;
-        if (splits <= 0) {
-            const int tiles = a.tiles_m * a.tiles_n;
-            splits = hos_cdiv(256, tiles);                         // one workgroup per CU
-            if (splits > a.nk / 8) splits = a.nk / 8 > 0 ? a.nk / 8 : 1;
-        }
-        if (splits > a.nk) splits = a.nk;
-        a.kt_per_split = hos_cdiv(a.nk, splits);
+        a.kt_per_split = hos_cdiv(a.nk, splits);          // splits chosen by wgrad_splits()
         splits = hos_cdiv(a.nk, a.kt_per_split);
     } else {
         splits = 1;
@@ -600,6 +601,39 @@ __global__ __launch_bounds__(256) void split_planes2_kernel(const float* __restr
             *reinterpret_cast<uint2*>(lb + (size_t)r * ldb + c) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
         }
     }
+}
+
+// dW[n][k] += sum_s ws[s][n][k]   (ws slabs [N][wsld], wsld % 4 == 0; dW row stride ldw)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, int N, int K, int wsld,
+                                                           float* __restrict__ dW, int ldw) {
+    const int groups = wsld >> 2;
+    const size_t total = (size_t)N * groups, slab = (size_t)N * wsld;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / groups), k = (int)(i % groups) * 4;
+        const float* p = ws + (size_t)n * wsld + k;
+        float4 s = *reinterpret_cast<const float4*>(p);
+        for (int j = 1; j < splits; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(p + j * slab);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float* d = dW + (size_t)n * ldw + k;
+        const float vals[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < K) d[e] += vals[e];
+    }
+}
+
+// split-K factor of the weight gradient: one workgroup per CU, at least 8 K tiles per split
+inline int wgrad_splits(int tiles, int nk, int requested) {
+    static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
+    int splits = env_splits > 0 ? env_splits : requested;
+    if (splits <= 0) {
+        splits = hos_cdiv(256, tiles);
+        if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
+    }
+    if (splits > nk) splits = nk;
+    const int per = hos_cdiv(nk, splits);
+    return hos_cdiv(nk, per);
 }
 
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -683,7 +717,7 @@ extern "C" int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, c
 
 extern "C" int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
                                  int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits,
-                                 hos_stream_t stream) {
+                                 float* ws, long long ws_floats, hos_stream_t stream) {
     if (!dZhi || !dZlo || !Xhi || !Xlo || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
     if (M % PBK) return HOS_E_SHAPE;
     if ((lddz & 7) || (ldx & 7)) return HOS_E_ALIGN;
@@ -693,6 +727,19 @@ extern "C" int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, c
     a.Bhi = (const uint16_t*)Xhi; a.Blo = (const uint16_t*)Xlo; a.ldb = ldx;
     a.M = N; a.N = K; a.nk = M / PBK;
     a.f32.C = dW; a.f32.ldc = ldw; a.f32.M = N; a.f32.N = K; a.f32.db = db;
+    const bool wide = K > 128;
+    const int tiles = hos_cdiv(N, PBM) * hos_cdiv(K, wide ? 256 : 128);
+    splits = wgrad_splits(tiles, a.nk, splits);
+    // slab reduction instead of atomics when the caller lent a large enough, 16-byte aligned workspace
+    const int wsld = (K + 3) & ~3;
+    const bool slabs = splits > 1 && ws != nullptr && al16p(ws) && (long long)splits * N * wsld <= ws_floats;
+    if (slabs) { a.f32.aux = ws; a.f32.aux_col = wsld; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return K > 128 ? launchp<256, PEPI_WGRAD, __bf16, true>(a, splits, s) : launchp<128, PEPI_WGRAD, __bf16, true>(a, splits, s);
+    const int rc = wide ? launchp<256, PEPI_WGRAD, __bf16, true>(a, splits, s) : launchp<128, PEPI_WGRAD, __bf16, true>(a, splits, s);
+    if (rc != 0 || !slabs) return rc;
+    const size_t total = (size_t)N * (wsld >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, splits, N, K, wsld, dW, ldw);
+    return hos_launch_status();
 }

@@ -323,7 +323,7 @@ class MipNeRF360MLP(FlatModule):
             g_embed += tmp[:W] @ Wt[:W, c0:c0 + EMBED]
 
     # ------------------------------------------------------------------ planes path (ops.GEMM_PLANES)
-    PLANES_MIN_WIDTH = 512
+    PLANES_MIN_WIDTH = int(os.environ.get("HOS_PLANES_MIN_WIDTH", "256"))
 
     def _use_planes(self) -> bool:
         return ops.get_gemm_mode() == ops.GEMM_PLANES and self.netwidth >= self.PLANES_MIN_WIDTH

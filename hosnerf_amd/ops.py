@@ -604,9 +604,24 @@ def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optio
         _pp(dX.hi), _pp(dX.lo), dX.ld))
 
 
+_wgrad_ws = {}          # device index -> fp32 scratch for the split-K slabs of hos_linearp_wgrad
+WGRAD_WS_FLOATS = 16 * 1024 * 1024 + 4096      # 64 MB: 16 slabs of a 1024 x 1024 weight gradient
+
+
+def _wgrad_workspace(device: torch.device) -> torch.Tensor:
+    ws = _wgrad_ws.get(device.index)
+    if ws is None:
+        ws = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
+        _wgrad_ws[device.index] = ws
+    return ws
+
+
 def linearp_wgrad(dZ: Planes, X: Planes, dW: torch.Tensor, db, M: int, N: int, K: int, w_col0: int = 0, splits: int = 0,
-                  x_col0: int = 0):
-    """dW[:, w_col0:w_col0+K] += dZ^T @ X[:, x_col0:x_col0+K]; db += column sums of dZ (row-major bf16 planes)."""
+                  x_col0: int = 0, use_ws: bool = False):
+    """dW[:, w_col0:w_col0+K] += dZ^T @ X[:, x_col0:x_col0+K]; db += column sums of dZ (row-major bf16 planes).
+    use_ws=True sums the split-K partial tiles through a workspace in a fixed order (bit-reproducible; measured
+    time-neutral at 1024x1024, slower for the 256-wide proposal MLPs) instead of fp32 atomics."""
+    ws = _wgrad_workspace(dW.device) if use_ws else None
     _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
         "hos_linearp_wgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(X.hi) + 2 * x_col0, _pp(X.lo) + 2 * x_col0, X.ld,
-        ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits))
+        ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits, ptr(ws), 0 if ws is None else ws.numel()))

@@ -118,9 +118,12 @@ int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, const void* 
                       void* dXhi, void* dXlo, int lddx, hos_stream_t stream);
 
 /* Weight gradient: dW[N,K] += dZ[M,N]^T @ X[M,K] (both ROW-MAJOR bf16 planes; the reduction-contiguous MFMA
- * fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ; fp32 atomics.  M % 32 == 0. */
+ * fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ.  M % 32 == 0.
+ * The split-K partial tiles are written to `ws` (>= splits * N * round4(K) floats, caller-owned scratch, may be
+ * NULL) and summed by a second launch; without a workspace they are accumulated with fp32 atomics. */
 int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
-                      int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits, hos_stream_t stream);
+                      int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits,
+                      float* ws, long long ws_floats, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).

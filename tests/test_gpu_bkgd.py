@@ -481,7 +481,11 @@ def test_planes_gemm_matches_fp64(M, N, K):
     refd = (dY.double() @ W.double()) * (X > 0)
     assert (dX.float().double() - refd).abs().max().item() < 2e-4 * refd.abs().max().item() + 1e-5
     dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
-    ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K)
     refw = dY.double().T @ X.double()
-    assert (dW.double() - refw).abs().max().item() < 2e-4 * refw.abs().max().item()
-    assert (db.double() - dY.double().sum(0)).abs().max().item() < 2e-3
+    for use_ws in (True, False):             # slab reduction through the workspace / fp32 atomics
+        dW.zero_(); db.zero_()
+        ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K, use_ws=use_ws)
+        assert (dW.double() - refw).abs().max().item() < 2e-4 * refw.abs().max().item()
+        assert (db.double() - dY.double().sum(0)).abs().max().item() < 2e-3
+    ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K)                                  # accumulates
+    assert (dW.double() - 2 * refw).abs().max().item() < 4e-4 * refw.abs().max().item()
