@@ -215,9 +215,20 @@ def main():
             table = prof.summary()
             dom = max(table, key=lambda r: r["total_ms"]) if table else None
             if dom is not None:
+                # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
+                # so the figure comes from the committed rocprofv3 --pmc pass of the same kernel and shape
+                # (scripts/pmc_gemmp.sh -> profiles/r01_pmc_gemmp_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); null if absent
+                traffic = None
+                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemmp_traffic.json")
+                if os.path.exists(tpath):
+                    with open(tpath) as f:
+                        tj = json.load(f)
+                    key = dom["kernel"].split("[")[0] + "[32768x1024x1024]"
+                    if key in tj and dom["flop_per_launch"] == 2.0 * 32768 * 1024 * 1024:
+                        traffic = tj[key]["hbm_bytes_per_launch"]
                 peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "fp32" else SPLIT_MFMA_PEAK_TFLOPS
                 out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                   "frac": dom["tflops"] / peak, "traffic": None,
+                                   "frac": dom["tflops"] / peak, "traffic": traffic,
                                    "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
                                    "flop_per_launch": dom["flop_per_launch"]}
             out["kernels"] = table
