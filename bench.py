@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=256)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="capture only zero_grad+forward+loss+backward; all-reduce, clip and Adam are launched eagerly "
+                         "(what multi-GPU runs do, so that no RCCL call sits inside a captured graph)")
     ap.add_argument("--gemm", choices=["planes", "split", "fp32"], default="planes",
                     help="split = fp16/bf16 hi-lo split MFMA (3 products, fp32 accumulate); fp32 = exact fp32 MFMA")
     return ap.parse_args()
@@ -121,16 +124,20 @@ def main():
 
     batch["times"] = 0.5          # python float: no host sync inside the step (the reference syncs on `time` every call)
 
-    def step(i, dynamic=False, frac=None):
+    def fwd_bwd(i, frac=None):
         opt.zero_grad()
         rend, hist = model(batch, (i / max_steps) if frac is None else frac, True, True, 0.1, 1e6)
         loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
         loss.backward()
+        return loss.detach()
+
+    def step(i, dynamic=False, frac=None):
+        loss = fwd_bwd(i, frac)
         if dynamic:
             opt.step(dynamic=True)
         else:
             opt.step(stage1_lr(i, max_steps))
-        return loss.detach()
+        return loss
 
     def barrier():
         if world > 1:
@@ -145,7 +152,8 @@ def main():
     # Per-step scalars that change (lr, Adam bias corrections) live in a 12-byte device block refreshed before each
     # replay; train_frac (only the resampling anneal scalar) is frozen at its capture value.
     graph = None
-    if world == 1 and not args.no_graph:
+    split_graph = (world > 1 or args.split_graph)     # keep the RCCL all-reduce (and the 3 launches behind it) out of the graph
+    if not args.no_graph:
         try:
             opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
             side = torch.cuda.Stream()
@@ -156,11 +164,14 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step(args.warmup, dynamic=True, frac=0.5)
+            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+                static_loss = fwd_bwd(args.warmup, frac=0.5) if split_graph else step(args.warmup, dynamic=True, frac=0.5)
             for _ in range(2):
                 opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
                 graph.replay()
+                if split_graph:
+                    opt.step(dynamic=True)
             torch.cuda.synchronize()
         except Exception as e:      # fall back to eager launches, and say so in the JSON
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -175,6 +186,8 @@ def main():
         if graph is not None:
             opt.set_step_hyper(stage1_lr(args.warmup + i, max_steps))
             graph.replay()
+            if split_graph:
+                opt.step(dynamic=True)
             loss = static_loss
         else:
             loss = step(args.warmup + i)
@@ -204,7 +217,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)",
             "gemm": args.gemm,
-            "launch": "hipGraph replay" if graph is not None else "eager", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
+            "launch": ("hipGraph replay (fwd+bwd) + eager all-reduce/clip/Adam" if split_graph else "hipGraph replay") if graph is not None else "eager", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
             "config": {"workload": "BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, "
                                    "64/64/32 samples, PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states",
                        "rays_per_gpu": args.rays, "global_rays": args.rays * world, "parallelism": f"dp{world} (ray shards, 1 flat-gradient all-reduce/step)"},

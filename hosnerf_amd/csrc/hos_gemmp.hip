@@ -341,24 +341,58 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #else
 #define HOS_STAMP(slot) do {} while (0)
 #endif
+    // One quarter = NM MFMAs (3 products x TM x TH tiles) with the LDS reads of the NEXT quarter (and, in the last
+    // quarter, the DMA requests of tile kt+2) issued BETWEEN them: `fill(i)` runs right behind MFMA i.  A wave issues
+    // in order, so anything placed in front of an MFMA group delays it; placed between MFMAs it costs nothing
+    // while the matrix pipe is busy.  Eight back-to-back global_load_lds stalled a wave for 600-1900 cycles
+    // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once).
+    constexpr int NM = 3 * TM * TH;
+#define HOS_GROUP(AH, AL, BH, BL, YH, FILL)                                                               \
+    do {                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
+        _Pragma("unroll") for (int x = 0; x < TM; ++x) { tie(AH[x]); tie(AL[x]); }                        \
+        _Pragma("unroll") for (int y = 0; y < TH; ++y) { tie(BH[y]); tie(BL[y]); }                        \
+        if (YH == 0) db_acc(AH, AL);                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
+            const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;                           \
+            if (!HOS_ABLATE_MFMA) {                                                                       \
+                if (pr == 0)      acc[x][(YH) * TH + y] = pmfma(AL[x].v, BH[y].v, acc[x][(YH) * TH + y]); \
+                else if (pr == 1) acc[x][(YH) * TH + y] = pmfma(AH[x].v, BL[y].v, acc[x][(YH) * TH + y]); \
+                else              acc[x][(YH) * TH + y] = pmfma(AH[x].v, BH[y].v, acc[x][(YH) * TH + y]); \
+            }                                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+            FILL(i);                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                            \
+        }                                                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
+    } while (0)
+
     unsigned so = 0;                     // byte offset of the stage holding tile kt
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const unsigned sn = STAGE - so;
+        const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
+        const int dstage = so ? 1 : 0;
         HOS_STAMP(0);
-        HOS_READ_B(b1h, b1l, so, 0, 1);
-        HOS_WAIT(NRB, a0h, a0l, b0h, b0l);
-        db_acc(a0h, a0l);
-        HOS_MMA(a0h, a0l, b0h, b0l, 0);
+        auto fill1 = [&](int i) {                // under (A0,B0): B1 = (s0, yh1)
+            if (i == 1) HOS_READ_B1(b1h, b1l, so, 0, 1, 0);
+            if (i == 3) HOS_READ_B1(b1h, b1l, so, 0, 1, 1);
+        };
+        HOS_GROUP(a0h, a0l, b0h, b0l, 0, fill1);
         HOS_STAMP(1);
-        HOS_READ_A(a1h, a1l, so, 1);
-        HOS_READ_B(b0h, b0l, so, 1, 0);
-        HOS_WAIT(NRA + NRB, a0h, a0l, b1h, b1l);
-        HOS_MMA(a0h, a0l, b1h, b1l, 1);
+        auto fill2 = [&](int i) {                // under (A0,B1): A1 = (s1), B0 = (s1, yh0)
+            if (i == 0) HOS_READ_A1(a1h, a1l, so, 1, 0);
+            if (i == 1) HOS_READ_A1(a1h, a1l, so, 1, 1);
+            if (i == 2) HOS_READ_B1(b0h, b0l, so, 1, 0, 0);
+            if (i == 3) HOS_READ_B1(b0h, b0l, so, 1, 0, 1);
+        };
+        HOS_GROUP(a0h, a0l, b1h, b1l, 1, fill2);
         HOS_STAMP(2);
-        HOS_READ_B(b1h, b1l, so, 1, 1);
-        HOS_WAIT(NRB, a1h, a1l, b0h, b0l);
-        db_acc(a1h, a1l);
-        HOS_MMA(a1h, a1l, b0h, b0l, 0);
+        auto fill3 = [&](int i) {                // under (A1,B0): B1 = (s1, yh1)
+            if (i == 1) HOS_READ_B1(b1h, b1l, so, 1, 1, 0);
+            if (i == 3) HOS_READ_B1(b1h, b1l, so, 1, 1, 1);
+        };
+        HOS_GROUP(a1h, a1l, b0h, b0l, 0, fill3);
         HOS_STAMP(3);
         // this wave's share of tile kt+1 has landed and its reads of this stage are complete; after the barrier
         // that holds for every wave, so the stage may be refilled and the other one read
@@ -366,44 +400,24 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         HOS_STAMP(4);
         asm volatile("s_barrier" ::: "memory");
         HOS_STAMP(5);
-        // Last quarter: its operands are already in registers, so the MFMAs start right behind the barrier and
-        // the DMA requests of tile kt+2 (first two thirds) and the first fragment reads of tile kt+1 (last third)
-        // are issued BETWEEN them.  Eight back-to-back global_load_lds stalled the issuing wave for 600-1900 cycles
-        // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once), and an
-        // in-order wave cannot issue an MFMA while it waits to issue a DMA (timeline: scripts/trace_gemmp.py).
-        {
-            const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
-            const int dstage = so ? 1 : 0;
-            constexpr int NM = 3 * TM * TH, ND = 2 * TM * TH;
-#pragma unroll
-            for (int y = 0; y < TH; ++y) { tie(b1h[y]); tie(b1l[y]); }      // landed before the barrier (lgkmcnt(0) above)
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < NM; ++i) {
-                const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;
-                if (!HOS_ABLATE_MFMA) {
-                    if (pr == 0)      acc[x][TH + y] = pmfma(a1l[x].v, b1h[y].v, acc[x][TH + y]);
-                    else if (pr == 1) acc[x][TH + y] = pmfma(a1h[x].v, b1l[y].v, acc[x][TH + y]);
-                    else              acc[x][TH + y] = pmfma(a1h[x].v, b1h[y].v, acc[x][TH + y]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (!HOS_ABLATE_DMA && more2 && i < ND) {
-#pragma unroll
-                    for (int q = i * QMAX / ND; q < (i + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 2, dstage);
-                }
-                if (more1) {
-                    if (i == NM - 4) HOS_READ_A1(a0h, a0l, sn, 0, 0);
-                    if (i == NM - 3) HOS_READ_A1(a0h, a0l, sn, 0, 1);
-                    if (i == NM - 2) HOS_READ_B1(b0h, b0l, sn, 0, 0, 0);
-                    if (i == NM - 1) HOS_READ_B1(b0h, b0l, sn, 0, 0, 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+        auto fill4 = [&](int i) {                // under (A1,B1): A0, B0 of tile kt+1, then the DMA of tile kt+2
+            if (more1) {
+                if (i == 0) HOS_READ_A1(a0h, a0l, sn, 0, 0);
+                if (i == 1) HOS_READ_A1(a0h, a0l, sn, 0, 1);
+                if (i == 2) HOS_READ_B1(b0h, b0l, sn, 0, 0, 0);
+                if (i == 3) HOS_READ_B1(b0h, b0l, sn, 0, 0, 1);
             }
-            __builtin_amdgcn_s_setprio(0);
-        }
+            constexpr int D0 = NM / 3, ND = NM - D0;          // DMA slots: the last two thirds of the group
+            if (!HOS_ABLATE_DMA && more2 && i >= D0) {
+#pragma unroll
+                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 2, dstage);
+            }
+        };
+        HOS_GROUP(a1h, a1l, b1h, b1l, 1, fill4);
         HOS_STAMP(7);
         so = sn;
     }
+#undef HOS_GROUP
 #undef HOS_STAMP
 #undef HOS_MMA
 #undef HOS_WAIT
