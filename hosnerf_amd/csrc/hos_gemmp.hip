@@ -162,6 +162,12 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int tr_pitch = isB ? B_PITCH : A_PITCH;
 
     auto issue_dma = [&](int q, int kt, int stage) {
+#ifdef HOS_EXP_SKIP_B_DMA      // timing experiment: only the A planes are staged (half the DMA bytes; results invalid)
+        if (isB) return;
+#endif
+#ifdef HOS_EXP_SKIP_A_DMA
+        if (!isB) return;
+#endif
         unsigned off;
         const uint16_t* P;
         if constexpr (!TR) {
@@ -642,7 +648,7 @@ inline int wgrad_splits(int tiles, int nk, int requested) {
     static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
     int splits = env_splits > 0 ? env_splits : requested;
     if (splits <= 0) {
-        splits = hos_cdiv(256, tiles);
+        splits = 256 / tiles > 0 ? 256 / tiles : 1;       // never more workgroups than CUs: one over costs a whole second round
         if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
     }
     if (splits > nk) splits = nk;
@@ -741,7 +747,10 @@ extern "C" int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, c
     a.Bhi = (const uint16_t*)Xhi; a.Blo = (const uint16_t*)Xlo; a.ldb = ldx;
     a.M = N; a.N = K; a.nk = M / PBK;
     a.f32.C = dW; a.f32.ldc = ldw; a.f32.M = N; a.f32.N = K; a.f32.db = db;
-    const bool wide = K > 128;
+    // 256 x 128 tiles up to K = 256: a [256,256] gradient then has two tiles x 128 splits instead of one x 256 --
+    // half the atomic traffic at the same parallelism (98 -> 55 us at M = 65536)
+    static const int narrow_max = getenv("HOS_WGRAD_NARROW_MAX") ? atoi(getenv("HOS_WGRAD_NARROW_MAX")) : 256;
+    const bool wide = K > narrow_max;
     const int tiles = hos_cdiv(N, PBM) * hos_cdiv(K, wide ? 256 : 128);
     splits = wgrad_splits(tiles, a.nk, splits);
     // slab reduction instead of atomics when the caller lent a large enough, 16-byte aligned workspace
