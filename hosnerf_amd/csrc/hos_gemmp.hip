@@ -8,20 +8,24 @@
 // scripts/probe/dma_probe.hip: this DMA pattern alone streams the whole operand set of a [32768,1024,1024] GEMM in
 // 66-87 us at one workgroup per CU (20-26 B/clk/CU), i.e. under the 82 us the MFMAs need.
 //
-// One kernel for the three passes; element (r,c) of a split matrix is hi[r*ld+c] + lo[r*ld+c]:
+// Plane storage ("interleaved planes"): a split matrix [R][ld] (ld % 32 == 0) is ONE 16-bit array [R][ld/32][2][32]:
+// per row and per block of 32 columns, 32 hi values followed by the 32 lo values (128 bytes).  The 32-deep K slice
+// of a row that a tile needs is then one whole 128-byte line (a request for half a line costs the memory path as much
+// as a whole one: scripts/probe/dma_probe.hip streams the operand set in 66 us with 128-byte pieces, 87 us with 64).
+// One kernel for the three passes; element (r,c) of a split matrix is hi + lo of its block:
 //   FWD    Y[m][n]  = sum_k X[m][k]  W[n][k]     X, W   fp16 planes (22 mantissa bits: fp32-grade), k contiguous
 //   DGRAD  dX[m][k] = sum_n dZ[m][n] Wt[k][n]    dZ, Wt bf16 planes (8-bit exponent: gradients of any size)
 //   WGRAD  dW[n][k] = sum_m dZ[m][n] X[m][k]     dZ, X  bf16 planes, ROW-MAJOR (reduction index = row): the MFMA
 //          fragments (8 consecutive reduction values per lane) are gathered with ds_read_b64_tr_b16, the gfx950
 //          LDS transpose read, so no transposed copy of any activation is ever written to HBM.
 //
-// Tile 256 x BN x 32, 512 threads (8 wave64 as 4(M) x 2(N)), LDS = 2 stages x {A hi, A lo, B hi, B lo}:
-//   * k-contiguous operands: plane tile [rows][32 k] = 64-byte rows, 16-byte chunks XOR-swizzled by (row>>2)&3 so
-//     the ds_read_b128 fragment reads are conflict free;
-//   * reduction-row operands (WGRAD): plane tile [32 m][R cols], byte column XOR-swizzled by (m&3)<<6 so the four
-//     rows a transpose read touches sit in four different 64-byte bank groups.
+// Tile 256 x BN x 32, 512 threads (8 wave64 as 4(M) x 2(N)), LDS = 2 stages x {A tile, B tile}:
+//   * k-contiguous operands: tile [rows][hi 32 k | lo 32 k] = 128-byte rows, the eight 16-byte chunks of a row
+//     XOR-swizzled by (row>>1)&7 so the ds_read_b128 fragment reads are conflict free;
+//   * reduction-row operands (WGRAD): tile [32 m][R cols x {hi,lo}], the 64-byte units of a row XOR-swizzled by
+//     m&3 so the four rows a transpose read touches sit in four different 64-byte bank groups.
 //   global_load_lds writes LDS linearly (wave base + lane*16), so both swizzles are applied on the per-lane SOURCE
-//   address.  Wave pair p (waves 2p, 2p+1) owns plane p of a stage.
+//   address.  Waves 0-3 stage the A tile (a quarter each), waves 4-7 the B tile.
 // Main loop: software-pipelined over quarter tiles with explicit counted waits and raw s_barrier (see below).
 // Epilogue: plane outputs go through a wave-private LDS staging buffer so that every global store instruction
 // writes whole 128-byte lines (the MFMA C layout gives a lane one column of 16 rows).
@@ -58,18 +62,19 @@ __device__ __forceinline__ f32x16 pmfma(const PVec<_Float16>::x8& a, const PVec<
 enum PEpi { PEPI_F32 = 0, PEPI_PLANES_FWD = 1, PEPI_PLANES_DGRAD = 2, PEPI_WGRAD = 3 };
 
 struct PArgs {
-    // operands (16-bit planes); A may have a second K segment (skip concat, k-contiguous form only)
-    const uint16_t* Ahi; const uint16_t* Alo; int lda; int kt0;
-    const uint16_t* A1hi; const uint16_t* A1lo; int lda1;
-    const uint16_t* Bhi; const uint16_t* Blo; int ldb;
+    // operands (interleaved 16-bit planes, row pitch 2*ld elements); A may have a second K segment (skip concat,
+    // k-contiguous form only)
+    const uint16_t* A; int lda; int kt0;
+    const uint16_t* A1; int lda1;
+    const uint16_t* B; int ldb;
     int M, N;            // output extents (rows i of the A side, rows j of the B side)
     int nk, kt_per_split, tiles_m, tiles_n;
     GemmArgs f32;        // fp32 output path (fused epilogues of hos_gemm_common.h) and WGRAD accumulation
     const float* bias;   // FWD
     int relu;            // FWD: apply ReLU
-    const uint16_t* mask_hi; int ldmask;          // DGRAD: fp16 hi plane of the layer input; gradient passes where > 0
-    uint16_t* Yhi; uint16_t* Ylo; int ldy;        // row-major planes [M][ldy]: fp16 for FWD, bf16 for DGRAD
-    uint16_t* Ybhi; uint16_t* Yblo; int ldyb;     // FWD only: the same values as bf16 planes (WGRAD operand)
+    const uint16_t* mask; int ldmask;             // DGRAD: fp16 planes of the layer input; gradient passes where hi > 0
+    uint16_t* Y; int ldy;                         // row-major planes [M][ldy]: fp16 for FWD, bf16 for DGRAD
+    uint16_t* Yb; int ldyb;                       // FWD only: the same values as bf16 planes (WGRAD operand)
 };
 
 template <typename E> __device__ __forceinline__ uint16_t to_bits(E v) { return __builtin_bit_cast(uint16_t, v); }
@@ -105,11 +110,11 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     constexpr int TM = PBM / (4 * 32);       // 2
     constexpr int TN = BN / (WN * 32);       // 4 or 2
     constexpr int TH = TN / 2;
-    constexpr int A_PLANE = PBM * PROWB, B_PLANE = BN * PROWB;      // 32 x rows x 2 bytes in either form
-    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    constexpr int QA = PBM / 32, QB = BN / 32;      // DMA instructions per wave per K tile for an A / B plane
+    constexpr int A_TILE = PBM * 128, B_TILE = BN * 128;            // bytes: rows x (hi 64 B + lo 64 B) in either form
+    constexpr int STAGE = A_TILE + B_TILE;
+    constexpr int QA = PBM / 32, QB = BN / 32;      // DMA instructions per wave per K tile for the A / B tile
     constexpr int QMAX = QA > QB ? QA : QB;
-    constexpr int A_PITCH = PBM * 2, B_PITCH = BN * 2;              // TR form: bytes per reduction row
+    constexpr int A_PITCH = PBM * 4, B_PITCH = BN * 4;              // TR form: bytes per reduction row (hi and lo)
 
     extern __shared__ __attribute__((aligned(16))) char smemp[];
 
@@ -132,37 +137,35 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;
 
-    // ---- DMA plan of this wave: plane (wave>>1), half (wave&1) of its tile ------------------------------------
-    const int plane = wave >> 1;                 // 0: A hi, 1: A lo, 2: B hi, 3: B lo
-    const bool isB = plane >= 2;
+    // ---- DMA plan of this wave -----------------------------------------------------------------------------------
+    const bool isB = wave >= 4;                  // waves 0-3 stage the A tile, waves 4-7 the B tile
+    const int quarter = wave & 3;                // ... one quarter of it each
     const int nq = isB ? QB : QA;                // instructions per K tile
-    const int lds_plane_off = isB ? (2 * A_PLANE + (plane - 2) * B_PLANE) : plane * A_PLANE;
 #ifdef HOS_EXP_SAME_A      // timing experiment: every workgroup streams the SAME A panel (all L2 hits)
     const int g_row0 = isB ? j0 : 0;
 #else
     const int g_row0 = isB ? j0 : i0;            // first output row (k-contiguous) / first column (TR) of this side
 #endif
     const int g_limit = isB ? a.N : a.M;
-    // Source planes selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc build a pointer
+    // Source arrays selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc build a pointer
     // table in scratch; every scratch_load result was then waited for with vmcnt(0), which drained the LDS-DMA
     // queue before EACH global_load_lds and serialised the eight requests of a tile.)
     const uint16_t* P0; const uint16_t* P1; int ld0, ld1;
-    if (plane == 0)      { P0 = a.Ahi; P1 = a.A1hi; ld0 = a.lda; ld1 = a.lda1; }
-    else if (plane == 1) { P0 = a.Alo; P1 = a.A1lo; ld0 = a.lda; ld1 = a.lda1; }
-    else if (plane == 2) { P0 = a.Bhi; P1 = a.Bhi;  ld0 = a.ldb; ld1 = a.ldb; }
-    else                 { P0 = a.Blo; P1 = a.Blo;  ld0 = a.ldb; ld1 = a.ldb; }
+    if (!isB) { P0 = a.A; P1 = a.A1; ld0 = a.lda; ld1 = a.lda1; }
+    else      { P0 = a.B; P1 = a.B;  ld0 = a.ldb; ld1 = a.ldb; }
     const int kt0 = (isB || TR) ? 0x7fffffff : a.kt0;
-    const int plane_bytes = isB ? B_PLANE : A_PLANE;
-    char* const lds_wave = smemp + lds_plane_off + (wave & 1) * (plane_bytes / 2);
+    const int tile_bytes = isB ? B_TILE : A_TILE;
+    char* const lds_wave = smemp + (isB ? A_TILE : 0) + quarter * (tile_bytes / 4);
 
-    // k-contiguous form: instruction q covers rows 16q..16q+15 of this wave's half, lane -> (row, swizzled chunk)
-    const int kc_row = (wave & 1) * ((isB ? BN : PBM) / 2) + (lane >> 2);
-    const int kc_chunk = (lane & 3) ^ ((lane >> 4) & 3);
-    // TR form: instruction q covers 1 KB of this wave's 16 reduction rows; pitch = 2 * (columns of the tile)
+    // k-contiguous form: instruction q covers 8 rows x 128 B of this wave's quarter; lane -> (row, chunk position);
+    // the source chunk is position ^ swizzle(row), swizzle(row) = (row>>1)&7 = (lane>>4) | ((q&1)<<2)
+    const int kc_row = quarter * ((isB ? BN : PBM) / 4) + (lane >> 3);
+    const int kc_pos = lane & 7, kc_swz = (lane >> 4) & 3;
+    // TR form: instruction q covers 1 KB of this wave's 8 reduction rows; pitch = 4 * (columns of the tile)
     const int tr_pitch = isB ? B_PITCH : A_PITCH;
 
     auto issue_dma = [&](int q, int kt, int stage) {
-#ifdef HOS_EXP_SKIP_B_DMA      // timing experiment: only the A planes are staged (half the DMA bytes; results invalid)
+#ifdef HOS_EXP_SKIP_B_DMA      // timing experiment: only the A tile is staged (half the DMA bytes; results invalid)
         if (isB) return;
 #endif
 #ifdef HOS_EXP_SKIP_A_DMA
@@ -174,18 +177,20 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             const bool seg1 = kt >= kt0;                                 // A may switch to its second K segment
             P = seg1 ? P1 : P0;
             const int ld = seg1 ? ld1 : ld0;
-            const int k0 = (seg1 ? kt - kt0 : kt) * PBK;
-            int gr = g_row0 + kc_row + 16 * q;
+            const int kb = seg1 ? kt - kt0 : kt;                         // 32-column block of the row
+            int gr = g_row0 + kc_row + 8 * q;
             gr = gr < g_limit ? gr : g_limit - 1;                       // clamp: out-of-range rows are never stored
-            off = (unsigned)gr * (unsigned)ld + (unsigned)(k0 + kc_chunk * 8);
+            const int chunk = kc_pos ^ (kc_swz | ((q & 1) << 2));       // 0-3: hi k 0..31, 4-7: lo
+            off = (unsigned)gr * (unsigned)(2 * ld) + (unsigned)(kb * 64 + chunk * 8);
         } else {
             P = P0;
-            const int pos = q * 1024 + lane * 16;                       // byte position inside this wave's half plane
-            const int m = (wave & 1) * 16 + pos / tr_pitch;             // reduction row inside the K tile
-            const int bcol = (pos % tr_pitch) ^ ((m & 3) << 6);         // source byte column (swizzle on the source)
-            int gc = g_row0 + (bcol >> 1);
+            const int pos = q * 1024 + lane * 16;                       // byte position inside this wave's quarter
+            const int m = quarter * 8 + pos / tr_pitch;                 // reduction row inside the K tile
+            const int rb = pos % tr_pitch;                              // byte inside the LDS row
+            const int unit = (rb >> 6) ^ (m & 3);                       // source 64-byte unit (swizzle on the source)
+            int gc = g_row0 + (unit >> 1) * 32 + ((rb >> 4) & 3) * 8;   // logical column of this 16-byte piece
             gc = gc < ((g_limit + 7) & ~7) ? gc : 0;                    // clamp: columns past the operand are never stored
-            off = (unsigned)(kt * PBK + m) * (unsigned)ld0 + (unsigned)gc;
+            off = (unsigned)(kt * PBK + m) * (unsigned)(2 * ld0) + (unsigned)((gc >> 5) * 64 + (unit & 1) * 32 + (gc & 31));
         }
         dma16(P + off, lds_wave + stage * STAGE + q * 1024);             // LDS address is wave-uniform
     };
@@ -211,30 +216,37 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // s_waitcnt lgkmcnt(N), N = LDS reads issued after the ones the group needs (LDS returns in order), and the
     // fragments pass through that statement as "+v" operands so no MFMA can be scheduled above its wait
     // (cdna_hip_programming.md 5.7, form (ii)).
-    //   k-contiguous: lane (row = l31, k half = lhi) reads the 16-byte chunk (2s + lhi) ^ ((l31>>2)&3) of its row.
+    //   k-contiguous: lane (row = l31, k half = lhi) reads chunk (2s + lhi) [hi] / 4 + (2s + lhi) [lo] of its 128-byte
+    //       row, stored at chunk position c ^ ((row>>1)&7).
     //   TR: 16-lane group g = lane>>4 reads the [4 m][16 col] block (m0 = 16 s + 8 (g>>1) (+4), col0 = 16 (g&1));
     //       lane p of the group supplies the address of row m0 + (p>>2), columns col0 + 4 (p&3) .. +3 and receives
     //       column col0 + p of the four rows: two reads give the 8 consecutive reduction values of its MFMA row.
-    // Per-lane byte offsets inside stage 0; everything else of an address is an immediate or the stage offset.
+    //       A 32-column block is two 64-byte units (hi, lo), stored at unit position u ^ (m&3).
+    // Per-lane byte offsets inside stage 0 ([.][0] hi, [.][1] lo); the rest of an address is an immediate or the stage.
     constexpr int NOA = 2, NOB = TR ? TN : 2;
-    unsigned offA[NOA], offB[NOB];
+    unsigned offA[NOA][2], offB[NOB][2];
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smemp;
     if constexpr (!TR) {
-        const int swz = (l31 >> 2) & 3;
+        const int swz = (l31 >> 1) & 7;
 #pragma unroll
-        for (int sx = 0; sx < 2; ++sx) {
-            const int ch = (2 * sx + lhi) ^ swz;
-            offA[sx] = lds_base + (wm * (TM * 32) + l31) * PROWB + ch * 16;
-            offB[sx] = lds_base + 2 * A_PLANE + (wn * (TN * 32) + l31) * PROWB + ch * 16;
-        }
+        for (int sx = 0; sx < 2; ++sx)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                const int pos = (hl * 4 + 2 * sx + lhi) ^ swz;
+                offA[sx][hl] = lds_base + (wm * (TM * 32) + l31) * 128 + pos * 16;
+                offB[sx][hl] = lds_base + A_TILE + (wn * (TN * 32) + l31) * 128 + pos * 16;
+            }
     } else {
         const int tr_p = lane & 15, tr_g = lane >> 4;
         const int m_lane = 8 * (tr_g >> 1) + (tr_p >> 2), sw = tr_p >> 2;
         const int lcol = (16 * (tr_g & 1) + 4 * (tr_p & 3)) * 2;
 #pragma unroll
-        for (int x = 0; x < TM; ++x) offA[x] = lds_base + m_lane * A_PITCH + (((wm * TM + x) ^ sw) << 6) + lcol;
+        for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
-        for (int y = 0; y < TN; ++y) offB[y] = lds_base + 2 * A_PLANE + m_lane * B_PITCH + (((wn * TN + y) ^ sw) << 6) + lcol;
+            for (int x = 0; x < TM; ++x) offA[x][hl] = lds_base + m_lane * A_PITCH + ((((wm * TM + x) * 2 + hl) ^ sw) << 6) + lcol;
+#pragma unroll
+            for (int y = 0; y < TN; ++y) offB[y][hl] = lds_base + A_TILE + m_lane * B_PITCH + ((((wn * TN + y) * 2 + hl) ^ sw) << 6) + lcol;
+        }
     }
 #define HOS_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define HOS_RDTR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
@@ -246,13 +258,13 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #define HOS_READ_A1(SET_H, SET_L, STG, S, X)                                                                   \
     do {                                                                                                       \
         if constexpr (!TR) {                                                                                   \
-            HOS_RD128(SET_H[X].v, offA[S] + (STG), (X) * 32 * PROWB);                                          \
-            HOS_RD128(SET_L[X].v, offA[S] + (STG), A_PLANE + (X) * 32 * PROWB);                                \
+            HOS_RD128(SET_H[X].v, offA[S][0] + (STG), (X) * 32 * 128);                                         \
+            HOS_RD128(SET_L[X].v, offA[S][1] + (STG), (X) * 32 * 128);                                         \
         } else {                                                                                               \
-            HOS_RDTR(SET_H[X].h0, offA[X] + (STG), (S) * 16 * A_PITCH);                                        \
-            HOS_RDTR(SET_H[X].h1, offA[X] + (STG), (S) * 16 * A_PITCH + 4 * A_PITCH);                          \
-            HOS_RDTR(SET_L[X].h0, offA[X] + (STG), A_PLANE + (S) * 16 * A_PITCH);                              \
-            HOS_RDTR(SET_L[X].h1, offA[X] + (STG), A_PLANE + (S) * 16 * A_PITCH + 4 * A_PITCH);                \
+            HOS_RDTR(SET_H[X].h0, offA[X][0] + (STG), (S) * 16 * A_PITCH);                                     \
+            HOS_RDTR(SET_H[X].h1, offA[X][0] + (STG), (S) * 16 * A_PITCH + 4 * A_PITCH);                       \
+            HOS_RDTR(SET_L[X].h0, offA[X][1] + (STG), (S) * 16 * A_PITCH);                                     \
+            HOS_RDTR(SET_L[X].h1, offA[X][1] + (STG), (S) * 16 * A_PITCH + 4 * A_PITCH);                       \
         }                                                                                                      \
     } while (0)
 #define HOS_READ_A(SET_H, SET_L, STG, S) do { HOS_READ_A1(SET_H, SET_L, STG, S, 0); HOS_READ_A1(SET_H, SET_L, STG, S, 1); } while (0)
@@ -260,13 +272,13 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     do {                                                                                                       \
         if constexpr ((Y) < TH) {                                                                              \
             if constexpr (!TR) {                                                                               \
-                HOS_RD128(SET_H[Y].v, offB[S] + (STG), ((YH) * TH + (Y)) * 32 * PROWB);                        \
-                HOS_RD128(SET_L[Y].v, offB[S] + (STG), B_PLANE + ((YH) * TH + (Y)) * 32 * PROWB);              \
+                HOS_RD128(SET_H[Y].v, offB[S][0] + (STG), ((YH) * TH + (Y)) * 32 * 128);                       \
+                HOS_RD128(SET_L[Y].v, offB[S][1] + (STG), ((YH) * TH + (Y)) * 32 * 128);                       \
             } else {                                                                                           \
-                HOS_RDTR(SET_H[Y].h0, offB[((YH) * TH + (Y)) % NOB] + (STG), (S) * 16 * B_PITCH);              \
-                HOS_RDTR(SET_H[Y].h1, offB[((YH) * TH + (Y)) % NOB] + (STG), (S) * 16 * B_PITCH + 4 * B_PITCH); \
-                HOS_RDTR(SET_L[Y].h0, offB[((YH) * TH + (Y)) % NOB] + (STG), B_PLANE + (S) * 16 * B_PITCH);    \
-                HOS_RDTR(SET_L[Y].h1, offB[((YH) * TH + (Y)) % NOB] + (STG), B_PLANE + (S) * 16 * B_PITCH + 4 * B_PITCH); \
+                HOS_RDTR(SET_H[Y].h0, offB[((YH) * TH + (Y)) % NOB][0] + (STG), (S) * 16 * B_PITCH);           \
+                HOS_RDTR(SET_H[Y].h1, offB[((YH) * TH + (Y)) % NOB][0] + (STG), (S) * 16 * B_PITCH + 4 * B_PITCH); \
+                HOS_RDTR(SET_L[Y].h0, offB[((YH) * TH + (Y)) % NOB][1] + (STG), (S) * 16 * B_PITCH);           \
+                HOS_RDTR(SET_L[Y].h1, offB[((YH) * TH + (Y)) % NOB][1] + (STG), (S) * 16 * B_PITCH + 4 * B_PITCH); \
             }                                                                                                  \
         }                                                                                                      \
     } while (0)
@@ -470,12 +482,12 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         // Plane outputs.  Every wave owns 8 KB of the (now idle) stage memory.  Per (x, pair of y) = 32 rows x 64
         // columns: each lane packs (hi, lo) of its values into one dword and writes it at [row][col] (ds_write_b32,
         // 32 consecutive dwords per half wave: conflict free); after the wave's own writes have landed every lane
-        // reads 16 bytes = four consecutive columns of one row and stores 8 bytes to the hi plane and 8 to the lo
-        // plane -- 16 lanes per row, so each store instruction writes four whole 128-byte lines per plane.
+        // reads 16 bytes = four consecutive columns of one row and stores 8 bytes to the hi half and 8 to the lo half
+        // of the column block -- 16 lanes per row, so a hi/lo store pair writes four rows x two whole 128-byte lines.
         asm volatile("s_barrier" ::: "memory");                   // all waves are done with the stage memory
         char* const stg = smemp + wave * 8192;
-        const bool dual = (EPI == PEPI_PLANES_FWD) && a.Ybhi != nullptr;
-        const bool first = a.Yhi != nullptr;
+        const bool dual = (EPI == PEPI_PLANES_FWD) && a.Yb != nullptr;
+        const bool first = a.Y != nullptr;
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
@@ -504,8 +516,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    uint16_t* const Ph = fmt == 0 ? a.Yhi : a.Ybhi;
-                    uint16_t* const Pl = fmt == 0 ? a.Ylo : a.Yblo;
+                    uint16_t* const Po = fmt == 0 ? a.Y : a.Yb;
                     const int ldo = fmt == 0 ? a.ldy : a.ldyb;
 #pragma unroll
                     for (int pass = 0; pass < 8; ++pass) {
@@ -514,21 +525,21 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                         uint4 w = *reinterpret_cast<const uint4*>(stg + idx * 16);
                         const int row = row0 + rl, col = col0 + cg;
                         if constexpr (EPI == PEPI_PLANES_DGRAD) {
-                            if (a.mask_hi != nullptr && row < a.M && col < a.ldmask) {
-                                const uint2 mk = *reinterpret_cast<const uint2*>(a.mask_hi + (size_t)row * a.ldmask + col);
+                            if (a.mask != nullptr && row < a.M && col < a.ldmask) {
+                                const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + (size_t)row * (2 * a.ldmask) + (col >> 5) * 64 + (col & 31));
                                 const uint32_t m4[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
                                 uint32_t* wv = reinterpret_cast<uint32_t*>(&w);
 #pragma unroll
                                 for (int k = 0; k < 4; ++k)
-                                    if ((m4[k] & 0x8000u) || (m4[k] & 0x7fffu) == 0) wv[k] = 0u;      // fp16 hi plane: x > 0 ?
+                                    if ((m4[k] & 0x8000u) || (m4[k] & 0x7fffu) == 0) wv[k] = 0u;      // fp16 hi part: x > 0 ?
                             }
                         }
                         if (row < a.M && col < ldo) {
                             const uint2 hi2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), __builtin_amdgcn_perm(w.w, w.z, 0x05040100u));
                             const uint2 lo2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), __builtin_amdgcn_perm(w.w, w.z, 0x07060302u));
-                            const size_t o = (size_t)row * ldo + col;
-                            *reinterpret_cast<uint2*>(Ph + o) = hi2;
-                            *reinterpret_cast<uint2*>(Pl + o) = lo2;
+                            const size_t o = (size_t)row * (2 * ldo) + (col >> 5) * 64 + (col & 31);
+                            *reinterpret_cast<uint2*>(Po + o) = hi2;
+                            *reinterpret_cast<uint2*>(Po + o + 32) = lo2;
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging reads done before it is rewritten
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 
 template <int BN, int EPI, typename EIN, bool TR>
 int launchp(PArgs& a, int splits, hipStream_t stream) {
-    constexpr size_t smem = 2 * (2 * PBM * PROWB + 2 * BN * PROWB);
+    constexpr size_t smem = 2 * (PBM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmp_kernel<BN, EPI, EIN, TR>),
@@ -560,11 +571,14 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     return hos_launch_status();
 }
 
-// fp32 [R][ld] -> 16-bit hi/lo planes, row-major (padding columns [C, ldo) zeroed) and/or transposed [C][ldt]
+// element offset of (row r, column c) in an interleaved-planes array with `ld` logical columns: hi there, lo 32 further
+__device__ __forceinline__ size_t pl_off(int r, int c, int ld) { return (size_t)r * (2 * ld) + (c >> 5) * 64 + (c & 31); }
+
+// fp32 [R][lds] -> interleaved planes, row-major [R][ldo] (padding columns [C, ldo) zeroed) and/or transposed [C][ldt]
 template <typename E>
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int lds, int R, int C,
-                                                           uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, int ldo,
-                                                           uint16_t* __restrict__ hiT, uint16_t* __restrict__ loT, int ldt) {
+                                                           uint16_t* __restrict__ out, int ldo,
+                                                           uint16_t* __restrict__ outT, int ldt) {
     __shared__ float tile[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
@@ -573,14 +587,15 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         const int r = r0 + ty + 8 * k, c = c0 + tx;
         const float v = (r < R && c < C) ? src[(size_t)r * lds + c] : 0.f;
         tile[ty + 8 * k][tx] = v;
-        if (hi != nullptr && r < R && c < ldo) {
+        if (out != nullptr && r < R && c < ldo) {
             uint16_t h, l;
             split1<E>(v, h, l);
-            hi[(size_t)r * ldo + c] = h;
-            lo[(size_t)r * ldo + c] = l;
+            const size_t o = pl_off(r, c, ldo);
+            out[o] = h;
+            out[o + 32] = l;
         }
     }
-    if (hiT == nullptr) return;
+    if (outT == nullptr) return;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -588,16 +603,17 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         if (c < C && r < ldt) {
             uint16_t h, l;
             split1<E>(r < R ? tile[tx][ty + 8 * k] : 0.f, h, l);
-            hiT[(size_t)c * ldt + r] = h;
-            loT[(size_t)c * ldt + r] = l;
+            const size_t o = pl_off(c, r, ldt);
+            outT[o] = h;
+            outT[o + 32] = l;
         }
     }
 }
 
-// fp32 [R][ld] -> fp16 planes and bf16 planes in one pass (row-major, 4 elements per thread)
+// fp32 [R][lds] -> fp16 planes and/or bf16 planes in one pass (row-major, 4 elements per thread)
 __global__ __launch_bounds__(256) void split_planes2_kernel(const float* __restrict__ src, int lds, int R, int C,
-                                                            uint16_t* __restrict__ h16, uint16_t* __restrict__ l16, int ld16,
-                                                            uint16_t* __restrict__ hb, uint16_t* __restrict__ lb, int ldb) {
+                                                            uint16_t* __restrict__ p16, int ld16,
+                                                            uint16_t* __restrict__ pb, int ldb) {
     const int ldmax = ld16 > ldb ? ld16 : ldb;
     const int groups = ldmax >> 2;
     const size_t total = (size_t)R * groups;
@@ -606,19 +622,21 @@ __global__ __launch_bounds__(256) void split_planes2_kernel(const float* __restr
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = (c + k < C) ? src[(size_t)r * lds + c + k] : 0.f;
-        if (h16 != nullptr && c < ld16) {
+        if (p16 != nullptr && c < ld16) {
             uint32_t p[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) p[k] = split_pack<_Float16>(v[k]);
-            *reinterpret_cast<uint2*>(h16 + (size_t)r * ld16 + c) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
-            *reinterpret_cast<uint2*>(l16 + (size_t)r * ld16 + c) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
+            const size_t o = pl_off(r, c, ld16);
+            *reinterpret_cast<uint2*>(p16 + o) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
+            *reinterpret_cast<uint2*>(p16 + o + 32) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
         }
-        if (hb != nullptr && c < ldb) {
+        if (pb != nullptr && c < ldb) {
             uint32_t p[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) p[k] = split_pack<__bf16>(v[k]);
-            *reinterpret_cast<uint2*>(hb + (size_t)r * ldb + c) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
-            *reinterpret_cast<uint2*>(lb + (size_t)r * ldb + c) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
+            const size_t o = pl_off(r, c, ldb);
+            *reinterpret_cast<uint2*>(pb + o) = make_uint2((p[0] & 0xffffu) | (p[1] << 16), (p[2] & 0xffffu) | (p[3] << 16));
+            *reinterpret_cast<uint2*>(pb + o + 32) = make_uint2((p[0] >> 16) | (p[1] & 0xffff0000u), (p[2] >> 16) | (p[3] & 0xffff0000u));
         }
     }
 }
@@ -660,55 +678,52 @@ inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u)
 
 }  // namespace
 
-extern "C" int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* hi, void* lo, int ldo,
-                                void* hiT, void* loT, int ldt, hos_stream_t stream) {
-    if (!src || R <= 0 || C <= 0 || (!hi && !hiT)) return HOS_E_ARG;
-    if ((hi && !lo) || (hiT && !loT)) return HOS_E_ARG;
-    const int cols = hi ? (ldo > C ? ldo : C) : C;
-    dim3 grid(hos_cdiv(cols, 32), hos_cdiv(hiT ? (ldt > R ? ldt : R) : R, 32));
+extern "C" int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* out, int ldo,
+                                void* outT, int ldt, hos_stream_t stream) {
+    if (!src || R <= 0 || C <= 0 || (!out && !outT)) return HOS_E_ARG;
+    if ((out && (ldo & 31)) || (outT && (ldt & 31))) return HOS_E_ALIGN;
+    const int cols = out ? (ldo > C ? ldo : C) : C;
+    dim3 grid(hos_cdiv(cols, 32), hos_cdiv(outT ? (ldt > R ? ldt : R) : R, 32));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == 0)
-        hipLaunchKernelGGL(split_planes_kernel<_Float16>, grid, dim3(256), 0, s, src, lds, R, C, (uint16_t*)hi, (uint16_t*)lo, ldo,
-                           (uint16_t*)hiT, (uint16_t*)loT, ldt);
+        hipLaunchKernelGGL(split_planes_kernel<_Float16>, grid, dim3(256), 0, s, src, lds, R, C, (uint16_t*)out, ldo, (uint16_t*)outT, ldt);
     else
-        hipLaunchKernelGGL(split_planes_kernel<__bf16>, grid, dim3(256), 0, s, src, lds, R, C, (uint16_t*)hi, (uint16_t*)lo, ldo,
-                           (uint16_t*)hiT, (uint16_t*)loT, ldt);
+        hipLaunchKernelGGL(split_planes_kernel<__bf16>, grid, dim3(256), 0, s, src, lds, R, C, (uint16_t*)out, ldo, (uint16_t*)outT, ldt);
     return hos_launch_status();
 }
 
-extern "C" int hos_split_planes2(const float* src, int lds, int R, int C, void* h16, void* l16, int ld16,
-                                 void* hb, void* lb, int ldb, hos_stream_t stream) {
-    if (!src || R <= 0 || C <= 0 || (!h16 && !hb)) return HOS_E_ARG;
-    if ((h16 && (!l16 || (ld16 & 3))) || (hb && (!lb || (ldb & 3)))) return HOS_E_ARG;
-    const int ldmax = (h16 ? ld16 : 0) > (hb ? ldb : 0) ? ld16 : ldb;
+extern "C" int hos_split_planes2(const float* src, int lds, int R, int C, void* p16, int ld16, void* pb, int ldb,
+                                 hos_stream_t stream) {
+    if (!src || R <= 0 || C <= 0 || (!p16 && !pb)) return HOS_E_ARG;
+    if ((p16 && (ld16 & 31)) || (pb && (ldb & 31))) return HOS_E_ALIGN;
+    const int ldmax = (p16 ? ld16 : 0) > (pb ? ldb : 0) ? ld16 : ldb;
     const size_t total = (size_t)R * (ldmax >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(split_planes2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, R, C,
-                       (uint16_t*)h16, (uint16_t*)l16, h16 ? ld16 : 0, (uint16_t*)hb, (uint16_t*)lb, hb ? ldb : 0);
+                       (uint16_t*)p16, p16 ? ld16 : 0, (uint16_t*)pb, pb ? ldb : 0);
     return hos_launch_status();
 }
 
-extern "C" int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0, const void* A1hi, const void* A1lo,
-                               int lda1, int K1, const void* Whi, const void* Wlo, int ldw, const float* bias,
-                               int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* Ybhi, void* Yblo, int ldyb,
+extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                               const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb,
                                float* C, int ldc, int epilogue, float* aux, int aux_col, float p0,
                                hos_stream_t stream) {
-    if (!Ahi || !Alo || !Whi || !Wlo || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
-    if (K1 > 0 && (!A1hi || !A1lo)) return HOS_E_ARG;
+    if (!A || !W || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
+    if (K1 > 0 && !A1) return HOS_E_ARG;
     if ((K0 % PBK) || (K1 % PBK)) return HOS_E_SHAPE;
-    if ((lda & 7) || (ldw & 7) || (K1 > 0 && (lda1 & 7))) return HOS_E_ALIGN;
-    if (!al16p(Ahi) || !al16p(Alo) || !al16p(Whi) || !al16p(Wlo)) return HOS_E_ALIGN;
-    const bool planes_out = (Yhi != nullptr) || (Ybhi != nullptr);
-    if (planes_out && ((Yhi && (!Ylo || (ldy & 3))) || (Ybhi && (!Yblo || (ldyb & 3))))) return HOS_E_ARG;
+    if ((lda & 31) || (ldw & 31) || (K1 > 0 && (lda1 & 31))) return HOS_E_ALIGN;
+    if (!al16p(A) || !al16p(W) || (K1 > 0 && !al16p(A1))) return HOS_E_ALIGN;
+    const bool planes_out = (Y != nullptr) || (Yb != nullptr);
+    if (planes_out && ((Y && (ldy & 31)) || (Yb && (ldyb & 31)))) return HOS_E_ALIGN;
     if (!planes_out && !C && epilogue != HOS_EPI_DENSITY) return HOS_E_ARG;
     PArgs a{};
-    a.Ahi = (const uint16_t*)Ahi; a.Alo = (const uint16_t*)Alo; a.lda = lda; a.kt0 = K0 / PBK;
-    a.A1hi = (const uint16_t*)A1hi; a.A1lo = (const uint16_t*)A1lo; a.lda1 = lda1;
-    a.Bhi = (const uint16_t*)Whi; a.Blo = (const uint16_t*)Wlo; a.ldb = ldw;
+    a.A = (const uint16_t*)A; a.lda = lda; a.kt0 = K0 / PBK;
+    a.A1 = (const uint16_t*)A1; a.lda1 = lda1;
+    a.B = (const uint16_t*)W; a.ldb = ldw;
     a.M = M; a.N = N; a.nk = (K0 + K1) / PBK;
     a.bias = bias; a.relu = relu;
-    a.Yhi = (uint16_t*)Yhi; a.Ylo = (uint16_t*)Ylo; a.ldy = ldy; a.Ybhi = (uint16_t*)Ybhi; a.Yblo = (uint16_t*)Yblo; a.ldyb = ldyb;
+    a.Y = (uint16_t*)Y; a.ldy = ldy; a.Yb = (uint16_t*)Yb; a.ldyb = ldyb;
     a.f32.C = C; a.f32.ldc = ldc; a.f32.M = M; a.f32.N = N; a.f32.bias = bias; a.f32.aux = aux; a.f32.aux_col = aux_col;
     a.f32.p0 = p0; a.f32.epi = epilogue;
     if (epilogue == HOS_EPI_RESIDUAL) { a.f32.mask = aux; a.f32.ldmask = aux_col; }
@@ -718,33 +733,31 @@ extern "C" int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0
     return wide ? launchp<256, PEPI_F32, _Float16, false>(a, 1, s) : launchp<128, PEPI_F32, _Float16, false>(a, 1, s);
 }
 
-extern "C" int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, const void* WThi, const void* WTlo,
-                                 int ldwt, int Npad, const void* mask_hi, int ldmask, int M, int K,
-                                 void* dXhi, void* dXlo, int lddx, hos_stream_t stream) {
-    if (!dZhi || !dZlo || !WThi || !WTlo || !dXhi || !dXlo || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
+extern "C" int hos_linearp_dgrad(const void* dZ, int lddz, const void* WT, int ldwt, int Npad, const void* mask, int ldmask,
+                                 int M, int K, void* dX, int lddx, hos_stream_t stream) {
+    if (!dZ || !WT || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
     if (Npad % PBK) return HOS_E_SHAPE;
-    if ((lddz & 7) || (ldwt & 7) || (lddx & 3) || (mask_hi && (ldmask & 3))) return HOS_E_ALIGN;
-    if (!al16p(dZhi) || !al16p(dZlo) || !al16p(WThi) || !al16p(WTlo)) return HOS_E_ALIGN;
+    if ((lddz & 31) || (ldwt & 31) || (lddx & 31) || (mask && (ldmask & 31))) return HOS_E_ALIGN;
+    if (!al16p(dZ) || !al16p(WT)) return HOS_E_ALIGN;
     PArgs a{};
-    a.Ahi = (const uint16_t*)dZhi; a.Alo = (const uint16_t*)dZlo; a.lda = lddz; a.kt0 = Npad / PBK;
-    a.Bhi = (const uint16_t*)WThi; a.Blo = (const uint16_t*)WTlo; a.ldb = ldwt;
+    a.A = (const uint16_t*)dZ; a.lda = lddz; a.kt0 = Npad / PBK;
+    a.B = (const uint16_t*)WT; a.ldb = ldwt;
     a.M = M; a.N = K; a.nk = Npad / PBK;
-    a.mask_hi = (const uint16_t*)mask_hi; a.ldmask = ldmask;
-    a.Yhi = (uint16_t*)dXhi; a.Ylo = (uint16_t*)dXlo; a.ldy = lddx;
+    a.mask = (const uint16_t*)mask; a.ldmask = ldmask;
+    a.Y = (uint16_t*)dX; a.ldy = lddx;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return K > 128 ? launchp<256, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s) : launchp<128, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s);
 }
 
-extern "C" int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
-                                 int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits,
-                                 float* ws, long long ws_floats, hos_stream_t stream) {
-    if (!dZhi || !dZlo || !Xhi || !Xlo || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+extern "C" int hos_linearp_wgrad(const void* dZ, int lddz, const void* X, int ldx, int x_col0, float* dW, int ldw, float* db,
+                                 int M, int N, int K, int splits, float* ws, long long ws_floats, hos_stream_t stream) {
+    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || x_col0 < 0) return HOS_E_ARG;
     if (M % PBK) return HOS_E_SHAPE;
-    if ((lddz & 7) || (ldx & 7)) return HOS_E_ALIGN;
-    if (!al16p(dZhi) || !al16p(dZlo) || !al16p(Xhi) || !al16p(Xlo)) return HOS_E_ALIGN;
+    if ((lddz & 31) || (ldx & 31) || (x_col0 & 31)) return HOS_E_ALIGN;
+    if (!al16p(dZ) || !al16p(X)) return HOS_E_ALIGN;
     PArgs a{};
-    a.Ahi = (const uint16_t*)dZhi; a.Alo = (const uint16_t*)dZlo; a.lda = lddz; a.kt0 = M / PBK;
-    a.Bhi = (const uint16_t*)Xhi; a.Blo = (const uint16_t*)Xlo; a.ldb = ldx;
+    a.A = (const uint16_t*)dZ; a.lda = lddz; a.kt0 = M / PBK;
+    a.B = (const uint16_t*)X + 2 * x_col0; a.ldb = ldx;          // column block x_col0/32 of every row
     a.M = N; a.N = K; a.nk = M / PBK;
     a.f32.C = dW; a.f32.ldc = ldw; a.f32.M = N; a.f32.N = K; a.f32.db = db;
     // 256 x 128 tiles up to K = 256: a [256,256] gradient then has two tiles x 128 splits instead of one x 256 --

@@ -338,10 +338,10 @@ class MipNeRF360MLP(FlatModule):
         hi = max(L.W.offset + L.W.numel for L in specs)
         span = st.param[lo:hi].view(1, -1)
         w16, _ = ops.split_planes2(span, ld=hi - lo, wantb=False)
+        flat16 = w16.t.view(-1)
 
         def view16(L):
-            o = L.W.offset - lo
-            return ops.Planes(w16.t[:, 0, o:o + L.W.numel].view(2, L.Npad, L.Kpad), L.Npad, L.Kpad)
+            return ops.Planes.from_flat(flat16, L.W.offset - lo, L.Npad, L.Kpad)
 
         W16 = [view16(L) for L in specs]
         WT = None

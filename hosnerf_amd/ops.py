@@ -512,41 +512,50 @@ def adam_step_dyn(p, g, m, v, hyper, beta1, beta2, eps, grad_scale=1.0, sumsq_bu
 
 # ------------------------------------------------------------------------------------------ planes GEMMs
 class Planes:
-    """A matrix stored as two 16-bit planes (hi, lo) in one [2, R, ld] tensor; value = hi + lo.
-    dtype torch.float16 for forward operands, torch.bfloat16 for gradient-side operands."""
+    """A matrix [rows, ld] stored as interleaved 16-bit planes: one [rows, ld/32, 2, 32] tensor -- per row and
+    32-column block the 32 hi values then the 32 lo values (value = hi + lo).  dtype torch.float16 for forward
+    operands, torch.bfloat16 for gradient-side operands.  `ld` is the logical (padded) column count, % 32 == 0."""
 
     __slots__ = ("t", "rows", "cols")
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int):
+        assert t.dim() == 4 and t.shape[2] == 2 and t.shape[3] == 32
         self.t, self.rows, self.cols = t, rows, cols
 
     @staticmethod
     def empty(rows: int, ld: int, dtype, device, cols: Optional[int] = None):
-        return Planes(torch.empty(2, rows, ld, dtype=dtype, device=device), rows, ld if cols is None else cols)
+        assert ld % 32 == 0, "planes need a leading dimension that is a multiple of 32"
+        return Planes(torch.empty(rows, ld // 32, 2, 32, dtype=dtype, device=device), rows, ld if cols is None else cols)
+
+    @staticmethod
+    def from_flat(flat16: torch.Tensor, offset: int, rows: int, ld: int, cols: Optional[int] = None):
+        """View of `rows x ld` elements starting at logical element `offset` (% 32 == 0) of a flat planes buffer."""
+        return Planes(flat16[2 * offset:2 * (offset + rows * ld)].view(rows, ld // 32, 2, 32), rows, ld if cols is None else cols)
 
     @property
     def hi(self):
-        return self.t[0]
+        return self.t[:, :, 0, :].reshape(self.rows, -1)
 
     @property
     def lo(self):
-        return self.t[1]
+        return self.t[:, :, 1, :].reshape(self.rows, -1)
 
     @property
     def ld(self) -> int:
-        return self.t.shape[2]
+        return self.t.shape[1] * 32
 
     def float(self) -> torch.Tensor:
-        return (self.t[0].float() + self.t[1].float())[:, :self.cols]
+        return (self.t[:, :, 0, :].float() + self.t[:, :, 1, :].float()).reshape(self.rows, -1)[:, :self.cols]
 
 
 def _pp(x):
-    """device pointer of a plane (contiguous 2-D 16-bit tensor) or 0."""
+    """device pointer of a Planes object (contiguous 16-bit HIP tensor) or 0."""
     if x is None:
         return 0
-    if not (x.is_cuda and x.is_contiguous() and x.element_size() == 2):
-        raise _lib.HosLibraryError("expected a contiguous 16-bit HIP tensor plane")
-    return x.data_ptr()
+    t = x.t if isinstance(x, Planes) else x
+    if not (t.is_cuda and t.is_contiguous() and t.element_size() == 2):
+        raise _lib.HosLibraryError("expected a contiguous 16-bit HIP planes tensor")
+    return t.data_ptr()
 
 
 def split_planes(src: torch.Tensor, C: Optional[int] = None, dtype=torch.float16, ldo: Optional[int] = None,
@@ -563,8 +572,7 @@ def split_planes(src: torch.Tensor, C: Optional[int] = None, dtype=torch.float16
         ldt = round_up(R, 32) if ldt is None else ldt
         outT = Planes.empty(C, ldt, dtype, dev, R)
     call("hos_split_planes", ptr(src), src.stride(0), R, C, 0 if dtype == torch.float16 else 1,
-         _pp(None if out is None else out.hi), _pp(None if out is None else out.lo), 0 if out is None else out.ld,
-         _pp(None if outT is None else outT.hi), _pp(None if outT is None else outT.lo), 0 if outT is None else outT.ld)
+         _pp(out), 0 if out is None else out.ld, _pp(outT), 0 if outT is None else outT.ld)
     return out, outT
 
 
@@ -575,9 +583,7 @@ def split_planes2(src: torch.Tensor, C: Optional[int] = None, ld: Optional[int] 
     ld = round_up(C, 32) if ld is None else ld
     p16 = Planes.empty(R, ld, torch.float16, src.device, C) if want16 else None
     pb = Planes.empty(R, ld, torch.bfloat16, src.device, C) if wantb else None
-    call("hos_split_planes2", ptr(src), src.stride(0), R, C,
-         _pp(None if p16 is None else p16.hi), _pp(None if p16 is None else p16.lo), ld,
-         _pp(None if pb is None else pb.hi), _pp(None if pb is None else pb.lo), ld)
+    call("hos_split_planes2", ptr(src), src.stride(0), R, C, _pp(p16), ld, _pp(pb), ld)
     return p16, pb
 
 
@@ -588,10 +594,8 @@ def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool 
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
     _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
-        "hos_linearp_fwd", _pp(A.hi), _pp(A.lo), A.ld, K0, _pp(None if A1 is None else A1.hi), _pp(None if A1 is None else A1.lo),
-        0 if A1 is None else A1.ld, K1, _pp(W.hi), _pp(W.lo), W.ld, ptr(bias), M, N, int(relu),
-        _pp(None if Y is None else Y.hi), _pp(None if Y is None else Y.lo), 0 if Y is None else Y.ld,
-        _pp(None if Yb is None else Yb.hi), _pp(None if Yb is None else Yb.lo), 0 if Yb is None else Yb.ld,
+        "hos_linearp_fwd", _pp(A), A.ld, K0, _pp(A1), 0 if A1 is None else A1.ld, K1, _pp(W), W.ld, ptr(bias), M, N, int(relu),
+        _pp(Y), 0 if Y is None else Y.ld, _pp(Yb), 0 if Yb is None else Yb.ld,
         ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
 
 
@@ -599,9 +603,8 @@ def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optio
                   dX: Optional[Planes] = None):
     """dX (bf16 planes [M][ld]) = (dZ @ WT^T) masked by mask.hi > 0; WT = transposed weight planes [K][Npad]."""
     _timed(f"gemmp_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
-        "hos_linearp_dgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(WT.hi), _pp(WT.lo), WT.ld, Npad,
-        _pp(None if mask is None else mask.hi), 0 if mask is None else mask.ld, M, K,
-        _pp(dX.hi), _pp(dX.lo), dX.ld))
+        "hos_linearp_dgrad", _pp(dZ), dZ.ld, _pp(WT), WT.ld, Npad, _pp(mask), 0 if mask is None else mask.ld, M, K,
+        _pp(dX), dX.ld))
 
 
 _wgrad_ws = {}          # device index -> fp32 scratch for the split-K slabs of hos_linearp_wgrad
@@ -623,5 +626,5 @@ def linearp_wgrad(dZ: Planes, X: Planes, dW: torch.Tensor, db, M: int, N: int, K
     time-neutral at 1024x1024, slower for the 256-wide proposal MLPs) instead of fp32 atomics."""
     ws = _wgrad_workspace(dW.device) if use_ws else None
     _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
-        "hos_linearp_wgrad", _pp(dZ.hi), _pp(dZ.lo), dZ.ld, _pp(X.hi) + 2 * x_col0, _pp(X.lo) + 2 * x_col0, X.ld,
+        "hos_linearp_wgrad", _pp(dZ), dZ.ld, _pp(X), X.ld, x_col0,
         ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits, ptr(ws), 0 if ws is None else ws.numel()))

@@ -86,44 +86,43 @@ int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* 
                      float* db, int M, int N, int K, int splits, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo planes
- * (element (r,c) = hi[r*ld+c] + lo[r*ld+c]; fp16 planes on the forward side, bf16 planes for gradients),
- * staged by LDS-DMA, 3 MFMAs per product.  The producer of a tensor does the split once; the trunk of the
- * MLPs (M:299-303 forward, its autograd backward) then runs without any conversion work in the K loop.
- * All leading dimensions are in elements and multiples of 8; reduction extents multiples of 32.
+ * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward
+ * side, bf16 for gradients), staged by LDS-DMA, 3 MFMAs per product.  The producer of a tensor does the split once;
+ * the trunk of the MLPs (M:299-303 forward, its autograd backward) then runs without conversion work in the K loop.
+ * Storage ("interleaved planes"): a matrix [R][ld], ld % 32 == 0, is ONE 16-bit array [R][ld/32][2][32] -- per row
+ * and 32-column block the 32 hi values, then the 32 lo values (128 bytes); element (r,c) = hi + lo with
+ * hi at r*2*ld + (c/32)*64 + c%32 and lo 32 elements further.  All `ld` arguments are logical column counts.
  * ------------------------------------------------------------------------------------------ */
 
-/* fp32 [R][lds] -> planes.  dtype 0 = fp16, 1 = bf16.  Row-major planes hi/lo [R][ldo] (columns [C,ldo) zeroed)
- * and/or transposed planes hiT/loT [C][ldt] (columns [R,ldt) zeroed); either pair may be NULL. */
-int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* hi, void* lo, int ldo,
-                     void* hiT, void* loT, int ldt, hos_stream_t stream);
+/* fp32 [R][lds] -> planes.  dtype 0 = fp16, 1 = bf16.  Row-major planes out [R][ldo] (columns [C,ldo) zeroed)
+ * and/or transposed planes outT [C][ldt] (columns [R,ldt) zeroed); either may be NULL. */
+int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* out, int ldo,
+                     void* outT, int ldt, hos_stream_t stream);
 
 /* fp32 [R][lds] -> fp16 planes [R][ld16] and/or bf16 planes [R][ldb] in one pass (padding columns zeroed). */
-int hos_split_planes2(const float* src, int lds, int R, int C, void* h16, void* l16, int ld16,
-                      void* hb, void* lb, int ldb, hos_stream_t stream);
+int hos_split_planes2(const float* src, int lds, int R, int C, void* p16, int ld16, void* pb, int ldb,
+                      hos_stream_t stream);
 
 /* Forward: acc[M,N] = [A | A1][M,K0+K1] @ W[N,K0+K1]^T (fp16 planes) + bias.
- *  - plane outputs (Yhi != NULL and/or Ybhi != NULL): Y = relu?(acc) as row-major fp16 planes [M][ldy] (input of
- *    the next layer) and/or as row-major bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed;
+ *  - plane outputs (Y != NULL and/or Yb != NULL): relu?(acc) as fp16 planes [M][ldy] (input of the next layer)
+ *    and/or as bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed;
  *  - otherwise the fp32 epilogues of hos_linear_fwd (C/ldc/epilogue/aux/aux_col/p0). */
-int hos_linearp_fwd(const void* Ahi, const void* Alo, int lda, int K0, const void* A1hi, const void* A1lo,
-                    int lda1, int K1, const void* Whi, const void* Wlo, int ldw, const float* bias,
-                    int M, int N, int relu, void* Yhi, void* Ylo, int ldy, void* Ybhi, void* Yblo, int ldyb,
+int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                    const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb,
                     float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream);
 
-/* Data gradient: dX[M,K] = dZ[M,Npad] @ Wt[K,Npad]^T (bf16 planes; Wt = transposed weight planes), masked by the
- * fp16 hi plane of the layer input (x > 0) if mask_hi != NULL; written as row-major bf16 planes [M][lddx]. */
-int hos_linearp_dgrad(const void* dZhi, const void* dZlo, int lddz, const void* WThi, const void* WTlo,
-                      int ldwt, int Npad, const void* mask_hi, int ldmask, int M, int K,
-                      void* dXhi, void* dXlo, int lddx, hos_stream_t stream);
+/* Data gradient: dX[M,K] = dZ[M,Npad] @ WT[K,Npad]^T (bf16 planes; WT = transposed weight planes), masked by the
+ * fp16 planes of the layer input (hi > 0) if mask != NULL; written as bf16 planes [M][lddx]. */
+int hos_linearp_dgrad(const void* dZ, int lddz, const void* WT, int ldwt, int Npad, const void* mask, int ldmask,
+                      int M, int K, void* dX, int lddx, hos_stream_t stream);
 
-/* Weight gradient: dW[N,K] += dZ[M,N]^T @ X[M,K] (both ROW-MAJOR bf16 planes; the reduction-contiguous MFMA
- * fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ.  M % 32 == 0.
- * The split-K partial tiles are written to `ws` (>= splits * N * round4(K) floats, caller-owned scratch, may be
- * NULL) and summed by a second launch; without a workspace they are accumulated with fp32 atomics. */
-int hos_linearp_wgrad(const void* dZhi, const void* dZlo, int lddz, const void* Xhi, const void* Xlo,
-                      int ldx, float* dW, int ldw, float* db, int M, int N, int K, int splits,
-                      float* ws, long long ws_floats, hos_stream_t stream);
+/* Weight gradient: dW[N,K] += dZ[M,N]^T @ X[M, x_col0 : x_col0+K] (both ROW-MAJOR bf16 planes; the
+ * reduction-contiguous MFMA fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ.
+ * M % 32 == 0, x_col0 % 32 == 0.  The split-K partial tiles are written to `ws` (>= splits * N * round4(K) floats,
+ * caller-owned scratch, may be NULL) and summed by a second launch; without a workspace they are accumulated with
+ * fp32 atomics. */
+int hos_linearp_wgrad(const void* dZ, int lddz, const void* X, int ldx, int x_col0, float* dW, int ldw, float* db,
+                      int M, int N, int K, int splits, float* ws, long long ws_floats, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).

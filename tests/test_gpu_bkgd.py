@@ -472,7 +472,8 @@ def test_planes_gemm_matches_fp64(M, N, K):
     ref = torch.relu(X.double() @ W.double().T + b.double())
     assert (Y.float().double() - ref).abs().max().item() < 2e-5
     assert (Yb.float().double() - ref).abs().max().item() < 2e-4           # bf16 hi/lo planes: 2^-17 relative
-    assert Y.t[:, :, N:].abs().max().item() == 0 if Npad > N else True      # padding columns zeroed
+    if Npad > N:                                                            # padding columns zeroed
+        assert Y.hi[:, N:].abs().max().item() == 0 and Y.lo[:, N:].abs().max().item() == 0
     C = torch.empty(M, N, device=dev)
     ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU)
     assert (C.double() - ref).abs().max().item() < 2e-5
