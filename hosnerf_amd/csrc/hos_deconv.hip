@@ -1,0 +1,94 @@
+// ConvTranspose3d(kernel 4, stride 2, padding 1) of the motion-weight volume decoder (U:21-59, `ConvDecoder3D`;
+// deconv_vol_decoder.py:17-42) as GEMM + gather, channel-last activations.
+//
+//   forward   Ycol[M, Cout*64] = X[M, Cin] @ W[Cin, Cout*64]          (hos_linear_dgrad form, W = the reference's
+//                                                                      [Cin, Cout, 4,4,4] weight as it lies in memory)
+//             out[(2D)^3, Cout] = act( bias + sum over the 8 taps that reach an output voxel )   <- hos_deconv3d_col2im
+//   backward  dYcol[i, co*64+k] = dPre[o(i,k), co]                                              <- hos_deconv3d_im2col
+//             dX = dYcol @ W^T (hos_linear_fwd form),  dW += X^T @ dYcol (hos_linear_wgrad)
+//
+// Per dimension an output index o receives input i through tap k with o = 2 i - 1 + k: o odd -> (k=0, i=(o+1)/2),
+// (k=2, i=(o-1)/2); o even -> (k=1, i=o/2), (k=3, i=o/2-1).  The decoder is 28 GFLOP per training step and its five
+// weight tensors are 253 MB: the GEMMs are weight-streaming (M = 1, 8, 64, 512, 4096 rows), these two kernels move
+// < 60 MB.  MIOpen spent 25-45 ms per step on the same layers (batch 1, 1^3..16^3 inputs).
+#include "hos_common.h"
+
+namespace {
+
+__device__ __forceinline__ void taps(int o, int D, int (&i)[2], int (&k)[2]) {
+    if (o & 1) { k[0] = 0; i[0] = (o + 1) >> 1; k[1] = 2; i[1] = (o - 1) >> 1; }
+    else       { k[0] = 1; i[0] = o >> 1;       k[1] = 3; i[1] = (o >> 1) - 1; }
+    if (i[0] >= D) i[0] = -1;
+    if (i[1] < 0) i[1] = -1;
+}
+
+__global__ __launch_bounds__(256) void deconv3d_col2im_kernel(const float* __restrict__ ycol, const float* __restrict__ bias,
+                                                              int D, int Cout, float slope, int leaky, float* __restrict__ out) {
+    const int O = 2 * D;
+    const long total = (long)O * O * O * Cout;
+    const int ldy = Cout * 64;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(t % Cout);
+        long o = t / Cout;
+        const int ox = (int)(o % O); o /= O;
+        const int oy = (int)(o % O);
+        const int oz = (int)(o / O);
+        int iz[2], kz[2], iy[2], ky[2], ix[2], kx[2];
+        taps(oz, D, iz, kz); taps(oy, D, iy, ky); taps(ox, D, ix, kx);
+        float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (iz[a] < 0 || iy[b] < 0 || ix[c] < 0) continue;
+                    const long m = ((long)iz[a] * D + iy[b]) * D + ix[c];
+                    acc += ycol[m * ldy + co * 64 + kz[a] * 16 + ky[b] * 4 + kx[c]];
+                }
+        if (leaky && acc < 0.f) acc *= slope;
+        out[t] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void deconv3d_im2col_kernel(const float* __restrict__ dpre, int D, int Cout,
+                                                              float* __restrict__ dycol) {
+    const int O = 2 * D;
+    const long total = (long)D * D * D * Cout * 64;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(t & 63);
+        long r = t >> 6;
+        const int co = (int)(r % Cout);
+        long m = r / Cout;
+        const int ix = (int)(m % D); m /= D;
+        const int iy = (int)(m % D);
+        const int iz = (int)(m / D);
+        const int oz = 2 * iz - 1 + (k >> 4), oy = 2 * iy - 1 + ((k >> 2) & 3), ox = 2 * ix - 1 + (k & 3);
+        float v = 0.f;
+        if (oz >= 0 && oz < O && oy >= 0 && oy < O && ox >= 0 && ox < O)
+            v = dpre[(((long)oz * O + oy) * O + ox) * Cout + co];
+        dycol[t] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, int Cout, float leaky_slope, int leaky,
+                                   float* out, hos_stream_t stream) {
+    if (!ycol || !out || D <= 0 || Cout <= 0) return HOS_E_ARG;
+    const long total = 8L * D * D * D * Cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(deconv3d_col2im_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), ycol, bias, D, Cout,
+                       leaky_slope, leaky, out);
+    return hos_launch_status();
+}
+
+extern "C" int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream) {
+    if (!dpre || !dycol || D <= 0 || Cout <= 0) return HOS_E_ARG;
+    const long total = (long)D * D * D * Cout * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(deconv3d_im2col_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dpre, D, Cout, dycol);
+    return hos_launch_status();
+}

@@ -296,13 +296,14 @@ class Network(FlatModule):
         P = self._plain
         h = F.leaky_relu(F.linear(P["mweight_vol_decoder.const_embedding"][None],
                                   P["mweight_vol_decoder.decoder.block_mlp.0.weight"],
-                                  P["mweight_vol_decoder.decoder.block_mlp.0.bias"]), 0.2).view(-1, 1024, 1, 1, 1)
+                                  P["mweight_vol_decoder.decoder.block_mlp.0.bias"]), 0.2)         # [1, 1024] = 1 voxel, channel-last
         n_conv = len(self._deconv_chans)
-        for n in range(n_conv):
-            h = F.conv_transpose3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
-                                   P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], stride=2, padding=1)
-            if n < n_conv - 1:
-                h = F.leaky_relu(h, 0.2)
+        D = 1
+        for n in range(n_conv):                  # ConvTranspose3d(4, 2, 1) as GEMM + gather, channel-last (hos_deconv.hip)
+            h = ops.deconv3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
+                             P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], D, n < n_conv - 1)
+            D *= 2
+        h = h.t().reshape(1, -1, D, D, D)        # [V^3, K+1] -> [1, K+1, V, V, V]
         return F.softmax(h + torch.log(priors[None]), dim=1)[0].contiguous()
 
     def _band_weights(self, iter_val: float, device) -> torch.Tensor:

@@ -123,6 +123,75 @@ def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Option
         ptr(db), M, N, K, splits))
 
 
+class gemm_mode:
+    """Context manager: run the enclosed GEMM launches in another arithmetic mode (the mode is read when a kernel is
+    launched, so this also works while a graph is being captured)."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_gemm_mode()
+        set_gemm_mode(self.mode)
+
+    def __exit__(self, *exc):
+        set_gemm_mode(self.prev)
+        return False
+
+
+# ------------------------------------------------------------------------------------------ ConvTranspose3d(4, 2, 1)
+class _Deconv3d(torch.autograd.Function):
+    """ConvTranspose3d(kernel 4, stride 2, padding 1), batch 1, channel-last activations, as
+    GEMM (exact fp32 MFMA) + gather (hos_deconv3d_*).  x [D^3, Cin], weight [Cin, Cout, 4,4,4] (the reference's
+    parameter layout), bias [Cout] -> [(2D)^3, Cout], optionally followed by LeakyReLU(0.2).
+    If `weight.grad` / `bias.grad` alias a flat gradient buffer the parameter gradients are accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, D, leaky):
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        M = D * D * D
+        x = x.contiguous()
+        Wm = weight.detach().view(Cin, Cout * 64)
+        ycol = torch.empty(M, Cout * 64, device=x.device)
+        with gemm_mode(GEMM_FP32):
+            linear_dgrad(x, Wm, Cin, Cout * 64, ycol)
+        out = torch.empty(8 * M, Cout, device=x.device)
+        call("hos_deconv3d_col2im", ptr(ycol), ptr(bias.detach()), D, Cout, 0.2, int(leaky), ptr(out))
+        ctx.save_for_backward(x, weight, bias, out)
+        ctx.D, ctx.leaky = D, leaky
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, out = ctx.saved_tensors
+        D, leaky = ctx.D, ctx.leaky
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        M = D * D * D
+        g = g.contiguous()
+        dpre = torch.where(out > 0, g, 0.2 * g) if leaky else g
+        dycol = torch.empty(M, Cout * 64, device=g.device)
+        call("hos_deconv3d_im2col", ptr(dpre), D, Cout, ptr(dycol))
+        Wm = weight.detach().view(Cin, Cout * 64)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # [M <= 4096, Cout*64 up to 32768] x [Cout*64, Cin]: a tiny output with a huge reduction -- needs split-K,
+            # which the forward-form tile kernel does not have (8 workgroups, 2.5 ms); plain library GEMM (rocBLAS)
+            dx = torch.matmul(dycol, Wm.t())
+        with gemm_mode(GEMM_FP32):
+            in_place = weight.grad is not None and weight.grad.is_contiguous()
+            gW = weight.grad.view(Cin, Cout * 64) if in_place else torch.zeros(Cin, Cout * 64, device=g.device)
+            linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)
+        db = dpre.sum(0)
+        if in_place and bias.grad is not None:
+            bias.grad += db
+            return dx, None, None, None, None
+        return dx, (None if in_place else gW.view_as(weight)), db, None, None
+
+
+def deconv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, D: int, leaky: bool) -> torch.Tensor:
+    return _Deconv3d.apply(x, weight, bias, D, leaky)
+
+
 # ------------------------------------------------------------------------------------------ rays
 _U_CACHE = {}
 

@@ -125,6 +125,19 @@ int hos_linearp_wgrad(const void* dZ, int lddz, const void* X, int ldx, int x_co
                       int M, int N, int K, int splits, float* ws, long long ws_floats, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ConvTranspose3d(kernel 4, stride 2, padding 1) of the motion-weight volume decoder (network_util.py:21-59,
+ * deconv_vol_decoder.py:17-42) = GEMM (hos_linear_*) + these two gathers; activations are channel-last [voxel][C].
+ * ------------------------------------------------------------------------------------------ */
+
+/* out[(2D)^3][Cout] = act(bias + taps of ycol[D^3][Cout*64]); act = LeakyReLU(leaky_slope) if leaky else identity. */
+int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, int Cout, float leaky_slope, int leaky,
+                        float* out, hos_stream_t stream);
+
+/* dycol[D^3][Cout*64] = gather of dpre[(2D)^3][Cout] (gradient w.r.t. the pre-activation output); zeros where a tap
+ * leaves the output volume. */
+int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).
  * ------------------------------------------------------------------------------------------ */
 

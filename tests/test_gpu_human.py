@@ -6,6 +6,7 @@ import tempfile
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -201,3 +202,31 @@ def test_gradients_vs_oracle(dev, net):
         assert cos > 0.999 and rel < 3e-2, (n, cos, rel)
     assert len(worst) >= 70, len(worst)      # every trainable tensor received a gradient
     net.zero_grad()
+
+
+@pytest.mark.parametrize("D,Cin,Cout,leaky", [(1, 1024, 512, True), (2, 512, 512, True), (4, 64, 96, True), (8, 32, 27, False)])
+def test_deconv3d_matches_torch(dev, D, Cin, Cout, leaky):
+    """hos_deconv3d_* + fp32 GEMMs vs F.conv_transpose3d(stride 2, padding 1) in fp64 (U:21-59): output, input
+    gradient, weight / bias gradients; channel-last in and out."""
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(D * 1000 + Cin)
+    x = torch.randn(D ** 3, Cin, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, 4, generator=g) / np.sqrt(Cin * 8)
+    b = torch.randn(Cout, generator=g) * 0.1
+    go = torch.randn(8 * D ** 3, Cout, generator=g)
+    # fp64 reference on the CPU
+    xr = x.double().t().reshape(1, Cin, D, D, D).requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, br, stride=2, padding=1)
+    if leaky:
+        yr = F.leaky_relu(yr, 0.2)
+    yr_cl = yr[0].reshape(Cout, -1).t()
+    (yr_cl * go.double()).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.deconv3d(xg, wg, bg, D, leaky)
+    (y * go.to(dev)).sum().backward()
+    assert maxerr(y, yr_cl) < 2e-5
+    assert maxerr(xg.grad, xr.grad[0].reshape(Cin, -1).t()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+    assert maxerr(wg.grad, wr.grad) < 2e-5 * max(1.0, float(wr.grad.abs().max()))
+    assert maxerr(bg.grad, br.grad) < 1e-4 * max(1.0, float(br.grad.abs().max()))
