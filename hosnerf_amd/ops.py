@@ -70,7 +70,7 @@ def _timed(key, flops, launch):
 
 # ------------------------------------------------------------------------------------------ GEMMs
 GEMM_FP32, GEMM_BF16X3, GEMM_PLANES = 0, 1, 2
-_planes_mode = False
+_planes_mode = True          # default: planes trunks + split GEMMs elsewhere (the library's own default is GEMM_BF16X3)
 
 
 def set_gemm_mode(mode: int):
