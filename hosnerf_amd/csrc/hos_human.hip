@@ -442,27 +442,52 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
             }
         }
     }
-    // pass 3: through the taps: g_vol and d w / d c
-    if (inside && live) {
+    // pass 3: through the taps: d w / d c per point; the volume gradient is scattered AFTERWARDS with lanes = channels:
+    // an fp32 atomic costs one request per 128-byte line it touches, not per lane (scripts/probe/atomic_probe.hip:
+    // 20 G lane-atomics/s with 64 scattered lines per instruction, 320 G/s with 64 consecutive floats), and the
+    // channel-last volume keeps the K <= 32 bone channels of a voxel in one line.  A point-per-lane scatter issued
+    // 8 taps x 26 channels x 64 different lines per wave instruction (4.9 ms for 262 144 points).
+    __shared__ float sGw[256][33];
+    __shared__ int sBase[256][8];
+    __shared__ float sTw[256][8];
+    {
+        const bool act = inside && live;
+#pragma unroll
+        for (int i = 0; i < KMAX; ++i) if (i < 32) sGw[threadIdx.x][i] = (act && i < K) ? gw[i] : 0.f;
         float dgx = 0.f, dgy = 0.f, dgz = 0.f;
         for (int t = 0; t < 8; ++t) {
             const int dx = t & 1, dy = (t >> 1) & 1, dz = t >> 2;
             const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-            if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
+            int tap_base = -1;
+            float tap_w = 0.f;
+            if (act && x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
                 const float wx = dx ? wx1 : wx0, wy = dy ? wy1 : wy0, wz = dz ? wz1 : wz0;
                 const size_t base = (((size_t)z * V + y) * V + x) * CL;
                 float dot = 0.f;    // sum_i gw_i * v_i(tap)
-                for (int i = 0; i < K; ++i) {
-                    dot += gw[i] * vol_cl[base + i];
-                    if (g_vol_cl != nullptr && gw[i] != 0.f)
-                        __hip_atomic_fetch_add(g_vol_cl + base + i, gw[i] * (wx * wy * wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                for (int i = 0; i < K; ++i) dot += gw[i] * vol_cl[base + i];
+                tap_base = (int)base;
+                tap_w = wx * wy * wz;
                 dgx += dot * (dx ? 1.f : -1.f) * wy * wz;
                 dgy += dot * wx * (dy ? 1.f : -1.f) * wz;
                 dgz += dot * wx * wy * (dz ? 1.f : -1.f);
             }
+            sBase[threadIdx.x][t] = tap_base;
+            sTw[threadIdx.x][t] = tap_w;
         }
-        gc[0] += dgx * half * sB[3]; gc[1] += dgy * half * sB[4]; gc[2] += dgz * half * sB[5];
+        if (act) { gc[0] += dgx * half * sB[3]; gc[1] += dgy * half * sB[4]; gc[2] += dgz * half * sB[5]; }
+    }
+    __syncthreads();
+    if (g_vol_cl != nullptr) {
+        const int c = lane & 31, hw = lane >> 5, w0 = (threadIdx.x >> 6) * 64;
+        for (int j = 0; j < 32; ++j) {
+            const int q = w0 + 2 * j + hw;                     // each half wave scatters one point per iteration
+            const float gv = sGw[q][c];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int b = sBase[q][t];
+                if (b >= 0 && c < K) __hip_atomic_fetch_add(g_vol_cl + b + c, gv * sTw[q][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
     if (live && g_cnl) { g_cnl[pp * 3] = gc[0]; g_cnl[pp * 3 + 1] = gc[1]; g_cnl[pp * 3 + 2] = gc[2]; }
     __syncthreads();
