@@ -103,12 +103,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); use tests -m 'not gpu' on CPU")
+    # HOS_BENCH_ONE_GPU=1 (testing only): all ranks share cuda:0 and exchange through gloo, so the multi-rank code
+    # path (graph replay + eager all-reduce, max-over-ranks timing) can be exercised on a 1-GPU box
+    one_gpu = os.environ.get("HOS_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from hosnerf_amd import ops, synth
     from hosnerf_amd.mipnerf360 import MipNeRF360
@@ -205,7 +213,7 @@ def main():
         prof = ops.KernelEvents()
         ops.set_kernel_events(prof)
         for i in range(min(args.steps, 5)):
-            step(args.warmup + args.steps + i)
+            fwd_bwd(args.warmup + args.steps + i)       # rank-local: no collective outside the timed region
         torch.cuda.synchronize()
         ops.set_kernel_events(None)
 
