@@ -384,7 +384,7 @@ int launch3(GemmArgs& a, int splits, hipStream_t stream) {
         if (env_splits > 0) splits = env_splits;
         if (splits <= 0) {
             const int tiles = a.tiles_m * a.tiles_n;
-            splits = hos_cdiv(512, tiles);                       // ~2 workgroups per CU
+            splits = 256 / tiles > 0 ? 256 / tiles : 1;          // one workgroup per CU: one over costs a whole second round
             if (splits > a.nk / 8) splits = a.nk / 8 > 0 ? a.nk / 8 : 1;
         }
         if (splits > a.nk) splits = a.nk;
@@ -409,6 +409,11 @@ int hos_gemm3_launch(GemmArgs a, int mode, int splits, hipStream_t stream) {
     switch (mode) {
         case MODE_FWD:   return wide ? launch3<256, MODE_FWD, _Float16>(a, 1, stream) : launch3<128, MODE_FWD, _Float16>(a, 1, stream);
         case MODE_DGRAD: return wide ? launch3<256, MODE_DGRAD, __bf16>(a, 1, stream) : launch3<128, MODE_DGRAD, __bf16>(a, 1, stream);
-        default:         return wide ? launch3<256, MODE_WGRAD, __bf16>(a, splits, stream) : launch3<128, MODE_WGRAD, __bf16>(a, splits, stream);
+        default: {
+            // 256 x 128 tiles up to N = 256: a [256,256] gradient then has two tiles x 128 splits instead of one x 256
+            // (half the atomic traffic at the same parallelism; same finding as hos_gemmp.hip)
+            static const int narrow_max = getenv("HOS_WGRAD_NARROW_MAX") ? atoi(getenv("HOS_WGRAD_NARROW_MAX")) : 256;
+            return a.N > narrow_max ? launch3<256, MODE_WGRAD, __bf16>(a, splits, stream) : launch3<128, MODE_WGRAD, __bf16>(a, splits, stream);
+        }
     }
 }
