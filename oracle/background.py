@@ -43,7 +43,7 @@ def max_dilate_weights(t: torch.Tensor, w: torch.Tensor, dilation: float,
     # For every new edge e_i: the largest pdf among dilated bins [lo_j, hi_j) containing it.
     e = edges[..., :, None]
     covered = (lo[..., None, :] <= e) & (hi[..., None, :] > e)        # H:158-160
-    pdf_d = torch.where(covered, pdf[..., None, :], torch.zeros(())).amax(dim=-1)[..., :-1]
+    pdf_d = torch.where(covered, pdf[..., None, :], torch.zeros((), device=pdf.device)).amax(dim=-1)[..., :-1]
     w_d = pdf_d * (edges[..., 1:] - edges[..., :-1])                  # H:182-183
     w_d = w_d / torch.clip(w_d.sum(dim=-1, keepdim=True), min=EPS)    # H:191-192
     assert w_d.shape[-1] == 3 * n
@@ -81,7 +81,7 @@ def cdf_from_logits(w_logits: torch.Tensor) -> torch.Tensor:
     """H:227-229 + H:197-204: softmax -> [0, clip(cumsum(w[:-1]),max=1), 1]."""
     w = F.softmax(w_logits, dim=-1)
     cw = torch.cumsum(w[..., :-1], dim=-1).clip(max=1.0)
-    z = torch.zeros(cw.shape[:-1] + (1,), dtype=cw.dtype)
+    z = torch.zeros(cw.shape[:-1] + (1,), dtype=cw.dtype, device=cw.device)
     return torch.cat([z, cw, torch.ones_like(z)], dim=-1)
 
 
@@ -110,7 +110,8 @@ def sample_intervals(randomized: bool, t: torch.Tensor, w_logits: torch.Tensor, 
                      domain: Tuple[float, float], jitter: Optional[torch.Tensor] = None,
                      return_index: bool = False):
     """H:373-399 sample_intervals (single_jitter=True) -> S+1 interval edges."""
-    u = sample_positions_u(num_samples, randomized, t.shape[:-1], jitter).to(t.dtype)
+    # (the reference draws u on the CPU and moves it with .type_as, H:363-365; .to(t) does the same)
+    u = sample_positions_u(num_samples, randomized, t.shape[:-1], jitter).to(t)
     u = torch.broadcast_to(u, t.shape[:-1] + (num_samples,))
     centers, idx = sorted_interp_indexed(u, cdf_from_logits(w_logits), t)   # H:227-231
     mid = (centers[..., 1:] + centers[..., :-1]) / 2
@@ -138,7 +139,7 @@ def cast_rays_cone(tdist: torch.Tensor, origins: torch.Tensor, directions: torch
     mean = d[..., None, :] * t_mean[..., None]
     d_mag_sq = torch.sum(d**2, dim=-1, keepdim=True).clip(min=1e-10)
     d_outer = d[..., :, None] * d[..., None, :]
-    null_outer = torch.eye(3, dtype=d.dtype) - d[..., :, None] * (d / d_mag_sq)[..., None, :]
+    null_outer = torch.eye(3, dtype=d.dtype, device=d.device) - d[..., :, None] * (d / d_mag_sq)[..., None, :]
     cov = t_var[..., None, None] * d_outer[..., None, :, :] + r_var[..., None, None] * null_outer[..., None, :, :]
     return mean + origins[..., None, :], cov
 
@@ -159,7 +160,7 @@ def contract(mean: torch.Tensor, cov: torch.Tensor) -> Tuple[torch.Tensor, torch
     s = (2 * r - 1) / r2
     z = torch.where(inside, x, s * x)
     c = (2 / (r2 * r) - 2 / r2) / r
-    eye = torch.eye(3, dtype=x.dtype)
+    eye = torch.eye(3, dtype=x.dtype, device=x.device)
     J = s[..., None] * eye + c[..., None] * (x[..., :, None] * x[..., None, :])
     J = torch.where(inside[..., None], eye.expand_as(J), J)
     cov2 = J @ cov.detach() @ J.transpose(-1, -2)
@@ -211,7 +212,7 @@ def lift_and_diagonalize(means, covs, basis):
 
 def integrated_pos_enc(mean: torch.Tensor, var: torch.Tensor, min_deg: int, max_deg: int) -> torch.Tensor:
     """H:78-89 + H:104-105.  level-major / direction-minor; [sin-part | sin(.+pi/2)-part]."""
-    scales = 2.0 ** torch.arange(min_deg, max_deg, dtype=mean.dtype)
+    scales = 2.0 ** torch.arange(min_deg, max_deg, dtype=mean.dtype, device=mean.device)
     shape = tuple(mean.shape[:-1]) + (-1,)
     sm = (mean[..., None, :] * scales[:, None]).reshape(shape)
     sv = (var[..., None, :] * scales[:, None] ** 2).reshape(shape)
@@ -221,7 +222,7 @@ def integrated_pos_enc(mean: torch.Tensor, var: torch.Tensor, min_deg: int, max_
 
 def pos_enc(x: torch.Tensor, min_deg: int, max_deg: int, append_identity: bool = True) -> torch.Tensor:
     """H:93-100 (view directions: min_deg=0, max_deg=4 -> 27 features)."""
-    scales = 2.0 ** torch.arange(min_deg, max_deg, dtype=x.dtype)
+    scales = 2.0 ** torch.arange(min_deg, max_deg, dtype=x.dtype, device=x.device)
     xb = (x[..., None, :] * scales[:, None]).reshape(tuple(x.shape[:-1]) + (-1,))
     feat = torch.sin(torch.cat([xb, xb + HALF_PI32], dim=-1))
     return torch.cat([x, feat], dim=-1) if append_identity else feat
@@ -274,7 +275,7 @@ class MLPWeights:
 def encode_samples(means, covs, basis, max_deg_point: int = 12):
     """M:213-222: contract -> lift -> IPE  ([B,S,504])."""
     m, c = contract(means, covs)
-    lm, lv = lift_and_diagonalize(m, c, basis)
+    lm, lv = lift_and_diagonalize(m, c, basis.to(m.device))
     return integrated_pos_enc(lm, lv, 0, max_deg_point)
 
 
@@ -341,8 +342,8 @@ def mipnerf360_forward(state_dict: Dict[str, torch.Tensor], batch: Dict[str, tor
     B = o.shape[0]
     time = float(torch.as_tensor(batch["times"]).reshape(-1)[0])
     state = select_state(time, transitions_times)
-    sdist = torch.cat([torch.zeros(B, 1), torch.ones(B, 1)], dim=-1)
-    weights = torch.ones(B, 1)
+    sdist = torch.cat([torch.zeros(B, 1, device=o.device), torch.ones(B, 1, device=o.device)], dim=-1)
+    weights = torch.ones(B, 1, device=o.device)
     prod = 1
     renderings, history = [], []
     for lvl in range(num_levels):

@@ -62,7 +62,7 @@ def motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
     """U:134-174: kinematic chain -> backward (cnl <- dst) and forward (dst <- cnl) rigid maps.
     Inputs [K,3,3], [K,3], [K,4,4]; returns (R_bwd [K,3,3], T_bwd [K,3], R_fwd, T_fwd)."""
     K = dst_Rs.shape[0]
-    G = torch.zeros(K, 4, 4, dtype=dst_Rs.dtype)
+    G = torch.zeros(K, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
     G[:, :3, :3] = dst_Rs
     G[:, :3, 3] = dst_Ts
     G[:, 3, 3] = 1.0
@@ -116,7 +116,7 @@ def trilinear_sample(vol: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
     iy = (grid[:, 1] + 1) / 2 * (H - 1)
     iz = (grid[:, 2] + 1) / 2 * (D - 1)
     x0, y0, z0 = torch.floor(ix), torch.floor(iy), torch.floor(iz)
-    out = torch.zeros(grid.shape[0], C, dtype=vol.dtype)
+    out = torch.zeros(grid.shape[0], C, dtype=vol.dtype, device=vol.device)
     flat = vol.reshape(C, -1)
     for dz in (0, 1):
         for dy in (0, 1):
@@ -128,7 +128,7 @@ def trilinear_sample(vol: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
                 ok = (xi >= 0) & (xi <= W - 1) & (yi >= 0) & (yi <= H - 1) & (zi >= 0) & (zi <= D - 1)
                 lin = (zi.clamp(0, D - 1) * H + yi.clamp(0, H - 1)) * W + xi.clamp(0, W - 1)
                 tap = flat[:, lin.long()].T
-                out = out + torch.where(ok[:, None], tap * (wx * wy * wz)[:, None], torch.zeros(()))
+                out = out + torch.where(ok[:, None], tap * (wx * wy * wz)[:, None], torch.zeros((), device=vol.device))
     return out
 
 
@@ -328,13 +328,13 @@ def stage3_composite(bkg_tdist, bkg_rgb, bkg_density, human, rays_o_bkg, rays_d_
     mask = human["pts_mask"]
     idx_fg = mask.sum(-1) > 5e-3                                                        # M:1547-1551
     B = mask.shape[0]
-    rgb_out = torch.zeros(B, 3)
     z_b = bkg_tdist[..., :-1]
+    rgb_out = torch.zeros(B, 3, device=z_b.device)
     bkg = torch.cat([bkg_rgb, bkg_density[..., None]], -1)
     hum = torch.cat([human["human_rgb"], human["human_density"][..., None]], -1)
     fg, bg = idx_fg, ~idx_fg
-    total_order = torch.zeros(0, z_b.shape[1] + z_h.shape[1], dtype=torch.int64)
-    hw = torch.zeros(0, z_h.shape[1])
+    total_order = torch.zeros(0, z_b.shape[1] + z_h.shape[1], dtype=torch.int64, device=z_b.device)
+    hw = torch.zeros(0, z_h.shape[1], device=z_b.device)
     if int(fg.sum()) > 0:
         zz, total_order = torch.sort(torch.cat([z_b[fg], z_h[fg]], -1), dim=-1, stable=True)   # M:1565
         allv = torch.cat([bkg[fg], hum[fg]], 1)
