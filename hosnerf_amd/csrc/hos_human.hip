@@ -416,38 +416,60 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
     const float clampg = (wsum >= 1e-4f) ? 1.f : 0.f;
     const float g0 = live ? g_xdef[pp * 3] : 0.f, g1 = live ? g_xdef[pp * 3 + 1] : 0.f, g2 = live ? g_xdef[pp * 3 + 2] : 0.f;
     const float gdot = g0 * xd + g1 * yd + g2 * zd;
-    // pass 2: g_w_i, g wrt c through q_i, R/T grads
+    // pass 2: g_w_i and g wrt c through q_i.  The R/T gradients  g_R_i = sum_p (g_p w_pi/den_p) (x) p,  g_T_i = sum_p g_p
+    // w_pi/den_p  are reduced AFTERWARDS with lanes = bones (the per-point factor s_pi = w_pi/den_p goes through LDS):
+    // 26 x 12 wave-wide butterfly sums per wave were half of this kernel's instructions.
+    __shared__ float sGw[256][33];
+    __shared__ float sPG[256][6];
     float gw[KMAX];
     float gc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
         gw[i] = 0.f;
+        float sfac = 0.f;
         if (i < K) {
             const float* r = sR + i * 9;
             const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
             const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
             const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
             gw[i] = ((g0 * qx + g1 * qy + g2 * qz) - clampg * gdot) / den;
-            const float s = w[i] / den;
-            const float gq[3] = {g0 * s, g1 * s, g2 * s};
+            sfac = w[i] / den;
+            const float gq[3] = {g0 * sfac, g1 * sfac, g2 * sfac};
             gc[0] += r[0] * gq[0] + r[3] * gq[1] + r[6] * gq[2];
             gc[1] += r[1] * gq[0] + r[4] * gq[1] + r[7] * gq[2];
             gc[2] += r[2] * gq[0] + r[5] * gq[1] + r[8] * gq[2];
-            float contrib[12] = {gq[0] * px, gq[0] * py, gq[0] * pz, gq[1] * px, gq[1] * py, gq[1] * pz,
-                                 gq[2] * px, gq[2] * py, gq[2] * pz, gq[0], gq[1], gq[2]};
+        }
+        if (i < 32) sGw[threadIdx.x][i] = sfac;
+    }
+    sPG[threadIdx.x][0] = px; sPG[threadIdx.x][1] = py; sPG[threadIdx.x][2] = pz;
+    sPG[threadIdx.x][3] = g0; sPG[threadIdx.x][4] = g1; sPG[threadIdx.x][5] = g2;       // (0 for dead lanes)
+    __syncthreads();
+    {
+        const int bone = threadIdx.x & 31, chunk = threadIdx.x >> 5;                   // 8 chunks of 32 points
+        if (bone < K) {
+            float a[12];
 #pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                const float sm = wave_sum(contrib[c]);
-                if (lane == 0) atomicAdd(&sAcc[i * 12 + c], sm);
+            for (int c = 0; c < 12; ++c) a[c] = 0.f;
+            for (int j = 0; j < 32; ++j) {
+                const int q = chunk * 32 + j;
+                const float sf = sGw[q][bone];
+                const float qx_ = sPG[q][0], qy_ = sPG[q][1], qz_ = sPG[q][2];
+                const float e0 = sPG[q][3] * sf, e1 = sPG[q][4] * sf, e2 = sPG[q][5] * sf;
+                a[0] += e0 * qx_; a[1] += e0 * qy_; a[2] += e0 * qz_;
+                a[3] += e1 * qx_; a[4] += e1 * qy_; a[5] += e1 * qz_;
+                a[6] += e2 * qx_; a[7] += e2 * qy_; a[8] += e2 * qz_;
+                a[9] += e0; a[10] += e1; a[11] += e2;
             }
+#pragma unroll
+            for (int c = 0; c < 12; ++c) atomicAdd(&sAcc[bone * 12 + c], a[c]);
         }
     }
+    __syncthreads();
     // pass 3: through the taps: d w / d c per point; the volume gradient is scattered AFTERWARDS with lanes = channels:
     // an fp32 atomic costs one request per 128-byte line it touches, not per lane (scripts/probe/atomic_probe.hip:
     // 20 G lane-atomics/s with 64 scattered lines per instruction, 320 G/s with 64 consecutive floats), and the
     // channel-last volume keeps the K <= 32 bone channels of a voxel in one line.  A point-per-lane scatter issued
     // 8 taps x 26 channels x 64 different lines per wave instruction (4.9 ms for 262 144 points).
-    __shared__ float sGw[256][33];
     __shared__ int sBase[256][8];
     __shared__ float sTw[256][8];
     {
