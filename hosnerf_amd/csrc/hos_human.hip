@@ -325,26 +325,51 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     const float gx_ = live ? g_xskel[pp * 3] : 0.f, gy_ = live ? g_xskel[pp * 3 + 1] : 0.f, gz_ = live ? g_xskel[pp * 3 + 2] : 0.f;
     const float gm = live ? g_mask[pp] : 0.f;
     const float gdot_xs = gx_ * xs + gy_ * ys + gz_ * zs;
-    // pass 2: per-bone gradients
-    for (int i = 0; i < K; ++i) {
-        const float* r = sR + i * 9;
-        const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
-        const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
-        const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
-        // d loss / d w_i
-        const float gw = ((gx_ * qx + gy_ * qy + gz_ * qz) - clampg * gdot_xs) / den + gm;
-        float dg[3];
-        const float w = trilinear_zero_grad(vol + i * V3, live ? g_vol + i * V3 : nullptr, V, (qx - sB[0]) * sB[3] - 1.f,
-                                            (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f, gw, dg);
-        // d loss / d q_i = g_xs * w/den + gw * dw/dq
-        float gq[3] = {gx_ * w / den + gw * dg[0] * sB[3], gy_ * w / den + gw * dg[1] * sB[4], gz_ * w / den + gw * dg[2] * sB[5]};
-        float contrib[12] = {gq[0] * px, gq[0] * py, gq[0] * pz, gq[1] * px, gq[1] * py, gq[1] * pz,
-                             gq[2] * px, gq[2] * py, gq[2] * pz, gq[0], gq[1], gq[2]};
-#pragma unroll
-        for (int c = 0; c < 12; ++c) {
-            const float s = wave_sum(contrib[c]);
-            if (lane == 0) atomicAdd(&sAcc[i * 12 + c], s);
+    // pass 2: per-bone gradients.  d loss / d q_i of every (point, bone) goes through LDS (16 bones at a time) and the
+    // R/T gradients  g_R_i = sum_p gq_pi (x) p,  g_T_i = sum_p gq_pi  are reduced with one thread per (bone, component,
+    // 64-point chunk) instead of 12 wave-wide butterfly sums per bone.
+    __shared__ float sQ[256][49];          // [point][16 bones x 3 components] (+1: bank spread)
+    __shared__ float sP[256][3];
+    sP[threadIdx.x][0] = px; sP[threadIdx.x][1] = py; sP[threadIdx.x][2] = pz;
+    for (int i0 = 0; i0 < K; i0 += 16) {
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = i0 + ii;
+            float gq[3] = {0.f, 0.f, 0.f};
+            if (i < K) {
+                const float* r = sR + i * 9;
+                const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
+                const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
+                const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
+                // d loss / d w_i
+                const float gw = ((gx_ * qx + gy_ * qy + gz_ * qz) - clampg * gdot_xs) / den + gm;
+                float dg[3];
+                const float w = trilinear_zero_grad(vol + i * V3, live ? g_vol + i * V3 : nullptr, V, (qx - sB[0]) * sB[3] - 1.f,
+                                                    (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f, gw, dg);
+                // d loss / d q_i = g_xs * w/den + gw * dw/dq   (all zero for dead lanes: their g_xskel / g_mask are 0)
+                gq[0] = gx_ * w / den + gw * dg[0] * sB[3];
+                gq[1] = gy_ * w / den + gw * dg[1] * sB[4];
+                gq[2] = gz_ * w / den + gw * dg[2] * sB[5];
+            }
+            sQ[threadIdx.x][ii * 3 + 0] = gq[0]; sQ[threadIdx.x][ii * 3 + 1] = gq[1]; sQ[threadIdx.x][ii * 3 + 2] = gq[2];
         }
+        __syncthreads();
+        {
+            const int e = threadIdx.x & 63, chunk = threadIdx.x >> 6;      // e = (bone in group) * 3 + component; 4 chunks of 64 points
+            const int bone = i0 + e / 3, comp = e % 3;
+            if (e < 48 && bone < K) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                for (int j = 0; j < 64; ++j) {
+                    const int q = chunk * 64 + j;
+                    const float v = sQ[q][e];
+                    a0 += v * sP[q][0]; a1 += v * sP[q][1]; a2 += v * sP[q][2]; a3 += v;
+                }
+                atomicAdd(&sAcc[bone * 12 + comp * 3 + 0], a0);
+                atomicAdd(&sAcc[bone * 12 + comp * 3 + 1], a1);
+                atomicAdd(&sAcc[bone * 12 + comp * 3 + 2], a2);
+                atomicAdd(&sAcc[bone * 12 + 9 + comp], a3);
+            }
+        }
+        __syncthreads();
     }
     __syncthreads();
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) {
