@@ -250,10 +250,14 @@ class Network(FlatModule):
         return L.W.view(flat), L.b.view(flat).view(-1)
 
     # ------------------------------------------------------------------ prologue (torch ops, once per call)
+    # Both frames of a training step (current pose and previous-frame pose) go through the prologue as ONE batch, and the
+    # kinematic chain is evaluated level by level of the SMPL tree (9 batched products instead of 2 x 25 chained ones):
+    # the prologue is launch-bound (26 joints), so its cost is its number of launches.
     def _pose_refine(self, Rs, Ts, posevec):
-        """N:589-605 + pose_decoders/mlp_delta_body_pose.py + U:66-92."""
+        """N:589-605 + pose_decoders/mlp_delta_body_pose.py + U:66-92.  Rs [F,K,3,3], Ts [F,K,3], posevec [F,75]."""
         P = self._plain
-        h = posevec[None]
+        F_ = Rs.shape[0]
+        h = posevec
         for name in ("block_mlps.0", "block_mlps.2", "block_mlps.4"):
             h = torch.relu(F.linear(h, P[f"pose_decoder.{name}.weight"], P[f"pose_decoder.{name}.bias"]))
 
@@ -268,28 +272,49 @@ class Network(FlatModule):
         x, y, z = r[:, 0], r[:, 1], r[:, 2]
         dR = torch.stack([x * x + (1 - x * x) * c, x * y * (1 - c) - z * s, x * z * (1 - c) + y * s,
                           x * y * (1 - c) + z * s, y * y + (1 - y * y) * c, y * z * (1 - c) - x * s,
-                          x * z * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z + (1 - z * z) * c], dim=1).view(-1, 3, 3)
-        dT = head("dstT").view(-1, 3)
-        Rs = torch.cat([Rs[0:1], torch.matmul(Rs[1:], dR)], 0)
-        Ts = torch.cat([Ts[0:1], Ts[1:] + dT], 0)
+                          x * z * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z + (1 - z * z) * c], dim=1).view(F_, -1, 3, 3)
+        dT = head("dstT").view(F_, -1, 3)
+        Rs = torch.cat([Rs[:, 0:1], torch.matmul(Rs[:, 1:], dR)], 1)
+        Ts = torch.cat([Ts[:, 0:1], Ts[:, 1:] + dT], 1)
         return Rs, Ts
 
-    @staticmethod
-    def _motion_basis(dst_Rs, dst_Ts, cnl_gtfms):
-        """U:134-174."""
-        K = dst_Rs.shape[0]
-        G = torch.zeros(K, 4, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
-        G[:, :3, :3] = dst_Rs
-        G[:, :3, 3] = dst_Ts
-        G[:, 3, 3] = 1.0
-        chain = [G[0]]
+    def _chain_levels(self, K: int, device):
+        """Per tree level: (joint indices, position of each joint's parent inside the previous level)."""
+        key = (K, str(device))
+        cache = getattr(self, "_levels_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1], cache[2]
+        depth = [0] * K
         for i in range(1, K):
-            chain.append(chain[SMPL_PARENT[i]] @ G[i])
-        dst = torch.stack(chain, 0)
+            depth[i] = depth[SMPL_PARENT[i]] + 1
+        levels, prev = [], [0]
+        for d in range(1, max(depth) + 1):
+            idx = [i for i in range(K) if depth[i] == d]
+            par = [prev.index(SMPL_PARENT[i]) for i in idx]
+            levels.append((idx, torch.tensor(par, device=device)))
+            prev = idx
+        order = [0] + [i for idx, _ in levels for i in idx]
+        inv = torch.tensor([order.index(i) for i in range(K)], device=device)
+        self._levels_cache = (key, levels, inv)
+        return levels, inv
+
+    def _motion_basis(self, dst_Rs, dst_Ts, cnl_gtfms):
+        """U:134-174 for F frames at once: dst_Rs [F,K,3,3], dst_Ts [F,K,3] -> (R_bwd, T_bwd, R_fwd, T_fwd), each [F,K,...]."""
+        F_, K = dst_Rs.shape[0], dst_Rs.shape[1]
+        bottom = torch.zeros(F_, K, 1, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
+        bottom[..., 3] = 1.0
+        G = torch.cat([torch.cat([dst_Rs, dst_Ts[..., None]], -1), bottom], -2)          # [F,K,4,4]
+        levels, inv = self._chain_levels(K, dst_Rs.device)
+        parts = [G[:, 0:1]]
+        prev = parts[0]
+        for idx, par in levels:
+            prev = torch.matmul(prev.index_select(1, par), G[:, idx])
+            parts.append(prev)
+        dst = torch.cat(parts, 1).index_select(1, inv)
         bwd = cnl_gtfms @ torch.inverse(dst)
         fwd = dst @ torch.inverse(cnl_gtfms)
-        return (bwd[:, :3, :3].contiguous(), bwd[:, :3, 3].contiguous(),
-                fwd[:, :3, :3].contiguous(), fwd[:, :3, 3].contiguous())
+        return (bwd[..., :3, :3].contiguous(), bwd[..., :3, 3].contiguous(),
+                fwd[..., :3, :3].contiguous(), fwd[..., :3, 3].contiguous())
 
     def _motion_weight_volume(self, priors):
         """deconv_vol_decoder.py:34-42 + U:21-59 -> [K+1, V, V, V]."""
@@ -466,19 +491,22 @@ class Network(FlatModule):
         state = select_state(time, self.transitions_times)
         nr_kick = cfg.non_rigid_motion_mlp.kick_in_iter
 
-        def refine(Rs, Ts, pv):
-            if iter_v >= cfg.pose_decoder.get("kick_in_iter", 0):
-                return self._pose_refine(Rs, Ts, pv)
-            return Rs, Ts
-
         def cond_of(pv):
             return torch.zeros_like(pv) * pv if iter_v < nr_kick else pv          # N:653-656
 
-        Rs, Ts = refine(dst_Rs, dst_Ts, dst_posevec)
-        R_b, T_b, R_f, T_f = self._motion_basis(Rs, Ts, cnl_gtfms)
+        # prologue for the current (and, for the flow set, the previous) frame in one batch
         if flow:
-            Rp, Tp = refine(kwargs["dst_Rs_prev"], kwargs["dst_Ts_prev"], kwargs["dst_posevec_prev"])
-            _, _, R_fp, T_fp = self._motion_basis(Rp, Tp, cnl_gtfms)
+            Rs = torch.stack([dst_Rs, kwargs["dst_Rs_prev"]], 0)
+            Ts = torch.stack([dst_Ts, kwargs["dst_Ts_prev"]], 0)
+            pv = torch.stack([dst_posevec.reshape(-1), kwargs["dst_posevec_prev"].reshape(-1)], 0)
+        else:
+            Rs, Ts, pv = dst_Rs[None], dst_Ts[None], dst_posevec.reshape(1, -1)
+        if iter_v >= cfg.pose_decoder.get("kick_in_iter", 0):
+            Rs, Ts = self._pose_refine(Rs, Ts, pv)
+        Rb_, Tb_, Rf_, Tf_ = self._motion_basis(Rs, Ts, cnl_gtfms)
+        R_b, T_b, R_f, T_f = Rb_[0], Tb_[0], Rf_[0], Tf_[0]
+        if flow:
+            R_fp, T_fp = Rf_[1], Tf_[1]
             cond_prev = cond_of(kwargs["dst_posevec_prev"]).contiguous()
         band_w = self._band_weights(iter_v, dev)
         cond = cond_of(dst_posevec).contiguous()

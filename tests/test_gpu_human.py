@@ -58,7 +58,7 @@ def maxerr(a, b):
 def test_prologue(dev, net, hp):
     b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in synth.human_batch(8, seed=3).items()}
     with torch.no_grad():
-        R, Tt, Rf, Tf = net._motion_basis(b["dst_Rs"], b["dst_Ts"], b["cnl_gtfms"])
+        R, Tt, Rf, Tf = (x[0] for x in net._motion_basis(b["dst_Rs"][None], b["dst_Ts"][None], b["cnl_gtfms"]))
         vol = net._motion_weight_volume(b["motion_weights_priors"])
     assert maxerr(R, hp["mb_R"]) < 5e-6 and maxerr(Tt, hp["mb_T"]) < 5e-6
     assert maxerr(Rf, hp["mb_Rf"]) < 5e-6 and maxerr(Tf, hp["mb_Tf"]) < 5e-6
@@ -96,7 +96,7 @@ def test_stratified_sampling(dev, net):
     gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
     with torch.no_grad():
         vol = net._motion_weight_volume(gb["motion_weights_priors"])
-        R, Tt, _, _ = net._motion_basis(gb["dst_Rs"], gb["dst_Ts"], gb["cnl_gtfms"])
+        R, Tt, _, _ = (x[0] for x in net._motion_basis(gb["dst_Rs"][None], gb["dst_Ts"][None], gb["cnl_gtfms"]))
     z, pts, _, _ = ops.human_sample_warp(gb["rays"][0].contiguous(), gb["rays"][1].contiguous(), gb["near"], gb["far"], 128, R, Tt, vol,
                                          gb["cnl_bbox_min_xyz"], gb["cnl_bbox_scale_xyz"], t_rand.to(dev))
     assert maxerr(z, want) < 5e-7
