@@ -291,9 +291,9 @@ class Network(FlatModule):
         for d in range(1, max(depth) + 1):
             idx = [i for i in range(K) if depth[i] == d]
             par = [prev.index(SMPL_PARENT[i]) for i in idx]
-            levels.append((idx, torch.tensor(par, device=device)))
+            levels.append((torch.tensor(idx, device=device), torch.tensor(par, device=device)))
             prev = idx
-        order = [0] + [i for idx, _ in levels for i in idx]
+        order = [0] + [int(i) for idx, _ in levels for i in idx.tolist()]
         inv = torch.tensor([order.index(i) for i in range(K)], device=device)
         self._levels_cache = (key, levels, inv)
         return levels, inv
@@ -308,7 +308,7 @@ class Network(FlatModule):
         parts = [G[:, 0:1]]
         prev = parts[0]
         for idx, par in levels:
-            prev = torch.matmul(prev.index_select(1, par), G[:, idx])
+            prev = torch.matmul(prev.index_select(1, par), G.index_select(1, idx))
             parts.append(prev)
         dst = torch.cat(parts, 1).index_select(1, inv)
         bwd = cnl_gtfms @ torch.inverse(dst)
