@@ -41,6 +41,7 @@ PROTOTYPES = {
     "hos_linearp_wgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],
     "hos_encode_ipe": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
+    "hos_encode_ipe_planes": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "hos_encode_viewdirs": [_P, _I, _I, _P, _I, _I, _P],
     "hos_alpha_weights_fwd": [_P, _P, _P, _I, _I, _I, _P, _P],
     "hos_alpha_weights_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P],

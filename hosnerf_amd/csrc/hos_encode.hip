@@ -23,10 +23,25 @@ constexpr int SB = 64;                  // samples per workgroup
 constexpr float EPS = 1.1920929e-07f;
 constexpr float HALF_PI = 1.57079637050628662109375f;   // float32(0.5*pi)
 
+// (hi, lo) split of one value for the interleaved-planes layout of hos_gemmp.hip: fp16 hi saturates at +-65504
+template <typename E> __device__ __forceinline__ float hi_clamp(float x) { return x; }
+template <> __device__ __forceinline__ float hi_clamp<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+template <typename E> __device__ __forceinline__ void split_store(unsigned short* __restrict__ P, size_t o, float x) {
+    const E h = (E)hi_clamp<E>(x);
+    const E l = (E)(x - (float)h);
+    P[o] = __builtin_bit_cast(unsigned short, h);
+    P[o + 32] = __builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ size_t plane_off(long row, int c, int ld) { return (size_t)row * (2 * ld) + (c >> 5) * 64 + (c & 31); }
+
+// PLANES = false: X fp32 [P][ldx].  PLANES = true: the same rows written directly as interleaved 16-bit planes
+// (fp16 planes p16 = first-layer operand, optional bf16 planes pb = weight-gradient operand), so the MLP never
+// sees an fp32 copy of the 576-wide encoding (saves the 151 MB write and the hos_split_planes2 pass per level).
+template <bool PLANES>
 __global__ __launch_bounds__(256) void encode_ipe_kernel(
     const float* __restrict__ tdist, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ radii, const float* __restrict__ basis, const float* __restrict__ embed,
-    int B, int S, float* __restrict__ X, int ldx) {
+    int B, int S, float* __restrict__ X, int ldx, unsigned short* __restrict__ p16, unsigned short* __restrict__ pb) {
     __shared__ float s_mean[SB][3];
     __shared__ float s_cov[SB][9];
     __shared__ float s_lm[SB][NDIR];
@@ -125,15 +140,29 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
         const float sm = s_lm[s][j] * sc;
         const float sv = s_lv[s][j] * (sc * sc);
         const float damp = expf(-0.5f * sv);
-        float* row = X + (size_t)(p0 + s) * ldx;
-        row[c] = damp * sinf(sm);
-        row[c + HALF] = damp * sinf(sm + HALF_PI);
+        const float v0 = damp * sinf(sm), v1 = damp * sinf(sm + HALF_PI);
+        if constexpr (!PLANES) {
+            float* row = X + (size_t)(p0 + s) * ldx;
+            row[c] = v0;
+            row[c + HALF] = v1;
+        } else {
+            const size_t o0 = plane_off(p0 + s, c, ldx), o1 = plane_off(p0 + s, c + HALF, ldx);
+            split_store<_Float16>(p16, o0, v0); split_store<_Float16>(p16, o1, v1);
+            if (pb != nullptr) { split_store<__bf16>(pb, o0, v0); split_store<__bf16>(pb, o1, v1); }
+        }
     }
     const int tail = ldx - NIPE;   // embedding + zero pad
     for (int it = t; it < SB * tail; it += 256) {
         const int s = it / tail, c = it % tail;
         if (p0 + s >= P) break;
-        X[(size_t)(p0 + s) * ldx + NIPE + c] = (c < NEMB) ? s_embed[c] : 0.f;
+        const float v = (c < NEMB) ? s_embed[c] : 0.f;
+        if constexpr (!PLANES) {
+            X[(size_t)(p0 + s) * ldx + NIPE + c] = v;
+        } else {
+            const size_t o = plane_off(p0 + s, NIPE + c, ldx);
+            split_store<_Float16>(p16, o, v);
+            if (pb != nullptr) split_store<__bf16>(pb, o, v);
+        }
     }
 }
 
@@ -167,8 +196,21 @@ extern "C" int hos_encode_ipe(const float* tdist, const float* rays_o, const flo
     if (!tdist || !rays_o || !rays_d || !radii || !basis || !embed || !X || B <= 0 || S <= 0) return HOS_E_ARG;
     if (ldx < NIPE + NEMB) return HOS_E_SHAPE;
     const long P = (long)B * S;
-    hipLaunchKernelGGL(encode_ipe_kernel, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), tdist, rays_o, rays_d, radii, basis, embed, B, S, X, ldx);
+    hipLaunchKernelGGL(encode_ipe_kernel<false>, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tdist, rays_o, rays_d, radii, basis, embed, B, S, X, ldx,
+                       (unsigned short*)nullptr, (unsigned short*)nullptr);
+    return hos_launch_status();
+}
+
+extern "C" int hos_encode_ipe_planes(const float* tdist, const float* rays_o, const float* rays_d, const float* radii,
+                                     const float* basis, const float* embed, int B, int S, void* p16, void* pb, int ld,
+                                     hos_stream_t stream) {
+    if (!tdist || !rays_o || !rays_d || !radii || !basis || !embed || !p16 || B <= 0 || S <= 0) return HOS_E_ARG;
+    if (ld < NIPE + NEMB || (ld & 31)) return HOS_E_SHAPE;
+    const long P = (long)B * S;
+    hipLaunchKernelGGL(encode_ipe_kernel<true>, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), tdist, rays_o, rays_d, radii, basis, embed, B, S, (float*)nullptr, ld,
+                       (unsigned short*)p16, (unsigned short*)pb);
     return hos_launch_status();
 }
 

@@ -212,7 +212,7 @@ class MipNeRF360MLP(FlatModule):
 
     def _forward_impl(self, X: torch.Tensor, viewdirs: Optional[torch.Tensor], B: int, S: int, save: bool):
         """X [P, X_LD] encoded samples -> density [P], rgb [P,3] | None, saved activations."""
-        if self._use_planes():
+        if isinstance(X, tuple) or self._use_planes():
             return self._forward_planes(X, viewdirs, B, S, save)
         P = X.shape[0]
         dev = X.device
@@ -350,12 +350,18 @@ class MipNeRF360MLP(FlatModule):
                   for L in specs]
         return W16, WT
 
-    def _forward_planes(self, X: torch.Tensor, viewdirs, B: int, S: int, save: bool):
-        P = X.shape[0]
-        dev = X.device
+    def _forward_planes(self, X, viewdirs, B: int, S: int, save: bool):
+        """X: (fp16 Planes, bf16 Planes | None) from hos_encode_ipe_planes, or an fp32 [P, X_LD] tensor (split here)."""
         W = self.netwidth
         W16, WT = self._weight_planes(need_t=save)
-        X16, Xb = ops.split_planes2(X, C=X_LD, ld=X_LD, wantb=save)
+        if isinstance(X, tuple):
+            X16, Xb = X
+            if save and Xb is None:
+                raise ValueError("the backward pass needs the bf16 planes of the encoding")
+        else:
+            X16, Xb = ops.split_planes2(X, C=X_LD, ld=X_LD, wantb=save)
+        P = X16.rows
+        dev = X16.t.device
         h = X16
         kin = X_LD
         y16: List[ops.Planes] = []
@@ -472,13 +478,17 @@ class MipNeRF360MLP(FlatModule):
         B, S = tdist.shape[0], tdist.shape[1] - 1
         state = select_state(time, self.transitions_times)
         embed = self._embeds.view(self.store.param)[state]
-        X = ops.encode_ipe(tdist, rays_o, rays_d, radii, self.pos_basis_t, embed, X_LD)
+        if self._use_planes():      # the encoder writes the 16-bit planes the trunk consumes (no fp32 copy of X)
+            X = ops.encode_ipe_planes(tdist, rays_o, rays_d, radii, self.pos_basis_t, embed, X_LD,
+                                      want_bf16=torch.is_grad_enabled())
+        else:
+            X = ops.encode_ipe(tdist, rays_o, rays_d, radii, self.pos_basis_t, embed, X_LD)
         if torch.is_grad_enabled():
             density, rgb = _MLPFn.apply(self._token, self, X, viewdirs, B, S, state)
         else:
             density, rgb, _ = self._forward_impl(X, viewdirs, B, S, save=False)
         density = density.view(B, S)
-        rgb = torch.zeros(B, S, 3, device=X.device) if self.disable_rgb else rgb.view(B, S, 3)
+        rgb = torch.zeros(B, S, 3, device=density.device) if self.disable_rgb else rgb.view(B, S, 3)
         return {"density": density, "rgb": rgb}
 
 
@@ -492,7 +502,7 @@ class _MLPFn(torch.autograd.Function):
         ctx.mlp, ctx.saved, ctx.state = mlp, saved, state
         ctx.density, ctx.rgb = density, rgb
         if rgb is None:
-            rgb = torch.zeros(0, device=X.device)
+            rgb = torch.zeros(0, device=density.device)
             ctx.mark_non_differentiable(rgb)
         return density, rgb
 

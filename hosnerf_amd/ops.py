@@ -241,6 +241,17 @@ def encode_ipe(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, out=N
     return X
 
 
+def encode_ipe_planes(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, want_bf16: bool = True):
+    """Same encoder, output directly as Planes (fp16, and bf16 if want_bf16) -- no fp32 copy of the encoding."""
+    B, S1 = tdist.shape
+    S = S1 - 1
+    p16 = Planes.empty(B * S, ldx, torch.float16, tdist.device)
+    pb = Planes.empty(B * S, ldx, torch.bfloat16, tdist.device) if want_bf16 else None
+    call("hos_encode_ipe_planes", ptr(tdist), ptr(rays_o), ptr(rays_d), ptr(radii.reshape(-1)), ptr(basis), ptr(embed),
+         B, S, _pp(p16), _pp(pb), ldx)
+    return p16, pb
+
+
 def encode_viewdirs(viewdirs, S: int, Xv: torch.Tensor, col0: int):
     B = viewdirs.shape[0]
     call("hos_encode_viewdirs", ptr(viewdirs), B, S, ptr(Xv), Xv.stride(0), col0)

@@ -163,6 +163,12 @@ int hos_encode_ipe(const float* tdist, const float* rays_o, const float* rays_d,
                    const float* basis, const float* embed, int B, int S, float* X, int ldx,
                    hos_stream_t stream);
 
+/* Same encoder, rows written directly as the interleaved 16-bit planes of the planes GEMMs (fp16 planes p16 [P][ld]
+ * and, if pb != NULL, bf16 planes): the MLP trunk then needs no fp32 copy of the encoding.  ld % 32 == 0, ld >= 568. */
+int hos_encode_ipe_planes(const float* tdist, const float* rays_o, const float* rays_d, const float* radii,
+                          const float* basis, const float* embed, int B, int S, void* p16, void* pb, int ld,
+                          hos_stream_t stream);
+
 /* View-direction encoding (H:93-100, deg 0..4, identity appended = 27) broadcast over samples
  * into columns [col0, col0+27) of Xv [B*S, ldx]; columns [col0+27, ldx) are zeroed (M:330-335). */
 int hos_encode_viewdirs(const float* viewdirs, int B, int S, float* Xv, int ldx, int col0,
