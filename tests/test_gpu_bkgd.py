@@ -222,6 +222,10 @@ def test_encode_ipe(dev, hv):
             assert maxerr(X[..., sl], want[..., sl]) < tol, (lvl, "oracle")
     assert torch.equal(X[..., 504:568].cpu(), embed.cpu().expand(B, S, 64))
     assert float(X[..., 568:].abs().max()) == 0
+    # planes variant: the same fp32 values, split into fp16 / bf16 hi-lo pairs by the encoder itself
+    p16, pb = ops.encode_ipe_planes(tdist, o, d, radii, basis, embed, 576)
+    q16, qb = ops.split_planes2(X.view(B * S, 576), C=576, ld=576)
+    assert torch.equal(p16.t, q16.t) and torch.equal(pb.t, qb.t)
     Xv = torch.full((B * S, 288), -7.0, device=dev)
     ops.encode_viewdirs(d, S, Xv, 256)
     assert maxerr(Xv.view(B, S, 288)[:, 0, 256:283], hv["dir_enc"]) < 2e-6
