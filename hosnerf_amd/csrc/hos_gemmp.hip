@@ -40,6 +40,9 @@
 #ifndef HOS_ABLATE_DMA
 #define HOS_ABLATE_DMA 0
 #endif
+#ifndef HOS_NO_SETPRIO
+#define HOS_NO_SETPRIO 0
+#endif
 
 namespace {
 
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         _Pragma("unroll") for (int x = 0; x < TM; ++x) { tie(AH[x]); tie(AL[x]); }                        \
         _Pragma("unroll") for (int y = 0; y < TH; ++y) { tie(BH[y]); tie(BL[y]); }                        \
         if (YH == 0) db_acc(AH, AL);                                                                      \
-        __builtin_amdgcn_s_setprio(1);                                                                    \
+        if (!HOS_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);                                               \
         _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
             const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;                           \
             if (!HOS_ABLATE_MFMA) {                                                                       \
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             FILL(i);                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
-        __builtin_amdgcn_s_setprio(0);                                                                    \
+        if (!HOS_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);                                               \
     } while (0)
 
     unsigned so = 0;                     // byte offset of the stage holding tile kt

@@ -87,3 +87,19 @@ def test_lr_schedule_and_state_selection():
     import numpy as np
     tt = np.array([0.2, 0.4, 0.6], dtype=np.float32)
     assert [select_state(t, tt) for t in (0.1, 0.2, 0.41, 0.6, 0.7)] == [0, 1, 2, 2, 3]
+
+
+def test_select_model_registry(tmp_path):
+    """utils/select_option.py::select_model names (SURVEY 8(b).3): the three stages resolve to modules that expose the
+    reference's attribute names; unknown names raise."""
+    import json
+    from hosnerf_amd.select_option import select_model
+    (tmp_path / "transitions_times.json").write_text(json.dumps({"f0": {"time": 0.4}}))
+    s1 = select_model("state_mipnerf360", str(tmp_path))
+    assert type(s1.model).__name__ == "MipNeRF360" and hasattr(s1, "training_step") and hasattr(s1, "configure_optimizers")
+    assert len(list(s1.parameters())) > 0 and abs(s1.learning_rate(0) - 2e-3 * 0.01) < 1e-9
+    with pytest.raises(ValueError):
+        select_model("nope", str(tmp_path))
+    import importlib
+    mod = importlib.import_module("hosnerf_amd.plugins.network_amd")
+    assert mod.Network.__name__ == "Network"
