@@ -494,3 +494,28 @@ def test_planes_gemm_matches_fp64(M, N, K):
         assert (db.double() - dY.double().sum(0)).abs().max().item() < 2e-3
     ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K)                                  # accumulates
     assert (dW.double() - 2 * refw).abs().max().item() < 4e-4 * refw.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_lit_module_with_torch_adam(dev):
+    """select_model('state_mipnerf360'): the Lightning-style surface -- training_step returns the loss, a plain
+    torch.optim.Adam from configure_optimizers() steps the parameters (their grads are views of the flat buffer)."""
+    from hosnerf_amd.select_option import select_model
+    lit = select_model("state_mipnerf360", _basedir())
+    lit.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+    lit = lit.to(dev)
+    opt = lit.configure_optimizers()
+    batch = {k: v.to(dev) for k, v in synth.stage1_batch(256, seed=1).items()}
+    batch["target"] = torch.full_like(batch["target"], 0.25)
+    losses = []
+    for i in range(12):
+        opt.zero_grad(set_to_none=False)
+        loss = lit.training_step(batch, i)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(lit.parameters(), 0.001)
+        for g in opt.param_groups:
+            g["lr"] = 5e-4
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and min(losses[-3:]) < losses[0] - 1e-4, losses
+    assert abs(lit.learning_rate(0) - 2e-5) < 1e-9 and abs(lit.learning_rate(512) - 2e-3) / 2e-3 < 0.02
