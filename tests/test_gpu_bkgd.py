@@ -453,7 +453,8 @@ def test_no_cpu_fallback(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (2048, 257, 1024), (512, 128, 576), (4096, 1024, 64)])
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (2048, 257, 1024), (512, 128, 576), (4096, 1024, 64), (448, 257, 576),
+                                   (96, 33, 32)])
 def test_planes_gemm_matches_fp64(M, N, K):
     """hos_split_planes* + hos_linearp_{fwd,dgrad,wgrad}: pre-split 16-bit hi/lo planes, LDS-DMA staging, transpose
     reads for the weight gradient.  fp32-grade accuracy against fp64, incl. ragged N and both tile widths."""
