@@ -125,6 +125,23 @@ int hos_linearp_wgrad(const void* dZ, int lddz, const void* X, int ldx, int x_co
                       int M, int N, int K, int splits, float* ws, long long ws_floats, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-frame ray set-up on the device (core/utils/camera_util.py:154-265 of stage 3).
+ * Kinv9 / R9 / T3 / bounds6 are HOST pointers (camera scalars are passed to the kernel by value); the ray arrays
+ * are device pointers.
+ * ------------------------------------------------------------------------------------------ */
+
+/* get_rays_from_KRT (C:154-183) and, when viewdirs / radii are non-NULL, get_rays_from_KRT_bkg (C:185-216):
+ * rays_o, rays_d, viewdirs [H*W,3], radii [H*W] for an H x W image, row-major pixels (pixel p = row*W + col). */
+int hos_camera_rays(const float* Kinv9, const float* R9, const float* T3, int H, int W, float* rays_o, float* rays_d,
+                    float* viewdirs, float* radii, hos_stream_t stream);
+
+/* rays_intersect_3d_bbox (C:219-265) for every ray: mask[p] = 1 iff exactly two of the six plane hits lie inside the
+ * box (bounds6 = min xyz, max xyz; grown by 0.01), near/far [n] (0 where invalid).  Like the reference it clamps
+ * direction components with magnitude < 1e-5 to 1e-5 IN PLACE in rays_d. */
+int hos_rays_aabb(const float* rays_o, float* rays_d, int64_t n, const float* bounds6, float* near, float* far,
+                  unsigned char* mask, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * ConvTranspose3d(kernel 4, stride 2, padding 1) of the motion-weight volume decoder (network_util.py:21-59,
  * deconv_vol_decoder.py:17-42) = GEMM (hos_linear_*) + these two gathers; activations are channel-last [voxel][C].
  * ------------------------------------------------------------------------------------------ */

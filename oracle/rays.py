@@ -1,0 +1,50 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the reference's per-frame ray set-up, numpy like the
+reference: `core/utils/camera_util.py` of stage 3 (`C:` below).  Imported only by tests.
+
+  rays_from_krt      C:154-183  get_rays_from_KRT       camera origin + per-pixel directions (|d_z| = 1 in camera space)
+  rays_from_krt_bkg  C:185-216  get_rays_from_KRT_bkg   same + unit view directions + mip-NeRF radii (row differences)
+  rays_aabb          C:219-265  rays_intersect_3d_bbox  six-plane AABB test, rays with exactly two hits, near/far
+"""
+import numpy as np
+
+
+def rays_from_krt(H, W, K, R, T):
+    rays_o = -np.dot(R.T, T).ravel()                                         # C:172
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")   # C:174-176
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
+    pixel_camera = np.dot(xy1, np.linalg.inv(K).T)                           # C:178
+    pixel_world = np.dot(pixel_camera - T.ravel(), R)                        # C:179
+    rays_d = pixel_world - rays_o[None, None]                                # C:181
+    return np.broadcast_to(rays_o, rays_d.shape), rays_d
+
+
+def rays_from_krt_bkg(H, W, K, R, T):
+    rays_o, rays_d = rays_from_krt(H, W, K, R, T)
+    viewdirs = rays_d / np.linalg.norm(rays_d, axis=-1, keepdims=True)       # C:210
+    dx = np.sqrt(np.sum((rays_d[:-1, :, :] - rays_d[1:, :, :]) ** 2, -1))    # C:212
+    dx = np.concatenate([dx, dx[-2:-1, :]], 0)                               # C:213 (last row repeats row H-2)
+    radii = dx[..., None] * 2 / np.sqrt(12)                                  # C:214
+    return rays_o, rays_d, viewdirs, radii
+
+
+def rays_aabb(bounds, ray_o, ray_d):
+    """bounds [2,3] (min, max); returns near, far for the valid rays and the [N] validity mask.
+    NOTE: like the reference this clamps tiny direction components of ray_d IN PLACE (C:238)."""
+    bounds = np.asarray(bounds) + np.array([-0.01, 0.01])[:, None]           # C:234
+    nominator = bounds[None] - ray_o[:, None]
+    ray_d[np.abs(ray_d) < 1e-5] = 1e-5                                       # C:238
+    d_intersect = (nominator / ray_d[:, None]).reshape(-1, 6)
+    p_intersect = d_intersect[..., None] * ray_d[:, None] + ray_o[:, None]
+    min_x, min_y, min_z, max_x, max_y, max_z = bounds.ravel()
+    eps = 1e-6
+    p_mask = ((p_intersect[..., 0] >= (min_x - eps)) * (p_intersect[..., 0] <= (max_x + eps)) *
+              (p_intersect[..., 1] >= (min_y - eps)) * (p_intersect[..., 1] <= (max_y + eps)) *
+              (p_intersect[..., 2] >= (min_z - eps)) * (p_intersect[..., 2] <= (max_z + eps)))     # C:245-250
+    mask_at_box = p_mask.sum(-1) == 2                                        # C:252
+    p_intervals = p_intersect[mask_at_box][p_mask[mask_at_box]].reshape(-1, 2, 3)
+    o = ray_o[mask_at_box]
+    d = ray_d[mask_at_box]
+    norm_ray = np.linalg.norm(d, axis=1)
+    d0 = np.linalg.norm(p_intervals[:, 0] - o, axis=1) / norm_ray
+    d1 = np.linalg.norm(p_intervals[:, 1] - o, axis=1) / norm_ray
+    return np.minimum(d0, d1), np.maximum(d0, d1), mask_at_box
