@@ -40,7 +40,15 @@ def _worker(rank, world, port, basedir, out_dir):
     expect = sum(r + 1 for r in range(world))
     ok = all(torch.all(p.grad == expect * (1 + (i % 3))) for i, p in enumerate(m.parameters()))
     pad_ok = float(m.mlps[2]._views.W.view(m.flat_grad)[:, 283:].abs().max()) == 0     # padding never becomes non-zero
-    torch.save({"ok": bool(ok), "pad_ok": pad_ok, "sum": float(m.flat_grad.double().sum())}, os.path.join(out_dir, f"r{rank}.pt"))
+    # inference side: contiguous ray ranges of a frame + one RGB all-gather (a frame of 101 rays: ragged over 2 ranks)
+    from hosnerf_amd.train import gather_frame, shard_frame
+    n = 101
+    frame = torch.arange(n * 3, dtype=torch.float32).view(n, 3)
+    idx, per = shard_frame(n, rank, world)
+    full = gather_frame(frame[idx] * 2.0, n)           # "render" = times two
+    gather_ok = bool(torch.equal(full, frame * 2.0)) and per == 51
+    torch.save({"ok": bool(ok), "pad_ok": pad_ok, "gather_ok": gather_ok, "sum": float(m.flat_grad.double().sum())},
+               os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -51,5 +59,5 @@ def test_flat_grad_allreduce_world2():
     out = tempfile.mkdtemp(prefix="hos_dist_out_")
     mp.spawn(_worker, args=(2, _free_port(), d, out), nprocs=2, join=True)
     res = [torch.load(os.path.join(out, f"r{r}.pt")) for r in range(2)]
-    assert all(r["ok"] and r["pad_ok"] for r in res)
+    assert all(r["ok"] and r["pad_ok"] and r["gather_ok"] for r in res)
     assert res[0]["sum"] == res[1]["sum"]
