@@ -254,19 +254,26 @@ namespace {
 
 // value and spatial gradient (w.r.t. the *normalised* grid coordinate) of the zero-padded trilinear tap;
 // optionally scatters g_out * tapweight into g_vol (same geometry as trilinear_zero).
+// The scatter is run-aggregated: the lanes of a wave are consecutive samples of a ray, so neighbouring lanes mostly fall
+// into the same voxel cell (~3 samples per cell); a segmented scan over runs of equal cell index sums their eight tap
+// contributions and only the last lane of a run issues the atomics.  An fp32 atomic costs one request per cache line it
+// touches (scripts/probe/atomic_probe.hip), and these are scattered -- each bone taps its own position --, so the
+// number of issuing lanes is what matters.  MUST be called by all 64 lanes of the wave (uses shuffles).
 __device__ __forceinline__ float trilinear_zero_grad(const float* __restrict__ vol, float* __restrict__ g_vol, int V,
-                                                     float gx, float gy, float gz, float g_out, float (&dgrid)[3]) {
+                                                     float gx, float gy, float gz, float g_out, float (&dgrid)[3], bool scatter) {
+    const int lane = threadIdx.x & 63;
     const float half = 0.5f * (float)(V - 1);
     const float ix = ((gx + 1.f) / 2.f) * (float)(V - 1);
     const float iy = ((gy + 1.f) / 2.f) * (float)(V - 1);
     const float iz = ((gz + 1.f) / 2.f) * (float)(V - 1);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     dgrid[0] = dgrid[1] = dgrid[2] = 0.f;
-    if (!(fx >= -1.f && fx <= (float)V && fy >= -1.f && fy <= (float)V && fz >= -1.f && fz <= (float)V)) return 0.f;
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const bool inside = (fx >= -1.f && fx <= (float)V && fy >= -1.f && fy <= (float)V && fz >= -1.f && fz <= (float)V);
+    const int x0 = inside ? (int)fx : 0, y0 = inside ? (int)fy : 0, z0 = inside ? (int)fz : 0;
     const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
     const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
     float out = 0.f;
+    float contrib[8];
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
@@ -274,7 +281,8 @@ __device__ __forceinline__ float trilinear_zero_grad(const float* __restrict__ v
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
-                if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
+                float cw = 0.f;
+                if (inside && x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V) {
                     const float wx = dx ? wx1 : wx0, wy = dy ? wy1 : wy0, wz = dz ? wz1 : wz0;
                     const size_t idx = ((size_t)z * V + y) * V + x;
                     const float v = vol[idx];
@@ -282,11 +290,42 @@ __device__ __forceinline__ float trilinear_zero_grad(const float* __restrict__ v
                     dgrid[0] += v * (dx ? 1.f : -1.f) * wy * wz;
                     dgrid[1] += v * wx * (dy ? 1.f : -1.f) * wz;
                     dgrid[2] += v * wx * wy * (dz ? 1.f : -1.f);
-                    if (g_vol != nullptr && g_out != 0.f)
-                        __hip_atomic_fetch_add(g_vol + idx, g_out * (wx * wy * wz), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cw = g_out * (wx * wy * wz);
                 }
+                contrib[dz * 4 + dy * 2 + dx] = cw;
             }
     dgrid[0] *= half; dgrid[1] *= half; dgrid[2] *= half;
+    if (g_vol != nullptr) {       // wave-uniform
+        const bool act = scatter && inside && g_out != 0.f;
+        const int key = act ? ((z0 + 1) * (V + 2) + (y0 + 1)) * (V + 2) + (x0 + 1) : -1 - lane;      // cell index; unique when idle
+        const int key_prev = __shfl_up(key, 1, 64);
+        int flag = (lane == 0 || key != key_prev) ? 1 : 0;                   // head of a run
+        const int key_next = __shfl_down(key, 1, 64);
+        const bool tail = (lane == 63) || (key_next != key);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {                             // segmented inclusive scan of the 8 tap sums
+            const int f_up = __shfl_up(flag, off, 64);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float v_up = __shfl_up(contrib[t], off, 64);
+                if (lane >= off && !flag) contrib[t] += v_up;
+            }
+            if (lane >= off) flag |= f_up;
+        }
+        if (act && tail) {
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                        const float cw = contrib[dz * 4 + dy * 2 + dx];
+                        if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V && cw != 0.f)
+                            __hip_atomic_fetch_add(g_vol + ((size_t)z * V + y) * V + x, cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+        }
+    }
     return out;
 }
 
@@ -343,8 +382,8 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
                 // d loss / d w_i
                 const float gw = ((gx_ * qx + gy_ * qy + gz_ * qz) - clampg * gdot_xs) / den + gm;
                 float dg[3];
-                const float w = trilinear_zero_grad(vol + i * V3, live ? g_vol + i * V3 : nullptr, V, (qx - sB[0]) * sB[3] - 1.f,
-                                                    (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f, gw, dg);
+                const float w = trilinear_zero_grad(vol + i * V3, g_vol + i * V3, V, (qx - sB[0]) * sB[3] - 1.f,
+                                                    (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f, gw, dg, live);
                 // d loss / d q_i = g_xs * w/den + gw * dw/dq   (all zero for dead lanes: their g_xskel / g_mask are 0)
                 gq[0] = gx_ * w / den + gw * dg[0] * sB[3];
                 gq[1] = gy_ * w / den + gw * dg[1] * sB[4];
