@@ -433,7 +433,11 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) sAcc[i] = 0.f;
     if (threadIdx.x < 3) { sB[threadIdx.x] = bbox_min[threadIdx.x]; sB[3 + threadIdx.x] = bbox_scale[threadIdx.x]; }
     __syncthreads();
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // persistent workgroups: a block walks 256-point chunks and keeps the R/T gradient sums in LDS across them, so the
+    // 12 K global atomics at the end (all blocks hit the same 12 K addresses) are issued once per block, not per chunk
+    const long nchunks = (P + 255) / 256;
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long p = chunk * 256 + threadIdx.x;
     const bool live = p < P;
     const long pp = live ? p : P - 1;
     const int lane = threadIdx.x & 63;
@@ -577,6 +581,7 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
     }
     if (live && g_cnl) { g_cnl[pp * 3] = gc[0]; g_cnl[pp * 3 + 1] = gc[1]; g_cnl[pp * 3 + 2] = gc[2]; }
     __syncthreads();
+    }   // chunk loop
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) {
         const int b = i / 12, c = i % 12;
         const float v = sAcc[i];
@@ -665,7 +670,8 @@ extern "C" int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, con
     if (!cnl_pts || !R_fwd || !T_fwd || !vol_cl || !bbox_min || !bbox_scale || !g_x_deform || !g_R || !g_T || P <= 0)
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || CL < K || (CL & 3) || V < 2) return HOS_E_SHAPE;
-    hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+    const long lb_chunks = (P + 255) / 256;
+    hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)(lb_chunks < 256 ? lb_chunks : 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), cnl_pts, R_fwd, T_fwd, vol_cl, V, CL, bbox_min, bbox_scale,
                        (long)P, K, g_x_deform, g_cnl, g_vol_cl, g_R, g_T);
     return hos_launch_status();
