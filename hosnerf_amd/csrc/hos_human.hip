@@ -342,7 +342,10 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) sAcc[i] = 0.f;
     if (threadIdx.x < 3) { sB[threadIdx.x] = bbox_min[threadIdx.x]; sB[3 + threadIdx.x] = bbox_scale[threadIdx.x]; }
     __syncthreads();
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // persistent workgroups (see lbs_forward_bwd_kernel): the R/T gradient sums stay in LDS across 256-point chunks
+    const long nchunks = (P + 255) / 256;
+    for (long chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    const long p = chunk * 256 + threadIdx.x;
     const bool live = p < P;
     const long pp = live ? p : P - 1;
     const int lane = threadIdx.x & 63;
@@ -410,6 +413,7 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
         }
         __syncthreads();
     }
+    }   // chunk loop
     __syncthreads();
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) {
         const int b = i / 12, c = i % 12;
@@ -657,7 +661,8 @@ extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const
     if (!pts || !R || !T || !vol || !bbox_min || !bbox_scale || !g_x_skel || !g_mask || !g_vol || !g_R || !g_T || P <= 0)
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || V < 2) return HOS_E_SHAPE;
-    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+    const long sw_chunks = (P + 255) / 256;
+    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)(sw_chunks < 256 ? sw_chunks : 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K, g_x_skel,
                        g_mask, g_vol, g_R, g_T);
     return hos_launch_status();
