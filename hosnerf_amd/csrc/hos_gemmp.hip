@@ -349,6 +349,12 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt, stage);
     };
 
+#ifdef HOS_TRACE   // block timeline: entry / loop start / loop end / exit of workgroups 0 and 300 (second round)
+#define HOS_BSTAMP(slot) do { if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && a.f32.aux) reinterpret_cast<long long*>(a.f32.aux)[256 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 4 + (slot)] = clock64(); } while (0)
+#else
+#define HOS_BSTAMP(slot) do {} while (0)
+#endif
+    HOS_BSTAMP(0);
     issue_tile(kt_begin, 0);
     if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -390,6 +396,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     } while (0)
 
     unsigned so = 0;                     // byte offset of the stage holding tile kt
+    HOS_BSTAMP(1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const unsigned sn = STAGE - so;
         const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         HOS_STAMP(7);
         so = sn;
     }
+    HOS_BSTAMP(2);
 #undef HOS_GROUP
 #undef HOS_STAMP
 #undef HOS_MMA
@@ -549,6 +557,11 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 }
             }
     }
+#ifdef HOS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    HOS_BSTAMP(3);
+#undef HOS_BSTAMP
 }
 
 template <int BN, int EPI, typename EIN, bool TR>

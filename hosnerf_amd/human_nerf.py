@@ -479,16 +479,17 @@ class Network(FlatModule):
         return g_cnl
 
     # ------------------------------------------------------------------ reference-style forward
-    def forward(self, rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None, near=None, far=None,
-                iter_val=1e7, t_rand=None, **kwargs):
+    def frame_prologue(self, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=None, iter_val=1e7, **kwargs):
+        """The per-FRAME part of `forward` (N:589-671): pose refinement, motion bases, band weights, pose condition and the
+        motion-weight volume.  None of it depends on the rays, so the evaluation loops (which call the reference network
+        once per 8192-ray chunk, M:1334-1352, and rebuild the 253 MB deconvolution volume every time) compute it once per
+        frame and pass it to `forward(prologue=...)`."""
         cfg = self.cfg
-        dev = rays.device
         K = cfg.total_bones
         iter_v = float(torch.as_tensor(iter_val).reshape(-1)[0])
         time = float(kwargs["time"])
         is_train = bool(kwargs["is_train"])
         flow = time > 0.005 and is_train
-        state = select_state(time, self.transitions_times)
         nr_kick = cfg.non_rigid_motion_mlp.kick_in_iter
 
         def cond_of(pv):
@@ -504,14 +505,26 @@ class Network(FlatModule):
         if iter_v >= cfg.pose_decoder.get("kick_in_iter", 0):
             Rs, Ts = self._pose_refine(Rs, Ts, pv)
         Rb_, Tb_, Rf_, Tf_ = self._motion_basis(Rs, Ts, cnl_gtfms)
-        R_b, T_b, R_f, T_f = Rb_[0], Tb_[0], Rf_[0], Tf_[0]
+        pro = {"flow": flow, "state": select_state(time, self.transitions_times), "R_b": Rb_[0], "T_b": Tb_[0],
+               "R_f": Rf_[0], "T_f": Tf_[0], "band_w": self._band_weights(iter_v, dst_Rs.device),
+               "cond": cond_of(dst_posevec).contiguous(), "vol": self._motion_weight_volume(motion_weights_priors)}
         if flow:
-            R_fp, T_fp = Rf_[1], Tf_[1]
-            cond_prev = cond_of(kwargs["dst_posevec_prev"]).contiguous()
-        band_w = self._band_weights(iter_v, dev)
-        cond = cond_of(dst_posevec).contiguous()
-        vol = self._motion_weight_volume(motion_weights_priors)
-        vol_cl = None
+            pro.update(R_fp=Rf_[1], T_fp=Tf_[1], cond_prev=cond_of(kwargs["dst_posevec_prev"]).contiguous())
+        # channel-last copy of the K bone channels for the K-channel forward tap
+        pro["vol_cl"] = F.pad(pro["vol"][:K].permute(1, 2, 3, 0), (0, 32 - K)).contiguous()
+        return pro
+
+    def forward(self, rays, dst_Rs=None, dst_Ts=None, cnl_gtfms=None, motion_weights_priors=None, dst_posevec=None, near=None,
+                far=None, iter_val=1e7, t_rand=None, prologue=None, with_cycle: bool = True, **kwargs):
+        cfg = self.cfg
+        dev = rays.device
+        K = cfg.total_bones
+        pro = prologue if prologue is not None else self.frame_prologue(
+            dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec=dst_posevec, iter_val=iter_val, **kwargs)
+        flow, state, band_w, cond, vol, vol_cl = pro["flow"], pro["state"], pro["band_w"], pro["cond"], pro["vol"], pro["vol_cl"]
+        R_b, T_b, R_f, T_f = pro["R_b"], pro["T_b"], pro["R_f"], pro["T_f"]
+        if flow:
+            R_fp, T_fp, cond_prev = pro["R_fp"], pro["T_fp"], pro["cond_prev"]
         bmin = kwargs["cnl_bbox_min_xyz"].contiguous()
         bscale = kwargs["cnl_bbox_scale_xyz"].contiguous()
 
@@ -540,8 +553,6 @@ class Network(FlatModule):
             b = z.shape[0]
             ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
                    "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
-            if vol_cl is None:   # channel-last copy of the K bone channels for the K-channel forward tap
-                vol_cl = F.pad(vol[:K].permute(1, 2, 3, 0), (0, 32 - K)).contiguous()
 
             def fwd_branch(c_pts, Rf_, Tf_, cond_):
                 if grad:
@@ -552,13 +563,15 @@ class Network(FlatModule):
 
             if flow:                                                               # N:474-502
                 ret["deform_pts_prev_final"] = fwd_branch(cnl, R_fp, T_fp, cond_prev).view(b, N, 3)
-            sel = torch.nonzero(mask.detach() > 0.005).reshape(-1)                 # N:505-536 (data-dependent size)
-            if sel.numel() > 0:
-                ret["deform_pts_final"] = fwd_branch(cnl.index_select(0, sel), R_f, T_f, cond)
-                ret["observe_pts"] = pts.view(-1, 3).index_select(0, sel)
-            else:
-                ret["deform_pts_final"] = pts[0, 0][None]
-                ret["observe_pts"] = pts[0, 0][None]
+            # N:505-536 (data-dependent size); the frame loops of eval.py never read the cycle outputs and switch them off
+            if with_cycle:
+                sel = torch.nonzero(mask.detach() > 0.005).reshape(-1)
+                if sel.numel() > 0:
+                    ret["deform_pts_final"] = fwd_branch(cnl.index_select(0, sel), R_f, T_f, cond)
+                    ret["observe_pts"] = pts.view(-1, 3).index_select(0, sel)
+                else:
+                    ret["deform_pts_final"] = pts[0, 0][None]
+                    ret["observe_pts"] = pts[0, 0][None]
             if not flow:
                 ret["z_vals"] = z
                 ret["rays_d"] = rays_d[sl]

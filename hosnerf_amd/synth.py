@@ -239,8 +239,26 @@ def human_batch(num_rays: int = 2048, seed: int = 777, time: float = 0.5, is_tra
         "iter_val": torch.full((1,), float(iter_val)),
         "rays_o_bkg": t(o_b), "rays_d_bkg": t(d_b), "viewdirs_bkg": t(vd), "radii": t(radii),
         "newsmpl_to_scale_world": t(A), "target_rgbs": t(rs.uniform(0, 1, size=(num_rays, 3))),
-        "canonical_joints": t(J),
+        "canonical_joints": t(J), "dst_bbox_min_xyz": t(pmin), "dst_bbox_max_xyz": t(pmax),
     }
+
+
+def eval_camera(H: int, W: int, hb: Dict[str, torch.Tensor]):
+    """A synthetic evaluation camera for the subject of `human_batch`: pinhole K, the SMPL-space extrinsics E and the
+    background-world extrinsics E_colmap that see the same pixels (what freeview.py:226-239 derives from the dataset's
+    cameras), as float64 host arrays."""
+    f = 0.45 * H                                          # wide enough that the box covers about a third of the frame
+    K = np.array([[f, 0.0, 0.5 * W], [0.0, f, 0.5 * H], [0.0, 0.0, 1.0]])
+    c = np.array([0.3, 0.2, 3.0])                         # the camera centre `human_batch` aims its rays from
+    R = np.diag([1.0, -1.0, -1.0])                        # x right, y down, z forward = -z of the SMPL frame
+    E = np.eye(4); E[:3, :3] = R; E[:3, 3] = -R @ c
+    A = hb["newsmpl_to_scale_world"].double().numpy()
+    s = np.cbrt(np.linalg.det(A[:3, :3]))
+    Rw = A[:3, :3] / s
+    Rc = R @ Rw.T
+    cb = A[:3, :3] @ c + A[:3, 3]
+    Ec = np.eye(4); Ec[:3, :3] = Rc; Ec[:3, 3] = -Rc @ cb
+    return K, E, Ec
 
 
 def human_state_dict(seed: int = 777, n_states: int = 2, small_decoder_scale: float = 1.0) -> Dict[str, torch.Tensor]:

@@ -47,6 +47,43 @@ def _worker(rank, world, port, basedir, out_dir):
     idx, per = shard_frame(n, rank, world)
     full = gather_frame(frame[idx] * 2.0, n)           # "render" = times two
     gather_ok = bool(torch.equal(full, frame * 2.0)) and per == 51
+    # the frame loop of eval.render_frame over the group, with a stand-in renderer (rgb = 2 * origin / 3 * origin): every
+    # rank must end up with the whole frame, ragged chunks and ragged per-rank shares included
+    from hosnerf_amd import eval as ev
+
+    class _Stub:
+        training = True
+
+        class cfg:
+            perturb = 1.0
+
+        class human:
+            @staticmethod
+            def frame_prologue(**kw):
+                return {"calls": 1}
+
+        def eval(self): self.training = False
+        def train(self, mode=True): self.training = mode
+        def render(self, b, **kw):
+            assert kw["prologue"] == {"calls": 1} and kw["with_cycle"] is False and b["rays"].shape[1] == b["near"].shape[0]
+            return {"rgb": b["rays_o_bkg"] * 2.0}
+        def render_bkg_only(self, bb, **kw): return bb["rays_o"] * 3.0
+
+    g = torch.Generator().manual_seed(5)
+    Hh, Ww = 3, 29
+    rm = torch.rand(Hh * Ww, generator=g) > 0.55
+    nf, nb = int(rm.sum()), int((~rm).sum())
+    fr = {"img_height": Hh, "img_width": Ww, "ray_mask": rm, "ray_mask_bkg": ~rm, "time": torch.tensor(0.5), "bgcolor": torch.zeros(3),
+          "rays": torch.rand(2, nf, 3, generator=g), "near": torch.rand(nf, 1, generator=g), "far": torch.rand(nf, 1, generator=g),
+          "rays_o_bkg": torch.rand(nf, 3, generator=g), "rays_d_bkg": torch.rand(nf, 3, generator=g),
+          "viewdirs_bkg": torch.rand(nf, 3, generator=g), "radii": torch.rand(nf, 1, generator=g),
+          "rays_o_bkg_only": torch.rand(nb, 3, generator=g), "rays_d_bkg_only": torch.rand(nb, 3, generator=g),
+          "viewdirs_bkg_only": torch.rand(nb, 3, generator=g), "radii_bkg_only": torch.rand(nb, 1, generator=g)}
+    stub = _Stub()
+    img = ev.render_frame(stub, fr, chunk_bkg=7, group=dist.group.WORLD)
+    frame_ok = bool(torch.equal(img[rm], fr["rays_o_bkg"] * 2.0) and torch.equal(img[~rm], fr["rays_o_bkg_only"] * 3.0)) \
+        and stub.training and stub.cfg.perturb == 1.0
+    gather_ok = gather_ok and frame_ok
     torch.save({"ok": bool(ok), "pad_ok": pad_ok, "gather_ok": gather_ok, "sum": float(m.flat_grad.double().sum())},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.destroy_process_group()
