@@ -68,3 +68,64 @@ def rays_intersect_3d_bbox(bounds, ray_o: torch.Tensor, ray_d: torch.Tensor):
     call("hos_rays_aabb", ptr(ray_o), ptr(ray_d), n, bp, ptr(near), ptr(far), mask.data_ptr())
     m = mask.bool()
     return near[m], far[m], m
+
+
+# ------------------------------------------------------------------------------------------ training item: patches
+def get_patch_ray_indices(N_patch: int, ray_mask: torch.Tensor, subject_mask: torch.Tensor, bbox_mask: torch.Tensor,
+                          patch_size: int, H: int, W: int, sample_subject_ratio: float, rng=np.random):
+    """`Dataset.get_patch_ray_indices` (core/data/human_nerf/train.py:225-332) with the masks resident on the device.
+
+    The random decisions are the reference's, drawn from the same numpy stream in the same order (`rng.rand(1)`, then
+    `rng.choice(n_candidates, size=[1], replace=False)` -- n_candidates is the only thing read back from the device, twice
+    per item); everything that touches pixels stays on the device.  Returns (select_inds [N*P*P] int64 into the
+    box-compacted ray arrays, pixel indices [N*P*P] into the frame, patch_masks [N,P,P] bool, patch_div_indices [N+1]).
+    Quirks kept: a patch is NOT intersected with the box (T:323 "to keep the patch size"), so pixels outside it map to
+    the previous box ray through `cumsum(ray_mask) - 1`, and -1 wraps to the last ray like a numpy index."""
+    dev = ray_mask.device
+    subject = subject_mask.reshape(-1).to(dev)
+    excl = bbox_mask.reshape(-1).to(dev) & ~subject                                   # T:238-241
+    cand = (torch.nonzero(subject).reshape(-1), torch.nonzero(excl).reshape(-1))      # np.where order = row major
+    masked_indices = torch.cumsum(ray_mask.reshape(-1).to(torch.int64), 0) - 1         # T:327
+    P = int(patch_size)
+    dy, dx = torch.meshgrid(torch.arange(P, device=dev), torch.arange(P, device=dev), indexing="ij")
+    pix = []
+    for _ in range(N_patch):
+        which = 0 if rng.rand(1)[0] < sample_subject_ratio else 1                      # T:256-259
+        n = int(cand[which].shape[0])
+        centre = cand[which][int(rng.choice(n, size=[1], replace=False)[0])]           # T:297-301
+        cy, cx = centre // W, centre % W
+        x_min = torch.clamp(cx - P // 2, 0, W - P)                                     # T:304-311
+        y_min = torch.clamp(cy - P // 2, 0, H - P)
+        pix.append(((y_min + dy) * W + (x_min + dx)).reshape(-1))
+    pix = torch.cat(pix, 0)
+    sel = masked_indices[pix]
+    sel = torch.where(sel < 0, sel + masked_indices[-1] + 1, sel)                      # numpy's negative index
+    patch_masks = torch.ones(N_patch, P, P, dtype=torch.bool, device=dev)              # T:323, :330
+    div = torch.arange(N_patch + 1, dtype=torch.int64) * (P * P)
+    return sel, pix, patch_masks, div
+
+
+_PATCH_KEYS = ("near", "far", "rays_o_bkg", "rays_d_bkg", "viewdirs_bkg", "radii", "ray_img", "ray_grid")
+
+
+def sample_patch_rays(item: dict, img: torch.Tensor, subject_mask: torch.Tensor, N_patches: int, patch_size: int,
+                      sample_subject_ratio: float, rng=np.random) -> dict:
+    """`Dataset.sample_patch_rays` (T:410-436): pick the patches and gather every per-ray array of the item
+    (`rays` [2,n,3] and the `_PATCH_KEYS` present, all box-compacted as `eval.frame_rays` returns them).  Returns the
+    item with those arrays replaced by the selected rays plus `target_patches` [N,P,P,3], `patch_masks`,
+    `patch_div_indices` and `target_rgbs` (= the gathered `ray_img`)."""
+    H, W = int(item["img_height"]), int(item["img_width"])
+    rm = item["ray_mask"]
+    sel, pix, masks, div = get_patch_ray_indices(N_patches, rm, subject_mask, rm.view(H, W), patch_size, H, W,
+                                                 sample_subject_ratio, rng)
+    out = dict(item)
+    out["rays"] = item["rays"].index_select(1, sel)
+    for k in _PATCH_KEYS:
+        if k in item:
+            out[k] = item[k].index_select(0, sel)
+    if "ray_img" in out:
+        out["target_rgbs"] = out["ray_img"]
+    out["target_patches"] = img.reshape(-1, img.shape[-1]).index_select(0, pix).view(N_patches, patch_size, patch_size, -1)
+    out["patch_masks"] = masks
+    out["patch_div_indices"] = div
+    return out

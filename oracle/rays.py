@@ -4,6 +4,7 @@ reference: `core/utils/camera_util.py` of stage 3 (`C:` below).  Imported only b
   rays_from_krt      C:154-183  get_rays_from_KRT       camera origin + per-pixel directions (|d_z| = 1 in camera space)
   rays_from_krt_bkg  C:185-216  get_rays_from_KRT_bkg   same + unit view directions + mip-NeRF radii (row differences)
   rays_aabb          C:219-265  rays_intersect_3d_bbox  six-plane AABB test, rays with exactly two hits, near/far
+  patch_ray_indices  T:225-332  Dataset.get_patch_ray_indices  training item: random P x P patches -> ray indices
 """
 import numpy as np
 
@@ -48,3 +49,25 @@ def rays_aabb(bounds, ray_o, ray_d):
     d0 = np.linalg.norm(p_intervals[:, 0] - o, axis=1) / norm_ray
     d1 = np.linalg.norm(p_intervals[:, 1] - o, axis=1) / norm_ray
     return np.minimum(d0, d1), np.maximum(d0, d1), mask_at_box
+
+
+def patch_ray_indices(N_patch, ray_mask, subject_mask, bbox_mask, patch_size, H, W, sample_subject_ratio, rng=np.random):
+    """T:225-332 (`Dataset.get_patch_ray_indices` + `_get_patch_ray_indices`, T = core/data/human_nerf/train.py of stage 3).
+    Returns select_inds [N*P*P] (indices into the box-compacted ray arrays, possibly -1), xy_min [N,2], patch masks
+    [N,P,P] (all True: the patch is not intersected with the box, T:323) and patch_div_indices [N+1]."""
+    excl = np.bitwise_and(bbox_mask, np.bitwise_not(subject_mask))                   # T:238-241
+    sels, xy, masks, div = [], [], [], [0]
+    for _ in range(N_patch):
+        cand = subject_mask if rng.rand(1)[0] < sample_subject_ratio else excl       # T:256-259
+        ys, xs = np.where(cand)                                                      # T:294
+        k = rng.choice(ys.shape[0], size=[1], replace=False)[0]                      # T:297-298
+        half = patch_size // 2
+        x0 = np.clip(xs[k] - half, 0, W - patch_size)                                # T:304-311
+        y0 = np.clip(ys[k] - half, 0, H - patch_size)
+        m = np.zeros((H, W), dtype=bool)
+        m[y0:y0 + patch_size, x0:x0 + patch_size] = True                             # T:313-314
+        sels.append((np.cumsum(ray_mask) - 1)[np.where(m.reshape(-1))])              # T:322-328
+        xy.append(np.array([x0, y0]))
+        masks.append(m[y0:y0 + patch_size, x0:x0 + patch_size])
+        div.append(div[-1] + sels[-1].shape[0])
+    return np.concatenate(sels, 0), np.stack(xy, 0), np.stack(masks, 0), np.array(div)

@@ -132,3 +132,32 @@ def test_render_frame_invariances(dev, hos):
     with ev.evaluating(hos):
         e = hos.render_bkg_only(bb)
     assert float((d - e).abs().max()) < 1e-6
+
+
+def test_training_item_on_device(dev, hos):
+    """the stage-3 training item (frame rays -> box test -> random patches) built on the device gives the
+    renderer the reference's batch keys; the patch choice does not depend on where the masks live."""
+    from hosnerf_amd import eval as ev, rays as R
+    H, W, P, N = 72, 64, 16, 2
+    fr, hb = make_frame(dev, H, W, seed=47)
+    n_box = int(fr["ray_mask"].sum())
+    g = torch.Generator().manual_seed(1)
+    img = torch.rand(H, W, 3, generator=g).to(dev)
+    fr["ray_img"] = img.view(-1, 3)[fr["ray_mask"]]
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    subject = (((yy - H / 2) / (H / 4)) ** 2 + ((xx - W / 2) / (W / 6)) ** 2 < 1.0)
+    np.random.seed(5)
+    item = R.sample_patch_rays(fr, img, subject.to(dev), N, P, 0.8)
+    np.random.seed(5)
+    cpu_fr = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in fr.items()}
+    item_cpu = R.sample_patch_rays(cpu_fr, img.cpu(), subject, N, P, 0.8)
+    assert item["rays"].shape == (2, N * P * P, 3) and item["near"].shape == (N * P * P, 1)
+    for k in ("rays", "near", "far", "rays_o_bkg", "radii", "target_patches", "target_rgbs"):
+        assert torch.equal(item[k].cpu(), item_cpu[k]), k
+    assert item["patch_div_indices"].tolist() == [0, P * P, 2 * P * P] and bool(item["patch_masks"].all())
+    assert item["rays_o_bkg_only"].shape[0] == H * W - n_box                  # frame-level keys pass through unchanged
+    b = dict(item)
+    b["is_train"] = False
+    with ev.evaluating(hos):
+        out = hos.render(b, randomized=False, is_train=False, with_cycle=False)
+    assert out["rgb"].shape == (N * P * P, 3) and bool(torch.isfinite(out["rgb"]).all())

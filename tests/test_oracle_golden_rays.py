@@ -24,3 +24,52 @@ def test_rays_aabb():
     assert np.array_equal(mask, G["mask"])
     assert np.abs(near - G["near"]).max() < 1e-6 and np.abs(far - G["far"]).max() < 1e-6
     assert (far >= near).all() and 0 < mask.sum() < mask.size
+
+
+# ------------------------------------------------------------------ training item: patch selection (train.py:225-436)
+GP = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patches.npz"))
+
+
+def _patch_args():
+    H, W, P, N = (int(GP[k]) for k in ("H", "W", "P", "N"))
+    return H, W, P, N, float(GP["ratio"]), GP["bbox_mask"], GP["subject_mask"]
+
+
+def test_oracle_patch_indices_bit_exact():
+    H, W, P, N, ratio, bbox, subj = _patch_args()
+    for s in GP["seeds"]:
+        np.random.seed(int(s))
+        sel, xy, masks, div = orays.patch_ray_indices(N, bbox.reshape(-1), subj, bbox, P, H, W, ratio)
+        assert np.array_equal(sel, GP[f"s{s}_select_inds"]) and np.array_equal(xy, GP[f"s{s}_xy_min"])
+        assert np.array_equal(masks, GP[f"s{s}_mask"]) and np.array_equal(div, GP[f"s{s}_div"])
+        assert np.array_equal(np.random.rand(2), GP[f"s{s}_rng_after"]), "numpy stream position after the call"
+
+
+def test_host_patch_selection_matches_reference():
+    """hosnerf_amd.rays.sample_patch_rays (torch index ops, device agnostic) on the reference's inputs: bit-exact indices,
+    gathered rays, target patches and the same numpy RNG stream position."""
+    import torch
+    from hosnerf_amd import rays as R
+    H, W, P, N, ratio, bbox, subj = _patch_args()
+    t = torch.from_numpy
+    item = {"img_height": H, "img_width": W, "ray_mask": t(bbox.reshape(-1)),
+            "rays": torch.stack([t(GP["in_rays_o"]), t(GP["in_rays_o"]) * 2], 0), "far": t(GP["in_far"]),
+            "ray_grid": t(GP["in_ray_grid"]), "ray_img": t(GP["in_rays_o"]) + 1}
+    saw_wrap = False
+    for s in GP["seeds"]:
+        np.random.seed(int(s))
+        sel, pix, masks, div = R.get_patch_ray_indices(N, item["ray_mask"], t(subj), t(bbox), P, H, W, ratio)
+        want = GP[f"s{s}_select_inds"].astype(np.int64)
+        saw_wrap |= bool((want < 0).any())
+        nv = int(bbox.sum())
+        assert np.array_equal(sel.numpy(), np.where(want < 0, want + nv, want))
+        assert np.array_equal(np.random.rand(2), GP[f"s{s}_rng_after"])
+        np.random.seed(int(s))
+        out = R.sample_patch_rays(item, t(GP["img"]), t(subj), N, P, ratio)
+        assert np.array_equal(out["rays"][0].numpy(), GP[f"s{s}_out_rays_o"])
+        assert np.array_equal(out["ray_grid"].numpy(), GP[f"s{s}_out_ray_grid"]) and np.array_equal(out["far"].numpy(), GP[f"s{s}_out_far"])
+        assert np.array_equal(out["target_patches"].numpy(), GP[f"s{s}_out_target_patches"])
+        assert np.array_equal(out["patch_masks"].numpy(), GP[f"s{s}_out_patch_masks"])
+        assert np.array_equal(out["patch_div_indices"].numpy(), GP[f"s{s}_out_patch_div_indices"])
+        assert torch.equal(out["target_rgbs"], out["rays"][0] + 1)
+    assert saw_wrap, "fixture must contain a patch above the first box ray (index -1 wraps like numpy)"
