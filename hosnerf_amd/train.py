@@ -184,24 +184,31 @@ def human_lr_ranges(net, lr_cnl: float = 6.667e-5, lr_other: float = 6.667e-6):
 
 def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
                   w_flow: float = 0.01, w_cycle: float = 0.01):
-    """M:1690-1716 get_loss without the LPIPS term (third-party VGG, out of scope): 0.2*MSE + 0.01*flow + 0.01*cycle.
-    Torch elementwise ops on [B,3] / [B_fg,128,2] tensors -- fusing them into the composite is a listed next step."""
+    """M:1690-1716 `get_loss` without the LPIPS term (third-party VGG, out of scope): 0.2*MSE + 0.01*flow + 0.01*cycle
+    (configs/default.yaml lossweights).  Returns (total, {name: unweighted term}).
+
+    The reference selects the foreground rows first (`ray_grid[idx_fg]`, `human_weights_onlyfg`, M:1704) -- a boolean
+    index, i.e. a device->host round trip per step, next to its four `.item()` reads (M:1617-1622).  Here the flow term
+    (M:1680-1688 + img2mae M:61-71) runs over ALL rays with the foreground flag folded into the flow mask: rows of
+    background rays have zero composite weight in `human_weights_sorted`, so the numerator is unchanged, and the
+    denominator sum(M) over the selected [B_fg, S, 1] block is S * sum_fg(M_ray).  No synchronisation, fixed shapes."""
     rgb = out["rgb"]
     target = batch["target_rgbs"] if "target_rgbs" in batch else batch["target_patches"].reshape(-1, 3)
-    losses = {"mse": torch.mean((rgb - target) ** 2)}
+    losses = {"mse": torch.mean((rgb - target) ** 2)}                             # _unpack_imgs is a reshape (M:41-50)
     flow = rgb.new_zeros(())
-    if "deform_pts_prev_final" in out and "ray_grid" in batch:                  # M:1680-1688 flow_func
-        fg = out["idx_fg"].bool()
-        if bool(fg.any()):
-            pts = out["deform_pts_prev_final"][fg]
-            hom = torch.cat([pts, torch.ones_like(pts[..., :1])], -1)
-            cam = torch.einsum("ji,bni->bnj", batch["newsmpl_to_camera_prev"], hom)[..., :3]
-            uvw = torch.einsum("ji,bni->bnj", batch["intrinsics_prev"], cam)
-            uv = uvw[..., :-1] / uvw[..., -1:]
-            grid = batch["ray_grid"][fg][:, None, :]
-            M = grid[..., -1:]
-            w = out["human_weights_sorted"][fg]
-            flow = torch.sum(torch.abs(uv - grid[..., :2] - grid[..., 2:4]) * w[..., None] * M) / (torch.sum(M.expand(-1, pts.shape[1], -1)) + 1e-8) / 2
+    if "deform_pts_prev_final" in out and "ray_grid" in batch:                  # time > 0.005 and training
+        pts = out["deform_pts_prev_final"]                                       # [B,S,3]
+        S = pts.shape[1]
+        A = batch["newsmpl_to_camera_prev"]
+        grid = batch["ray_grid"][:, None, :]                                     # [B,1,5]: x, y, flow_x, flow_y, valid
+        M = grid[..., 4:5] * out["idx_fg"].to(rgb.dtype)[:, None, None]          # [B,1,1]
+        on = M > 0
+        cam = pts @ A[:3, :3].T + A[:3, 3]
+        uvw = cam @ batch["intrinsics_prev"].T
+        depth = torch.where(on, uvw[..., 2:3], torch.ones_like(uvw[..., 2:3]))   # rows that do not count stay finite
+        uv = uvw[..., :2] / depth
+        err = torch.abs(uv - grid[..., :2] - grid[..., 2:4]) * out["human_weights_sorted"][..., None]
+        flow = torch.sum(torch.where(on, err, torch.zeros_like(err))) / (S * torch.sum(M) + 1e-8) / 2
     losses["flow"] = flow
     dis = out["observe_pts"] - out["deform_pts_final"]
     losses["cycle"] = torch.mean(torch.sum(dis**2, 1) / 2.0)
