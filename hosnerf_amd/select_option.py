@@ -80,15 +80,12 @@ class LitHOSNeRF(_Base):
     def __init__(self, basedir, cfg=None):
         super().__init__()
         self.cfg = default_cfg(basedir) if cfg is None else cfg
-        self.net = HOSNeRF(self.cfg)
-
-    @property
-    def model(self):
-        return self.net.model
-
-    @property
-    def human(self):
-        return self.net.human
+        net = HOSNeRF(self.cfg)
+        # registered under the reference's attribute names so that `state_dict()` has its keys (`model.*`, `human.*`);
+        # the composite renderer that owns the same two modules is kept as a plain attribute
+        self.model = net.model
+        self.human = net.human
+        object.__setattr__(self, "net", net)
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
         out = self.net.render(batch, randomized=True, is_train=True)
@@ -108,3 +105,25 @@ def select_model(model_name: str, basedir, **kwargs):
     if model_name not in _MODELS:
         raise ValueError(f"Unknown model named {model_name}; known: {sorted(_MODELS)}")
     return _MODELS[model_name](basedir, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------ checkpoints
+def lightning_checkpoint(lit: nn.Module, global_step: int = 0, epoch: int = 0) -> Dict:
+    """The part of a Lightning `.ckpt` the reference reads back (`pl_load(path)['state_dict']`, S3/run.py:206-212, and
+    `trainer.fit(ckpt_path=...)`): the module's `state_dict` under the reference's key names, on the host."""
+    return {"state_dict": {k: v.detach().cpu().clone() for k, v in lit.state_dict().items()},
+            "global_step": int(global_step), "epoch": int(epoch), "pytorch-lightning_version": "hosnerf_amd"}
+
+
+def save_checkpoint(lit: nn.Module, path: str, global_step: int = 0, epoch: int = 0) -> None:
+    torch.save(lightning_checkpoint(lit, global_step, epoch), path)
+
+
+def load_checkpoint(lit: nn.Module, path: str, strict: bool = False):
+    """`model.load_state_dict(pl_load(path)['state_dict'], strict=False)` (S3/run.py:206-212): a stage-2 checkpoint fills
+    `human.*`, a stage-1 checkpoint `model.*`; called once per file for the stage-3 warm start.  Values are copied INTO
+    the flat parameter store (the parameters are views of it), so optimiser state and captured graphs stay valid.
+    Returns torch's (missing_keys, unexpected_keys)."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+    return lit.load_state_dict(sd, strict=strict)

@@ -103,3 +103,42 @@ def test_select_model_registry(tmp_path):
     import importlib
     mod = importlib.import_module("hosnerf_amd.plugins.network_amd")
     assert mod.Network.__name__ == "Network"
+
+
+def test_checkpoint_round_trip_and_stage3_warm_start(tmp_path):
+    """S3/run.py:206-212: the stage-3 module is warm-started from a stage-2 checkpoint (`human.*` keys) and a stage-1
+    checkpoint (`model.*` keys) with `load_state_dict(ckpt['state_dict'], strict=False)`.  The Lightning-style files are
+    built from the reference's key names (tests/golden/state_dict_keys.json)."""
+    import json
+    import torch
+    from hosnerf_amd import synth
+    from hosnerf_amd.select_option import load_checkpoint, save_checkpoint, select_model
+    (tmp_path / "transitions_times.json").write_text(json.dumps({"f0": {"time": 0.4}}))
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    bsd, hsd = synth.background_state_dict(5, 2), synth.human_state_dict(6, 2)
+    assert set(bsd) <= set(ref["state_mipnerf360"]) and set(hsd) == set(ref["human_network"])
+    s1 = {"state_dict": {"model." + k: v for k, v in bsd.items()}, "global_step": 7}
+    s2 = {"state_dict": {"human." + k: v for k, v in hsd.items()}, "global_step": 9}
+    torch.save(s1, tmp_path / "bkgd.ckpt")
+    torch.save(s2, tmp_path / "human.ckpt")
+    lit = select_model("hosnerf", str(tmp_path))
+    keys = set(lit.state_dict())
+    assert keys == {"model." + k for k in ref["state_mipnerf360"]} | {"human." + k for k in ref["human_network"]}
+    flat_ptr = lit.human.flat_param.data_ptr()
+    missing, unexpected = load_checkpoint(lit, str(tmp_path / "human.ckpt"))
+    assert not unexpected and all(k.startswith("model.") for k in missing)
+    missing, unexpected = load_checkpoint(lit, str(tmp_path / "bkgd.ckpt"))
+    assert not unexpected and all(k.startswith("human.") or k not in s1["state_dict"] for k in missing)
+    got = lit.state_dict()
+    assert all(torch.equal(got["human." + k], v) for k, v in hsd.items())
+    assert all(torch.equal(got["model." + k], v) for k, v in bsd.items())
+    assert lit.human.flat_param.data_ptr() == flat_ptr, "loading copies into the flat store, it does not re-allocate it"
+    assert lit.net.model is lit.model and lit.net.human is lit.human
+    # our own checkpoint has the same surface and reloads bit-exactly into a fresh module
+    save_checkpoint(lit, str(tmp_path / "last.ckpt"), global_step=11)
+    ck = torch.load(tmp_path / "last.ckpt", weights_only=False)
+    assert set(ck["state_dict"]) == keys and ck["global_step"] == 11
+    lit2 = select_model("hosnerf", str(tmp_path))
+    missing, unexpected = load_checkpoint(lit2, str(tmp_path / "last.ckpt"), strict=True)
+    assert not missing and not unexpected
+    assert torch.equal(lit2.human.flat_param, lit.human.flat_param) and torch.equal(lit2.model.flat_param, lit.model.flat_param)
