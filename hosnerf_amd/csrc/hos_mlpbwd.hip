@@ -1,0 +1,398 @@
+// Fused backward of ONE thin linear layer (<= 128 in / <= 128 out features) over very many rows:
+//
+//     dX = (dZ . W) * [X > 0]        (DGRAD, ReLU mask of the layer's input, optional)
+//     dW += dZ^T . X,  db += sum_rows dZ        (WGRAD)
+//
+// The human-object branch runs 128-wide MLPs over P = rays x 128 = 262 144 sample points.  As two GEMMs a layer's
+// backward reads dZ twice and X twice (mask + WGRAD operand) and writes dX: 20 B per element; the split-precision WGRAD
+// on fp32 operands is additionally bound by its in-register transposes (1.9 TB/s measured).  Here one workgroup keeps the
+// layer's W (bf16 hi/lo, 64 KB at 128 x 128) resident in LDS, walks 64-row blocks of dZ and X -- each read ONCE from HBM,
+// split into bf16 (hi, lo) planes at staging time -- and feeds both products from the same two LDS tiles: 12 B per element.
+// No operand is transposed by VALU: every reduction-row operand (W for DGRAD, dZ^T and X for WGRAD) is stored row-major
+// and read with ds_read_b64_tr_b16, which hands a lane the 4 consecutive reduction values of its MFMA row.
+//   products: a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi in v_mfma_f32_32x32x16_bf16, fp32 accumulate (as hos_gemm3.hip)
+//   roofline: HBM.  12 B x M x 128 per launch; MFMA time is ~1/3 of the memory time at 11 B/clk/CU.
+// Reference: the autograd backward of nn.Linear + ReLU in core/nets/human_nerf/non_rigid_motion_mlps/mlp_offset.py:54-70.
+#include "hos_gemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct MlpBwdArgs {
+    const float* dZ; int lddz;
+    const float* X; int ldx;
+    const float* W; int ldw;
+    float* dX; int lddx;
+    float* dW; int lddw;
+    float* db;
+    int M, N, K;
+    int relu_mask;
+    float* ws;                    // optional [gridDim.x][32 NT][32 KT] partial dW slabs (NULL: fp32 atomics into dW)
+};
+
+constexpr int MB_R = 64;          // rows per block iteration
+constexpr int MB_NT = 512;
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// Fragment of a reduction-row operand stored row-major [reduction][columns] (16-bit): the lane of MFMA row
+// (lane & 31) and k half (lane >> 5) receives its 8 consecutive reduction values.  Inside a 16-lane group lane p supplies
+// the address of reduction row (p >> 2), columns 4 (p & 3) .. +3, and receives column p of the four rows.
+__device__ __forceinline__ bf16x8 tr_frag2(const char* p0, int pitch) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * pitch));
+    const s16x8 j = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, j);
+}
+
+__device__ __forceinline__ f32x16 mma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
+}
+
+// DGRAD epilogue of one 32x32 tile: quad transpose (a lane ends up with four consecutive columns of one row, see
+// gemm_epilogue_tile), ReLU mask from the sign of the bf16 hi part of X in LDS, 16-byte stores.  The mask must NOT be read
+// from global memory here: vmcnt retires in order, so a wave waiting for such a load would also wait for the whole
+// prefetch of the next tile issued just before it.
+__device__ __forceinline__ void dgrad_store(const MlpBwdArgs& a, const f32x16& acc, const char* xh_rows, int pitch, int grow0,
+                                            int col0, int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5, q = l31 & 3;
+    const int colb = col0 + (l31 & ~3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+        {
+            const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
+            const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+            if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+            const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
+            const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
+            if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+        }
+        const int lrow = q + 8 * g + 4 * lhi;                     // row inside the 32-row tile
+        const int row = grow0 + lrow;
+        if (row >= a.M || colb >= a.K) continue;
+        float v[4] = {v0, v1, v2, v3};
+        if (a.relu_mask) {
+            const uint2 m = *reinterpret_cast<const uint2*>(xh_rows + lrow * pitch + colb * 2);    // 4 x bf16
+            const uint32_t h[4] = {m.x & 0xffffu, m.x >> 16, m.y & 0xffffu, m.y >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((h[k] & 0x8000u) || (h[k] & 0x7fffu) == 0) v[k] = 0.f;                           // not (x > 0)
+        }
+        float* dst = a.dX + (size_t)row * a.lddx + colb;
+        if (colb + 3 < a.K) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (colb + k < a.K) dst[k] = v[k];
+        }
+    }
+}
+
+template <int NT, int KT>
+__global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
+    constexpr int N_ = NT * 32, K_ = KT * 32, R = MB_R;
+    // row pitches in bytes: +32 B so that consecutive rows start 8 banks apart
+    constexpr int PZ = N_ * 2 + 32, PX = K_ * 2 + 32, PW = K_ * 2 + 32;
+    constexpr int W_PLANE = N_ * PW, Z_PLANE = R * PZ, X_PLANE = R * PX;
+    constexpr int ZU = R * (N_ / 4) / MB_NT, XU = R * (K_ / 4) / MB_NT;          // float4 units per thread and tile
+    static_assert(ZU >= 1 && XU >= 1, "tile too small for 512 threads");
+    constexpr int DT = 2 * KT;                    // DGRAD 32x32 tiles per row block
+    constexpr int WT = NT * KT;                   // WGRAD tiles
+    constexpr int WPW = (WT + 7) / 8;             // WGRAD tiles per wave
+    static_assert(DT <= 8, "one DGRAD tile per wave");
+    static_assert(8 % KT == 0, "a wave's WGRAD tiles share kt");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_mb[];
+    char* const Wh = smem_mb;
+    char* const Wl = Wh + W_PLANE;
+    char* const Zh = Wl + W_PLANE;
+    char* const Zl = Zh + Z_PLANE;
+    char* const Xh = Zl + Z_PLANE;
+    char* const Xl = Xh + X_PLANE;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int tr_g = lane >> 4, tr_p = lane & 15;
+#ifdef HOS_MB_TRACE   // timing experiment: phase stamps of workgroups 0 and 200 in the (otherwise unused) workspace
+    long long* const trb = reinterpret_cast<long long*>(a.ws);
+    int trn = 0;
+#define MB_STAMP() do { if ((blockIdx.x == 0 || blockIdx.x == 200) && t == 0 && trn < 60) trb[(blockIdx.x ? 64 : 0) + trn++] = clock64(); } while (0)
+#else
+#define MB_STAMP() do {} while (0)
+#endif
+    MB_STAMP();
+    const int tr_row = 8 * (tr_g >> 1) + (tr_p >> 2);               // reduction row inside a 16-row step
+    const int tr_col = 16 * (tr_g & 1) + 4 * (tr_p & 3);            // column inside a 32-column tile
+
+    // two tiles of register prefetch (A, B): a tile's loads are issued two iterations before they are converted
+    float4 rzA[ZU], rxA[XU], rzB[ZU], rxB[XU];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](float4 (&rz)[ZU], float4 (&rx)[XU], int rb) {
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = t + MB_NT * i, row = u / (N_ / 4), c4 = u % (N_ / 4);
+            const int gr = rb * R + row;
+            rz[i] = (gr < a.M && c4 * 4 < a.lddz) ? ldg4(a.dZ + (size_t)gr * a.lddz + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = t + MB_NT * i, row = u / (K_ / 4), c4 = u % (K_ / 4);
+            const int gr = rb * R + row;
+            rx[i] = (gr < a.M && c4 * 4 < a.K) ? ldg4(a.X + (size_t)gr * a.ldx + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](const float4 (&rz)[ZU], const float4 (&rx)[XU]) {
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = t + MB_NT * i, row = u / (N_ / 4), c4 = u % (N_ / 4);
+            bsum.x += rz[i].x; bsum.y += rz[i].y; bsum.z += rz[i].z; bsum.w += rz[i].w;   // c4 is the same for every i
+            bf16x4 h, l;
+            split4(rz[i], h, l);
+            *reinterpret_cast<bf16x4*>(Zh + row * PZ + c4 * 8) = h;
+            *reinterpret_cast<bf16x4*>(Zl + row * PZ + c4 * 8) = l;
+        }
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = t + MB_NT * i, row = u / (K_ / 4), c4 = u % (K_ / 4);
+            bf16x4 h, l;
+            split4(rx[i], h, l);
+            *reinterpret_cast<bf16x4*>(Xh + row * PX + c4 * 8) = h;
+            *reinterpret_cast<bf16x4*>(Xl + row * PX + c4 * 8) = l;
+        }
+    };
+
+    f32x16 accW[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[j][r] = 0.f;
+
+    const int nrb = (a.M + R - 1) / R;
+    const int G = gridDim.x;
+    auto compute = [&](int rb) {
+        // ---- DGRAD MFMAs: dX[64 x K_] = dZ[64 x N_] . W[N_ x K_]: tile (rt, kt) on wave rt*KT + kt
+        f32x16 acc;
+        const int rt = wave / KT, kt = wave % KT;
+        if (wave < DT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const char* zrow = Zh + (rt * 32 + l31) * PZ + lhi * 16;
+            const char* wfrag = Wh + tr_row * PW + (kt * 32 + tr_col) * 2;
+#pragma unroll
+            for (int s = 0; s < N_ / 16; ++s) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(zrow + s * 32);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(zrow + Z_PLANE + s * 32);
+                const bf16x8 bh = tr_frag2(wfrag + s * 16 * PW, PW);
+                const bf16x8 bl = tr_frag2(wfrag + W_PLANE + s * 16 * PW, PW);
+                acc = mma3(ah, al, bh, bl, acc);
+            }
+        }
+        // ---- WGRAD: dW[N_ x K_] += dZ^T[N_ x 64] . X[64 x K_]: tile (nt, kt) = wave + 8 j.  8 % KT == 0, so a wave's tiles
+        // share kt: the X fragments are read once per reduction step
+        if (wave < WT) {
+            const int kw = wave % KT;
+            const char* xfrag = Xh + tr_row * PX + (kw * 32 + tr_col) * 2;
+#pragma unroll
+            for (int s = 0; s < R / 16; ++s) {
+                const bf16x8 bh = tr_frag2(xfrag + s * 16 * PX, PX);
+                const bf16x8 bl = tr_frag2(xfrag + X_PLANE + s * 16 * PX, PX);
+#pragma unroll
+                for (int j = 0; j < WPW; ++j) {
+                    const int ti = wave + 8 * j;
+                    if (ti < WT) {
+                        const char* zfrag = Zh + tr_row * PZ + ((ti / KT) * 32 + tr_col) * 2;
+                        const bf16x8 ah = tr_frag2(zfrag + s * 16 * PZ, PZ);
+                        const bf16x8 al = tr_frag2(zfrag + Z_PLANE + s * 16 * PZ, PZ);
+                        accW[j] = mma3(ah, al, bh, bl, accW[j]);
+                    }
+                }
+            }
+        }
+        // ---- DGRAD store (after the WGRAD MFMAs have been issued: the stores drain under them)
+        if (wave < DT && a.dX != nullptr) dgrad_store(a, acc, Xh + rt * 32 * PX, PX, rb * R + rt * 32, kt * 32, lane);
+    };
+
+    int rb = blockIdx.x;
+    if (rb < nrb) gload(rzA, rxA, rb);              // the first two tiles travel while W is staged
+    if (rb + G < nrb) gload(rzB, rxB, rb + G);
+    {   // ---- W -> LDS (hi, lo), once: all loads first, then the conversions
+        constexpr int WU = N_ * (K_ / 4) / MB_NT;
+        float4 rw[WU];
+#pragma unroll
+        for (int i = 0; i < WU; ++i) {
+            const int u = t + MB_NT * i, row = u / (K_ / 4), c4 = u % (K_ / 4);
+            rw[i] = (row < a.N && c4 * 4 < a.K) ? ldg4(a.W + (size_t)row * a.ldw + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < WU; ++i) {
+            const int u = t + MB_NT * i, row = u / (K_ / 4), c4 = u % (K_ / 4);
+            bf16x4 h, l;
+            split4(rw[i], h, l);
+            *reinterpret_cast<bf16x4*>(Wh + row * PW + c4 * 8) = h;
+            *reinterpret_cast<bf16x4*>(Wl + row * PW + c4 * 8) = l;
+        }
+    }
+    MB_STAMP();
+    while (rb < nrb) {
+        sstore(rzA, rxA);
+        MB_STAMP();
+        __syncthreads();                            // tile (and, the first time, W) visible
+        MB_STAMP();
+        if (rb + 2 * G < nrb) gload(rzA, rxA, rb + 2 * G);
+        compute(rb);
+        MB_STAMP();
+        __syncthreads();                            // every wave is done with this tile before it is overwritten
+        MB_STAMP();
+        rb += G;
+        if (rb >= nrb) break;
+        sstore(rzB, rxB);
+        __syncthreads();
+        if (rb + 2 * G < nrb) gload(rzB, rxB, rb + 2 * G);
+        compute(rb);
+        __syncthreads();
+        rb += G;
+    }
+
+    // ---- dW: one partial [N_, K_] per workgroup.  256 workgroups adding 16 K floats each into the SAME 64 KB with fp32
+    // atomics serialise in L2 (measured: 35 us of a 139 us launch); with a workspace every workgroup stores its slab with
+    // plain 16-byte stores and mlp_bwd_reduce_kernel sums the slabs (8-way atomics only).
+    MB_STAMP();
+    GemmArgs ew{};
+#ifdef HOS_MB_TRACE
+    if (false) {
+#else
+    if (a.ws != nullptr) {
+#endif
+        ew.C = a.ws + (size_t)blockIdx.x * (N_ * K_ + N_); ew.ldc = K_; ew.M = N_; ew.N = K_; ew.epi = HOS_EPI_NONE;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int ti = wave + 8 * j;
+            if (ti < WT) gemm_epilogue_tile<MODE_FWD>(ew, accW[j], (ti / KT) * 32, (ti % KT) * 32, lane);
+        }
+    } else {
+        ew.C = a.dW; ew.ldc = a.lddw; ew.M = a.N; ew.N = a.K;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int ti = wave + 8 * j;
+            if (ti < WT) gemm_epilogue_tile<MODE_WGRAD>(ew, accW[j], (ti / KT) * 32, (ti % KT) * 32, lane);
+        }
+    }
+    if (a.db != nullptr) {
+        float4* red = reinterpret_cast<float4*>(Zh);             // 8 KB of the (idle) tile memory
+        red[t] = bsum;
+        __syncthreads();
+        constexpr int G = N_ / 4;                                 // column groups; thread t owns group t % G
+        if (t < G) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = t; k < MB_NT; k += G) { const float4 v = red[k]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            const float sv[4] = {s.x, s.y, s.z, s.w};
+            bool direct = true;
+#ifndef HOS_MB_TRACE
+            if (a.ws != nullptr) {      // 256 workgroups x one atomic per bias element on the SAME address cost 10-20 us: slab tail
+                *reinterpret_cast<float4*>(a.ws + (size_t)blockIdx.x * (N_ * K_ + N_) + N_ * K_ + t * 4) = s;
+                direct = false;
+            }
+#endif
+            if (direct) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t * 4 + q < a.N) __hip_atomic_fetch_add(a.db + t * 4 + q, sv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+#ifdef HOS_MB_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MB_STAMP();
+#endif
+#undef MB_STAMP
+}
+
+// dW[n][k] += sum over slabs g of ws[g][n][k].  Block (x, y): 256 threads x float4 = 1024 consecutive elements, slabs
+// y, y + 32, ... (8 of 256): all eight 16-byte loads of a thread are issued before the first add (one memory latency
+// per thread, 2048 blocks in flight), then 32-way fp32 atomics.
+constexpr int MB_RSPLIT = 32;
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ ws, int slabs, int n_, int k_, float* __restrict__ dW,
+                                                             int lddw, float* __restrict__ db, int N, int K) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int nk = n_ * k_;
+    const int slab = nk + n_;                             // [n_][k_] partial of dW, then [n_] partial of db
+    if (e >= slab || (e >= nk && db == nullptr)) return;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = blockIdx.y + i * MB_RSPLIT;
+        v[i] = g < slabs ? *reinterpret_cast<const float4*>(ws + (size_t)g * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    if (e >= nk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (e - nk + q < N) __hip_atomic_fetch_add(db + e - nk + q, sv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int n = e / k_, k = e % k_;                     // k_ is a multiple of 32: the four elements share a row
+    if (n < N) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k + q < K) __hip_atomic_fetch_add(dW + (size_t)n * lddw + k + q, sv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int NT, int KT>
+int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
+    constexpr int N_ = NT * 32, K_ = KT * 32;
+    constexpr size_t smem = 2 * (size_t)N_ * (K_ * 2 + 32) + 2 * (size_t)MB_R * (N_ * 2 + 32) + 2 * (size_t)MB_R * (K_ * 2 + 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NT, KT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int nrb = hos_cdiv(a.M, MB_R);
+    const int grid = nrb < 256 ? nrb : 256;
+    if (a.ws != nullptr && (grid < 32 || ws_floats < (size_t)grid * (N_ * K_ + N_))) a.ws = nullptr;   // few workgroups: atomics are fine
+    hipLaunchKernelGGL((mlp_bwd_kernel<NT, KT>), dim3(grid), dim3(MB_NT), smem, stream, a);
+#ifndef HOS_MB_TRACE
+    if (a.ws != nullptr)
+        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(N_ * K_ + N_, 1024), MB_RSPLIT), dim3(256), 0, stream,
+                           a.ws, grid, N_, K_, a.dW, a.lddw, a.db, a.N, a.K);
+#endif
+    return hos_launch_status();
+}
+
+}  // namespace
+
+// dZ [M, lddz >= 32*ceil(N/32)] (columns >= N zero), X [M, ldx >= K], W [N, ldw] (first column of the K-slice) ->
+// dX [M, lddx] (NULL: skip), dW [N, lddw] +=, db [N] += (NULL: skip).  N, K <= 128, K % 4 == 0.
+// ws: optional scratch of ws_floats >= 256 * (128 * 128 + 128) floats for the per-workgroup dW partials (NULL: atomics).
+extern "C" int hos_linear_bwd_fused(const float* dZ, int lddz, const float* X, int ldx, const float* W, int ldw,
+                                    float* dX, int lddx, float* dW, int lddw, float* db, int M, int N, int K,
+                                    int relu_mask, float* ws, int64_t ws_floats, hos_stream_t stream) {
+    if (!dZ || !X || !W || !dW || M <= 0 || N <= 0 || K <= 0 || ws_floats < 0) return HOS_E_ARG;
+    if (N > 128 || K > 128) return HOS_E_SHAPE;
+    if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (K & 3) || (dX && (lddx & 3))) return HOS_E_ALIGN;
+    if (((uintptr_t)dZ | (uintptr_t)X | (uintptr_t)W | (uintptr_t)ws) & 15u) return HOS_E_ALIGN;
+    MlpBwdArgs a{dZ, lddz, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, relu_mask, ws};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nt = hos_cdiv(N, 32), kt = hos_cdiv(K, 32);
+    if (nt <= 1 && kt <= 4) return launch_mb<1, 4>(a, (size_t)ws_floats, s);
+    if (kt <= 2) return launch_mb<4, 2>(a, (size_t)ws_floats, s);
+    return launch_mb<4, 4>(a, (size_t)ws_floats, s);
+}

@@ -396,37 +396,35 @@ class Network(FlatModule):
 
     # ------------------------------------------------------------------ HIP MLP chains (backward)
     def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor):
-        """Parameter gradients into the flat buffer; returns d loss / d x  ([P,3])."""
+        """Parameter gradients into the flat buffer; returns d loss / d x  ([P,3]).  Every layer is 128 wide, so each
+        layer's (wgrad, dgrad) pair is one fused pass over (dZ, X) (ops.linear_bwd_fused); HOS_FUSED_BWD=0 selects the
+        two-GEMM form."""
         E, PE, acts = saved
         Pn, dev = x.shape[0], x.device
+        fused = ops.FUSED_THIN_BWD
+
+        def layer_bwd(dz, X, spec, N, K, out, relu_mask, w_col0=0, bias=True):
+            Wt, _ = self._w(spec)
+            gW, gb = self._w(spec, grad=True)
+            if fused:
+                ops.linear_bwd_fused(dz, X, Wt, gW, gb if bias else None, N, K, out, relu_mask, w_col0=w_col0)
+            else:
+                ops.linear_wgrad(dz, X, gW, gb if bias else None, N, K, w_col0=w_col0)
+                ops.linear_dgrad(dz, Wt, dz.shape[1], K, out, mask_src=X if relu_mask else None, w_col0=w_col0)
+            return out
+
         dz6 = torch.zeros(Pn, 32, device=dev)
         ops.slice_mask(g_xyz, 0, None, 0, 3, dz6)
-        Wt, _ = self._w(specs[6])
-        gW, gb = self._w(specs[6], grad=True)
-        ops.linear_wgrad(dz6, acts[5], gW, gb, 3, 128)
-        dz = torch.empty(Pn, 128, device=dev)
-        ops.linear_dgrad(dz6, Wt, 32, 128, dz, mask_src=acts[5])
+        dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
         dPE = dE = None
         for i in range(5, -1, -1):
-            Wt, _ = self._w(specs[i])
-            gW, gb = self._w(specs[i], grad=True)
             if i == 4:
-                ops.linear_wgrad(dz, acts[3], gW, gb, 128, 128)
-                ops.linear_wgrad(dz, PE, gW, None, 128, NR_LDPE, w_col0=128)
-                dPE = torch.empty(Pn, NR_LDPE, device=dev)
-                ops.linear_dgrad(dz, Wt, 128, NR_LDPE, dPE, w_col0=128)
-                nxt = torch.empty(Pn, 128, device=dev)
-                ops.linear_dgrad(dz, Wt, 128, 128, nxt, mask_src=acts[3])
-                dz = nxt
+                dPE = layer_bwd(dz, PE, specs[4], 128, NR_LDPE, torch.empty(Pn, NR_LDPE, device=dev), False, w_col0=128, bias=False)
+                dz = layer_bwd(dz, acts[3], specs[4], 128, 128, torch.empty(Pn, 128, device=dev), True)
             elif i == 0:
-                ops.linear_wgrad(dz, E, gW, gb, 128, NR_LDE)
-                dE = torch.empty(Pn, NR_LDE, device=dev)
-                ops.linear_dgrad(dz, Wt, 128, NR_LDE, dE)
+                dE = layer_bwd(dz, E, specs[0], 128, NR_LDE, torch.empty(Pn, NR_LDE, device=dev), False)
             else:
-                ops.linear_wgrad(dz, acts[i - 1], gW, gb, 128, 128)
-                nxt = torch.empty(Pn, 128, device=dev)
-                ops.linear_dgrad(dz, Wt, 128, 128, nxt, mask_src=acts[i - 1])
-                dz = nxt
+                dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
         g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
         ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True)
         return g_x

@@ -5,6 +5,8 @@ current torch stream.  Tensors are fp32, contiguous, on the HIP device.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional, Tuple
 
@@ -121,6 +123,34 @@ def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Option
     _timed(f"gemm_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
         "hos_linear_wgrad", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0),
         ptr(db), M, N, K, splits))
+
+
+def linear_bwd_fused(dY: torch.Tensor, X: torch.Tensor, W: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], N: int,
+                     K: int, out: Optional[torch.Tensor], relu_mask: bool, w_col0: int = 0):
+    """One thin layer's whole backward in one pass over (dY, X) (hos_mlpbwd.hip; N, K <= 128):
+    out[M,:K] = (dY[:, :N] @ W[:N, w_col0:w_col0+K]) * (X > 0 if relu_mask);  dW[:N, w_col0:..+K] += dY^T @ X;  db += colsum(dY)."""
+    M = dY.shape[0]
+    ws = _bwd_workspace(dY.device)
+    _timed(f"mlp_bwd_fused[M={M},N={N},K={K}]", 4.0 * M * N * K, lambda: call(
+        "hos_linear_bwd_fused", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(W) + 4 * w_col0, W.stride(0),
+        ptr(out), 0 if out is None else out.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, int(relu_mask),
+        ptr(ws), ws.numel()))
+    return out
+
+
+_BWD_WS = {}
+
+
+def _bwd_workspace(device) -> torch.Tensor:
+    """16.9 MB of per-workgroup dW / db partials for hos_linear_bwd_fused; one per device -- launches on a stream are ordered and
+    the reduce kernel that reads it is enqueued by the same call."""
+    key = str(device)
+    if key not in _BWD_WS:
+        _BWD_WS[key] = torch.empty(256 * (128 * 128 + 128), device=device)
+    return _BWD_WS[key]
+
+
+FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"
 
 
 class gemm_mode:

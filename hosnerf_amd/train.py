@@ -141,6 +141,17 @@ def shard_rays(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[st
     return out
 
 
+HOST_KEYS = ("time", "times", "iter_val", "is_train", "img_width", "img_height", "frame_name")
+
+
+def batch_to_device(batch: Dict, device) -> Dict:
+    """Move a dataset item to the device EXCEPT the control scalars the networks read on the host (`time` -> state
+    selection and the flow switch, `iter_val` -> kick-in switches and the hann window, N:589-656).  The reference moves them
+    too (`cpu_data_to_gpu`, M:1507) and then reads each back with an implicit `.item()`: a device->host round trip at the
+    START of every step, which keeps the host from queueing step n+1 while step n still runs."""
+    return {k: (v.to(device, non_blocking=True) if isinstance(v, torch.Tensor) and k not in HOST_KEYS else v) for k, v in batch.items()}
+
+
 def shard_frame(n_rays: int, rank: int, world: int):
     """Inference partition of a frame's rays: contiguous ranges, every rank the same length -- like the
     reference (S1/src/data/interface.py:152-166) the tail is padded by repeating the last rays so that the all-gather

@@ -85,6 +85,16 @@ int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npa
 int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
                      float* db, int M, int N, int K, int splits, hos_stream_t stream);
 
+/* Fused backward of one thin layer (N, K <= 128) over M rows -- replaces a hos_linear_wgrad + hos_linear_dgrad pair on the
+ * same (dY, X): dX [M,K] = (dY . W) masked by X > 0 (relu_mask != 0; dX NULL: skip), dW [N,ldw] += dY^T . X, db [N] += column
+ * sums of dY (NULL: skip).  dY [M, lddy] has its columns >= N zero up to the next multiple of 32; W points at the first
+ * column of the K-slice of the layer's weight [N, ldw] (nn.Linear layout).  bf16 hi/lo x3 products like the split GEMMs.
+ * ws / ws_floats: optional scratch (>= 256*(128*128+128) floats) for per-workgroup dW / db partials; NULL falls back to fp32 atomics.
+ * Reference: autograd of nn.Linear + ReLU in mlp_offset.py:54-70 (non-rigid MLPs, 128 wide, M = rays x 128). */
+int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, const float* W, int ldw,
+                         float* dX, int lddx, float* dW, int lddw, float* db, int M, int N, int K,
+                         int relu_mask, float* ws, int64_t ws_floats, hos_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward
  * side, bf16 for gradients), staged by LDS-DMA, 3 MFMAs per product.  The producer of a tensor does the split once;

@@ -37,7 +37,8 @@ def main():
     b["newsmpl_to_camera_prev"] = torch.eye(4)
     b["newsmpl_to_camera_prev"][2, 3] = 3.0
     b["intrinsics_prev"] = torch.tensor([[500.0, 0, 50], [0, 500.0, 50], [0, 0, 1]])
-    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    from hosnerf_amd.train import batch_to_device
+    gb = batch_to_device(b, dev)           # control scalars (time, iter_val) stay on the host: no round trip per step
     ob_ = FusedAdam(hos.model, lr=6.667e-5)
     oh_ = FusedAdam(hos.human, lr=6.667e-5, lr_ranges=human_lr_ranges(hos.human))
 

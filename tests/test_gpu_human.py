@@ -230,3 +230,50 @@ def test_deconv3d_matches_torch(dev, D, Cin, Cout, leaky):
     assert maxerr(xg.grad, xr.grad[0].reshape(Cin, -1).t()) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
     assert maxerr(wg.grad, wr.grad) < 2e-5 * max(1.0, float(wr.grad.abs().max()))
     assert maxerr(bg.grad, br.grad) < 1e-4 * max(1.0, float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,relu,wcol0,ldw", [(1000, 128, 128, True, 0, 128), (4133, 3, 128, True, 0, 128),
+                                                   (70001, 128, 64, False, 128, 192), (64, 128, 128, False, 0, 128),
+                                                   (2500, 100, 112, True, 0, 128)])
+def test_linear_bwd_fused(dev, M, N, K, relu, wcol0, ldw):
+    """hos_mlpbwd.hip: one thin layer's wgrad + dgrad in one pass == fp64 autograd of relu-masked nn.Linear backward, and
+    the two-GEMM form it replaces (same bf16 hi/lo x3 arithmetic)."""
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    Np = (N + 31) // 32 * 32
+    dY = torch.zeros(M, Np)
+    dY[:, :N] = torch.randn(M, N, generator=g) * 1e-3
+    X = torch.randn(M, max(K, 64), generator=g)                  # pre-activations' ReLU output has zeros: emulate both signs
+    X = torch.where(torch.rand(M, X.shape[1], generator=g) < 0.4, torch.zeros_like(X), X.abs())
+    W = torch.zeros(Np, ldw)
+    W[:N] = torch.randn(N, ldw, generator=g) / 11.0
+    dYd, Xd, Wd = dY.to(dev), X.to(dev), W.to(dev)
+    dW = torch.full((Np, ldw), 0.5, device=dev)                   # accumulates INTO existing gradients
+    db = torch.full((Np,), 0.25, device=dev)
+    out = torch.full((M, K), float("nan"), device=dev)
+    ops.linear_bwd_fused(dYd, Xd, Wd, dW, db, N, K, out, relu, w_col0=wcol0)
+    # fp64 truth
+    dY64, X64, W64 = dY[:, :N].double(), X[:, :K].double(), W[:N, wcol0:wcol0 + K].double()
+    dX64 = dY64 @ W64
+    if relu:
+        dX64 = dX64 * (X64 > 0)
+    dW64 = dY64.t() @ X64
+    db64 = dY64.sum(0)
+    sx, sw = float(dX64.abs().max()), float(dW64.abs().max())
+    assert float((out.double().cpu() - dX64).abs().max()) < 2e-5 * sx
+    got_dW = dW.cpu().double()
+    assert float((got_dW[:N, wcol0:wcol0 + K] - 0.5 - dW64).abs().max()) < 3e-5 * sw
+    untouched = torch.ones(Np, ldw, dtype=torch.bool)
+    untouched[:N, wcol0:wcol0 + K] = False
+    assert bool((got_dW[untouched] == 0.5).all()), "only the [N, K] slice of the gradient may change"
+    assert float((db.cpu().double()[:N] - 0.25 - db64).abs().max()) < 3e-5 * max(1e-6, float(db64.abs().max())) + 1e-7
+    assert bool((db.cpu()[N:] == 0.25).all())
+    # the two-GEMM form (needs K % 32 == 0 for its dgrad tile contract only via padding -> compare where it applies)
+    if K % 32 == 0 and N in (3, 128):
+        dW2 = torch.zeros(Np, ldw, device=dev)
+        db2 = torch.zeros(Np, device=dev)
+        out2 = torch.empty(M, K, device=dev)
+        ops.linear_wgrad(dYd, Xd, dW2, db2, N, K, w_col0=wcol0)
+        ops.linear_dgrad(dYd, Wd, Np, K, out2, mask_src=Xd if relu else None, w_col0=wcol0)
+        assert float((out - out2).abs().max()) < 1e-5 * sx
+        assert float((dW - 0.5 - dW2)[:N, wcol0:wcol0 + K].abs().max()) < 2e-5 * sw
