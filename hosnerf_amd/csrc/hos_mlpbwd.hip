@@ -31,10 +31,11 @@ struct MlpBwdArgs {
     float* db;
     int M, N, K;
     int relu_mask;
-    float* ws;                    // optional [gridDim.x][32 NT][32 KT] partial dW slabs (NULL: fp32 atomics into dW)
+    float* ws;                    // optional per-workgroup slabs [dW partial (if ws_dw) | db partial] (NULL: fp32 atomics)
+    int ws_dw;
 };
 
-constexpr int MB_R = 64;          // rows per block iteration
+constexpr int mb_rows(bool dg) { return dg ? 64 : 32; }   // rows per block iteration (wide WGRAD: 128 accumulator registers)
 constexpr int MB_NT = 512;
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -101,15 +102,18 @@ __device__ __forceinline__ void dgrad_store(const MlpBwdArgs& a, const f32x16& a
     }
 }
 
-template <int NT, int KT>
+// DG = true: the fused layer backward (N, K <= 128, W resident).  DG = false: WGRAD only for wider layers (N <= 256,
+// K <= 256; W does not fit next to the tiles), same staging and transposed reads, dX comes from the split GEMM.
+template <int NT, int KT, bool DG>
 __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
-    constexpr int N_ = NT * 32, K_ = KT * 32, R = MB_R;
+    constexpr int N_ = NT * 32, K_ = KT * 32, R = mb_rows(DG);
     // row pitches in bytes: +32 B so that consecutive rows start 8 banks apart
     constexpr int PZ = N_ * 2 + 32, PX = K_ * 2 + 32, PW = K_ * 2 + 32;
-    constexpr int W_PLANE = N_ * PW, Z_PLANE = R * PZ, X_PLANE = R * PX;
+    constexpr int W_PLANE = DG ? N_ * PW : 0, Z_PLANE = R * PZ, X_PLANE = R * PX;
+    constexpr bool PF2 = DG;                      // two tiles of register prefetch (one when the accumulators need the registers)
     constexpr int ZU = R * (N_ / 4) / MB_NT, XU = R * (K_ / 4) / MB_NT;          // float4 units per thread and tile
     static_assert(ZU >= 1 && XU >= 1, "tile too small for 512 threads");
-    constexpr int DT = 2 * KT;                    // DGRAD 32x32 tiles per row block
+    constexpr int DT = DG ? 2 * KT : 0;           // DGRAD 32x32 tiles per row block
     constexpr int WT = NT * KT;                   // WGRAD tiles
     constexpr int WPW = (WT + 7) / 8;             // WGRAD tiles per wave
     static_assert(DT <= 8, "one DGRAD tile per wave");
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
     const int tr_col = 16 * (tr_g & 1) + 4 * (tr_p & 3);            // column inside a 32-column tile
 
     // two tiles of register prefetch (A, B): a tile's loads are issued two iterations before they are converted
-    float4 rzA[ZU], rxA[XU], rzB[ZU], rxB[XU];
+    float4 rzA[ZU], rxA[XU], rzB[PF2 ? ZU : 1], rxB[PF2 ? XU : 1];
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](float4 (&rz)[ZU], float4 (&rx)[XU], int rb) {
 #pragma unroll
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
         // ---- DGRAD MFMAs: dX[64 x K_] = dZ[64 x N_] . W[N_ x K_]: tile (rt, kt) on wave rt*KT + kt
         f32x16 acc;
         const int rt = wave / KT, kt = wave % KT;
-        if (wave < DT) {
+        if constexpr (DG) if (wave < DT) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const char* zrow = Zh + (rt * 32 + l31) * PZ + lhi * 16;
@@ -222,13 +226,13 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
             }
         }
         // ---- DGRAD store (after the WGRAD MFMAs have been issued: the stores drain under them)
-        if (wave < DT && a.dX != nullptr) dgrad_store(a, acc, Xh + rt * 32 * PX, PX, rb * R + rt * 32, kt * 32, lane);
+        if constexpr (DG) if (wave < DT && a.dX != nullptr) dgrad_store(a, acc, Xh + rt * 32 * PX, PX, rb * R + rt * 32, kt * 32, lane);
     };
 
     int rb = blockIdx.x;
-    if (rb < nrb) gload(rzA, rxA, rb);              // the first two tiles travel while W is staged
-    if (rb + G < nrb) gload(rzB, rxB, rb + G);
-    {   // ---- W -> LDS (hi, lo), once: all loads first, then the conversions
+    if (rb < nrb) gload(rzA, rxA, rb);              // the first tiles travel while W is staged
+    if constexpr (PF2) if (rb + G < nrb) gload(rzB, rxB, rb + G);
+    if constexpr (DG) {   // ---- W -> LDS (hi, lo), once: all loads first, then the conversions
         constexpr int WU = N_ * (K_ / 4) / MB_NT;
         float4 rw[WU];
 #pragma unroll
@@ -246,24 +250,34 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
         }
     }
     MB_STAMP();
-    while (rb < nrb) {
-        sstore(rzA, rxA);
-        MB_STAMP();
-        __syncthreads();                            // tile (and, the first time, W) visible
-        MB_STAMP();
-        if (rb + 2 * G < nrb) gload(rzA, rxA, rb + 2 * G);
-        compute(rb);
-        MB_STAMP();
-        __syncthreads();                            // every wave is done with this tile before it is overwritten
-        MB_STAMP();
-        rb += G;
-        if (rb >= nrb) break;
-        sstore(rzB, rxB);
-        __syncthreads();
-        if (rb + 2 * G < nrb) gload(rzB, rxB, rb + 2 * G);
-        compute(rb);
-        __syncthreads();
-        rb += G;
+    if constexpr (PF2) {
+        while (rb < nrb) {
+            sstore(rzA, rxA);
+            MB_STAMP();
+            __syncthreads();                        // tile (and, the first time, W) visible
+            MB_STAMP();
+            if (rb + 2 * G < nrb) gload(rzA, rxA, rb + 2 * G);
+            compute(rb);
+            MB_STAMP();
+            __syncthreads();                        // every wave is done with this tile before it is overwritten
+            MB_STAMP();
+            rb += G;
+            if (rb >= nrb) break;
+            sstore(rzB, rxB);
+            __syncthreads();
+            if (rb + 2 * G < nrb) gload(rzB, rxB, rb + 2 * G);
+            compute(rb);
+            __syncthreads();
+            rb += G;
+        }
+    } else {
+        for (; rb < nrb; rb += G) {
+            sstore(rzA, rxA);
+            __syncthreads();
+            if (rb + G < nrb) gload(rzA, rxA, rb + G);
+            compute(rb);
+            __syncthreads();
+        }
     }
 
     // ---- dW: one partial [N_, K_] per workgroup.  256 workgroups adding 16 K floats each into the SAME 64 KB with fp32
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
 #ifdef HOS_MB_TRACE
     if (false) {
 #else
-    if (a.ws != nullptr) {
+    if (a.ws != nullptr && a.ws_dw) {
 #endif
         ew.C = a.ws + (size_t)blockIdx.x * (N_ * K_ + N_); ew.ldc = K_; ew.M = N_; ew.N = K_; ew.epi = HOS_EPI_NONE;
 #pragma unroll
@@ -302,7 +316,8 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
             bool direct = true;
 #ifndef HOS_MB_TRACE
             if (a.ws != nullptr) {      // 256 workgroups x one atomic per bias element on the SAME address cost 10-20 us: slab tail
-                *reinterpret_cast<float4*>(a.ws + (size_t)blockIdx.x * (N_ * K_ + N_) + N_ * K_ + t * 4) = s;
+                const int nk = a.ws_dw ? N_ * K_ : 0;
+                *reinterpret_cast<float4*>(a.ws + (size_t)blockIdx.x * (nk + N_) + nk + t * 4) = s;
                 direct = false;
             }
 #endif
@@ -324,21 +339,23 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
 // y, y + 32, ... (8 of 256): all eight 16-byte loads of a thread are issued before the first add (one memory latency
 // per thread, 2048 blocks in flight), then 32-way fp32 atomics.
 constexpr int MB_RSPLIT = 32;
-__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ ws, int slabs, int n_, int k_, float* __restrict__ dW,
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ ws, int slabs, int n_, int k_, int nk, float* __restrict__ dW,
                                                              int lddw, float* __restrict__ db, int N, int K) {
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int nk = n_ * k_;
     const int slab = nk + n_;                             // [n_][k_] partial of dW, then [n_] partial of db
     if (e >= slab || (e >= nk && db == nullptr)) return;
-    float4 v[8];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int sy = gridDim.y;                             // slabs blockIdx.y, + sy, + 2 sy, ... in rounds of eight loads
+    for (int g0 = blockIdx.y; g0 < slabs; g0 += 8 * sy) {
+        float4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int g = blockIdx.y + i * MB_RSPLIT;
-        v[i] = g < slabs ? *reinterpret_cast<const float4*>(ws + (size_t)g * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 8; ++i) {
+            const int g = g0 + i * sy;
+            v[i] = g < slabs ? *reinterpret_cast<const float4*>(ws + (size_t)g * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
     }
-    float4 s = v[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
     const float sv[4] = {s.x, s.y, s.z, s.w};
     if (e >= nk) {
 #pragma unroll
@@ -354,25 +371,28 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __rest
     }
 }
 
-template <int NT, int KT>
+template <int NT, int KT, bool DG>
 int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
     constexpr int N_ = NT * 32, K_ = KT * 32;
-    constexpr size_t smem = 2 * (size_t)N_ * (K_ * 2 + 32) + 2 * (size_t)MB_R * (N_ * 2 + 32) + 2 * (size_t)MB_R * (K_ * 2 + 32);
+    constexpr int R = mb_rows(DG);
+    constexpr size_t smem = (DG ? 2 * (size_t)N_ * (K_ * 2 + 32) : 0) + 2 * (size_t)R * (N_ * 2 + 32) + 2 * (size_t)R * (K_ * 2 + 32);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NT, KT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_bwd_kernel<NT, KT, DG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const int nrb = hos_cdiv(a.M, MB_R);
+    const int nrb = hos_cdiv(a.M, R);
     const int grid = nrb < 256 ? nrb : 256;
-    if (a.ws != nullptr && (grid < 32 || ws_floats < (size_t)grid * (N_ * K_ + N_))) a.ws = nullptr;   // few workgroups: atomics are fine
-    hipLaunchKernelGGL((mlp_bwd_kernel<NT, KT>), dim3(grid), dim3(MB_NT), smem, stream, a);
+    a.ws_dw = 1;
+    const int nk = a.ws_dw ? N_ * K_ : 0;
+    if (a.ws != nullptr && (grid < 32 || ws_floats < (size_t)grid * (nk + N_) || (!a.ws_dw && a.db == nullptr))) a.ws = nullptr;
+    hipLaunchKernelGGL((mlp_bwd_kernel<NT, KT, DG>), dim3(grid), dim3(MB_NT), smem, stream, a);
 #ifndef HOS_MB_TRACE
     if (a.ws != nullptr)
-        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(N_ * K_ + N_, 1024), MB_RSPLIT), dim3(256), 0, stream,
-                           a.ws, grid, N_, K_, a.dW, a.lddw, a.db, a.N, a.K);
+        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), DG ? MB_RSPLIT : 8), dim3(256), 0, stream,
+                           a.ws, grid, N_, K_, nk, a.dW, a.lddw, a.db, a.N, a.K);
 #endif
     return hos_launch_status();
 }
@@ -389,10 +409,27 @@ extern "C" int hos_linear_bwd_fused(const float* dZ, int lddz, const float* X, i
     if (N > 128 || K > 128) return HOS_E_SHAPE;
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (K & 3) || (dX && (lddx & 3))) return HOS_E_ALIGN;
     if (((uintptr_t)dZ | (uintptr_t)X | (uintptr_t)W | (uintptr_t)ws) & 15u) return HOS_E_ALIGN;
-    MlpBwdArgs a{dZ, lddz, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, relu_mask, ws};
+    MlpBwdArgs a{dZ, lddz, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, relu_mask, ws, 1};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = hos_cdiv(N, 32), kt = hos_cdiv(K, 32);
-    if (nt <= 1 && kt <= 4) return launch_mb<1, 4>(a, (size_t)ws_floats, s);
-    if (kt <= 2) return launch_mb<4, 2>(a, (size_t)ws_floats, s);
-    return launch_mb<4, 4>(a, (size_t)ws_floats, s);
+    if (nt <= 1 && kt <= 4) return launch_mb<1, 4, true>(a, (size_t)ws_floats, s);
+    if (kt <= 2) return launch_mb<4, 2, true>(a, (size_t)ws_floats, s);
+    return launch_mb<4, 4, true>(a, (size_t)ws_floats, s);
+}
+
+// WGRAD of a wider layer with the same staging (fp32 operands split once into LDS planes, transposed LDS reads, no VALU
+// transposes): dW [N, lddw] += dZ^T . X, db [N] += column sums.  N <= 256, K <= 256, K % 4 == 0.  The split-K partials of
+// the 256 workgroups (and their db partials) go through `ws` (>= 256*(256*256+256) floats = 67 MB; NULL or smaller: fp32 atomics,
+// measured 72 us of fixed cost per launch against ~30 us for the slab write + reduce).
+extern "C" int hos_linear_wgrad_tr(const float* dZ, int lddz, const float* X, int ldx, float* dW, int lddw, float* db,
+                                   int M, int N, int K, float* ws, int64_t ws_floats, hos_stream_t stream) {
+    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+    if (N > 256 || K > 256) return HOS_E_SHAPE;
+    if ((lddz & 3) || (ldx & 3) || (K & 3)) return HOS_E_ALIGN;
+    if (((uintptr_t)dZ | (uintptr_t)X) & 15u) return HOS_E_ALIGN;
+    MlpBwdArgs a{dZ, lddz, X, ldx, nullptr, 0, nullptr, 0, dW, lddw, db, M, N, K, 0, ws, 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int kt = hos_cdiv(K, 32);
+    if (kt <= 4) return launch_mb<8, 4, false>(a, (size_t)ws_floats, s);
+    return launch_mb<8, 8, false>(a, (size_t)ws_floats, s);
 }

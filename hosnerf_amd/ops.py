@@ -120,6 +120,15 @@ def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Option
                  w_col0: int = 0, splits: int = 0):
     """dW[:N, w_col0:w_col0+K] += dY[:, :N]^T @ X[:, :K];  db[:N] += colsum(dY[:, :N])."""
     M = dY.shape[0]
+    if WGRAD_TR and 128 < N <= 256 and M >= 16384 and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3:
+        # many rows, thin layer: staged-planes kernel with transposed LDS reads (hos_mlpbwd.hip), K in chunks of <= 256
+        ws = _bwd_workspace(dY.device)
+        for k0 in range(0, K, 256):
+            kc = min(256, K - k0)
+            _timed(f"wgrad_tr[M={N},N={kc},K={M}]", 2.0 * M * N * kc, lambda: call(
+                "hos_linear_wgrad_tr", ptr(dY), dY.stride(0), ptr(X) + 4 * k0, X.stride(0), ptr(dW) + 4 * (w_col0 + k0), dW.stride(0),
+                ptr(db) if k0 == 0 else None, M, N, kc, ptr(ws), ws.numel()))
+        return
     _timed(f"gemm_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
         "hos_linear_wgrad", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0),
         ptr(db), M, N, K, splits))
@@ -142,15 +151,16 @@ _BWD_WS = {}
 
 
 def _bwd_workspace(device) -> torch.Tensor:
-    """16.9 MB of per-workgroup dW / db partials for hos_linear_bwd_fused; one per device -- launches on a stream are ordered and
+    """67 MB of per-workgroup dW / db partials (256 slabs of up to 256 x 256 + 256 floats) for hos_linear_bwd_fused; one per device -- launches on a stream are ordered and
     the reduce kernel that reads it is enqueued by the same call."""
     key = str(device)
     if key not in _BWD_WS:
-        _BWD_WS[key] = torch.empty(256 * (128 * 128 + 128), device=device)
+        _BWD_WS[key] = torch.empty(256 * (256 * 256 + 256), device=device)
     return _BWD_WS[key]
 
 
 FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"
+WGRAD_TR = os.environ.get("HOS_WGRAD_TR", "1") != "0"
 
 
 class gemm_mode:

@@ -95,6 +95,12 @@ int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, con
                          float* dX, int lddx, float* dW, int lddw, float* db, int M, int N, int K,
                          int relu_mask, float* ws, int64_t ws_floats, hos_stream_t stream);
 
+/* WGRAD of a layer up to 256 x 256 with the staging of hos_linear_bwd_fused (operands split once into LDS planes, transposed
+ * LDS reads instead of in-register transposes): dW [N,ldw] += dY^T . X, db [N] += column sums (NULL: skip).  ws: optional
+ * scratch (>= 256*(256*256+256) floats) for the per-workgroup dW / db partials (NULL: fp32 atomics).  Replaces hos_linear_wgrad for M >> N, K. */
+int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
+                        int M, int N, int K, float* ws, int64_t ws_floats, hos_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward
  * side, bf16 for gradients), staged by LDS-DMA, 3 MFMAs per product.  The producer of a tensor does the split once;

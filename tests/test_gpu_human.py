@@ -277,3 +277,33 @@ def test_linear_bwd_fused(dev, M, N, K, relu, wcol0, ldw):
         ops.linear_dgrad(dYd, Wd, Np, K, out2, mask_src=Xd if relu else None, w_col0=wcol0)
         assert float((out - out2).abs().max()) < 1e-5 * sx
         assert float((dW - 0.5 - dW2)[:N, wcol0:wcol0 + K].abs().max()) < 2e-5 * sw
+
+
+@pytest.mark.parametrize("M,N,K,wcol0,ldw", [(20000, 256, 256, 0, 256), (16390, 256, 384, 0, 384), (33001, 200, 100, 4, 128), (16384, 256, 128, 128, 256)])
+def test_linear_wgrad_tr(dev, M, N, K, wcol0, ldw):
+    """hos_linear_wgrad_tr (the route ops.linear_wgrad takes for 128 < N <= 256 and many rows) against fp64."""
+    from hosnerf_amd import ops
+    assert ops.WGRAD_TR
+    g = torch.Generator().manual_seed(M + K)
+    Np = (N + 31) // 32 * 32
+    dY = torch.zeros(M, Np)
+    dY[:, :N] = torch.randn(M, N, generator=g) * 1e-3
+    X = torch.relu(torch.randn(M, K, generator=g))
+    dW = torch.full((Np, ldw), 0.5, device=dev)
+    db = torch.full((Np,), 0.25, device=dev)
+    ev = ops.KernelEvents()
+    ops.set_kernel_events(ev)
+    try:
+        ops.linear_wgrad(dY.to(dev), X.to(dev), dW, db, N, K, w_col0=wcol0)
+    finally:
+        ops.set_kernel_events(None)
+    assert all(k.startswith("wgrad_tr") for k in ev.records), list(ev.records)
+    dW64 = dY[:, :N].double().t() @ X.double()
+    db64 = dY[:, :N].double().sum(0)
+    got = dW.cpu().double()
+    assert float((got[:N, wcol0:wcol0 + K] - 0.5 - dW64).abs().max()) < 3e-5 * float(dW64.abs().max())
+    keep = torch.ones(Np, ldw, dtype=torch.bool)
+    keep[:N, wcol0:wcol0 + K] = False
+    assert bool((got[keep] == 0.5).all())
+    assert float((db.cpu().double()[:N] - 0.25 - db64).abs().max()) < 3e-5 * float(db64.abs().max()) + 1e-7
+    assert bool((db.cpu()[N:] == 0.25).all())
