@@ -12,6 +12,13 @@
 // point = 12 B in (o,d,near,far amortised) + 32 B out (z, pts, x_skel, mask) + 26*8*4 B of L2 gathers.
 #include "hos_common.h"
 
+#include <cstdlib>
+// workgroups of the persistent backward kernels (they keep per-block partial sums in LDS and flush them once)
+static inline long persist_grid() {
+    static const long g = getenv("HOS_PERSIST_GRID") ? atol(getenv("HOS_PERSIST_GRID")) : 256;
+    return g > 0 ? g : 256;
+}
+
 namespace {
 
 constexpr int KMAX = 32;   // bones
@@ -662,7 +669,7 @@ extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || V < 2) return HOS_E_SHAPE;
     const long sw_chunks = (P + 255) / 256;
-    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)(sw_chunks < 256 ? sw_chunks : 256)), dim3(256), 0,
+    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)(sw_chunks < persist_grid() ? sw_chunks : persist_grid())), dim3(256), 0,
                        static_cast<hipStream_t>(stream), pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K, g_x_skel,
                        g_mask, g_vol, g_R, g_T);
     return hos_launch_status();
@@ -676,7 +683,7 @@ extern "C" int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, con
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || CL < K || (CL & 3) || V < 2) return HOS_E_SHAPE;
     const long lb_chunks = (P + 255) / 256;
-    hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)(lb_chunks < 256 ? lb_chunks : 256)), dim3(256), 0,
+    hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)(lb_chunks < persist_grid() ? lb_chunks : persist_grid())), dim3(256), 0,
                        static_cast<hipStream_t>(stream), cnl_pts, R_fwd, T_fwd, vol_cl, V, CL, bbox_min, bbox_scale,
                        (long)P, K, g_x_deform, g_cnl, g_vol_cl, g_R, g_T);
     return hos_launch_status();

@@ -97,7 +97,8 @@ int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, con
 
 /* WGRAD of a layer up to 256 x 256 with the staging of hos_linear_bwd_fused (operands split once into LDS planes, transposed
  * LDS reads instead of in-register transposes): dW [N,ldw] += dY^T . X, db [N] += column sums (NULL: skip).  ws: optional
- * scratch (>= 256*(256*256+256) floats) for the per-workgroup dW / db partials (NULL: fp32 atomics).  Replaces hos_linear_wgrad for M >> N, K. */
+ * scratch (>= 256*(256*256+256) floats) for the per-workgroup dW / db partials (NULL: fp32 atomics).  Replaces hos_linear_wgrad for M >> N, K.
+ * Reference: autograd of the 256-wide nn.Linear layers of CanonicalMLP, canonical_mlps/mlp_rgb_sigma.py:49-58. */
 int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
                         int M, int N, int K, float* ws, int64_t ws_floats, hos_stream_t stream);
 
