@@ -32,6 +32,8 @@ PROTOTYPES = {
     "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P],
     "hos_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "hos_thin_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     "hos_linear_wgrad_tr": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P],
     "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hos_camera_rays": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],

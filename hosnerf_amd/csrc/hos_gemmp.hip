@@ -665,10 +665,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / groups), k = (int)(i % groups) * 4;
         const float* p = ws + (size_t)n * wsld + k;
-        float4 s = *reinterpret_cast<const float4*>(p);
-        for (int j = 1; j < splits; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(p + j * slab);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        // eight independent 16-byte loads per round: one memory latency per round instead of one per slab
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = 0; j0 < splits; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (j0 + u < splits) ? *reinterpret_cast<const float4*>(p + (size_t)(j0 + u) * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
         }
         float* d = dW + (size_t)n * ldw + k;
         const float vals[4] = {s.x, s.y, s.z, s.w};

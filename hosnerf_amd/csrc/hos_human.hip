@@ -319,7 +319,11 @@ __device__ __forceinline__ float trilinear_zero_grad(const float* __restrict__ v
             }
             if (lane >= off) flag |= f_up;
         }
+#ifdef HOS_EXP_NO_SCATTER      // timing experiment: everything but the atomics (results invalid)
+        if (false) {
+#else
         if (act && tail) {
+#endif
 #pragma unroll
             for (int dz = 0; dz < 2; ++dz)
 #pragma unroll

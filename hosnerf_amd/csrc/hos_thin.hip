@@ -1,0 +1,281 @@
+// Thin-layer GEMMs with REGISTER-RESIDENT weights:   C[M, N] = epi(A[M, K] . B^T),  N, K <= 256,  M = rays x samples >> N.
+//
+// The 256-wide canonical MLP of the human branch runs at M = 262 144 rows.  A tiled GEMM re-reads the whole 256 x 256
+// weight for every 256-row tile (as many bytes again as the activations), has only eight K tiles to hide its prologue and
+// epilogue behind, and -- on fp32 operands -- spends half its issue slots converting: 217 us forward / 267 us DGRAD per
+// layer = 2.5-3 TB/s.  Here a workgroup is persistent, each of its 8 waves owns 32 output columns and keeps ITS slice of
+// the weight as ready-made MFMA B fragments in registers for the whole launch (16 reduction steps x (hi, lo) x 4 VGPRs =
+// 128 VGPRs; 8 waves x 64 lanes x 512 B = the 256 KB that do not fit LDS), and the only thing that streams is the
+// activation tile: read once from HBM, split into 16-bit (hi, lo) planes while it is staged to LDS (double buffered),
+// read as A fragments by all eight waves.  HBM traffic = A in + C out (+ the ReLU mask source for DGRAD).
+//   FWD  : B[n][k] = W[n][k]   (nn.Linear weight rows are k-contiguous: two 16-byte loads per fragment), fp16 hi/lo
+//   DGRAD: B[k][n] = W[n][k]   (column gather, once per launch), bf16 hi/lo, ReLU mask of the layer input staged as bytes
+//   products: a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate (hos_gemm3.hip)
+//   roofline: HBM, 8 B (FWD) / 12 B (DGRAD) per row and column.
+// Reference: CanonicalMLP.forward, core/nets/human_nerf/canonical_mlps/mlp_rgb_sigma.py:49-58, and its autograd.
+#include "hos_gemm_common.h"
+#include <type_traits>
+
+namespace {
+
+template <typename E> struct V8 { typedef E t __attribute__((ext_vector_type(8))); typedef E q __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ f32x16 mfma_e(const V8<__bf16>::t& a, const V8<__bf16>::t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_e(const V8<_Float16>::t& a, const V8<_Float16>::t& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+template <typename E> __device__ __forceinline__ float hi_of(float x) { return x; }
+template <> __device__ __forceinline__ float hi_of<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+
+template <typename E>
+__device__ __forceinline__ void split_pair(float x, E& hi, E& lo) {
+    hi = (E)hi_of<E>(x);
+    lo = (E)(x - (float)hi);
+}
+
+struct ThinArgs {
+    const float* A; int lda;          // activations (FWD: layer input; DGRAD: dZ)
+    const float* W; int ldw;          // nn.Linear weight [Nout_fwd, ldw]
+    const float* bias;                // FWD only (may be NULL)
+    float* C; int ldc;
+    int M, N, K;                      // C is [M, N]; reduction length K
+    int epi;                          // FWD: HOS_EPI_NONE / HOS_EPI_RELU
+    const float* mask; int ldmask;    // DGRAD: ReLU mask source [M, >= N] (NULL: none)
+};
+
+constexpr int TH_NT = 512;
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// KS: reduction steps of 16 (K <= 16 KS).  R: rows per tile (64 FWD, 32 DGRAD: the mask tile needs the registers).
+template <int KS, bool DGRAD>
+__global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
+    typedef typename std::conditional<DGRAD, __bf16, _Float16>::type E;
+    typedef typename V8<E>::t e8;
+    typedef typename V8<E>::q e4;
+    constexpr int R = DGRAD ? 32 : 64;
+    constexpr int KD = KS * 16;
+    constexpr int P = KD * 2 + 32;                       // LDS row pitch of one plane (bytes): +32 B = 8 banks per row
+    constexpr int PLANE = R * P, BUF = 2 * PLANE;        // hi, lo
+    constexpr int MSK = DGRAD ? R * 256 : 0;             // mask bytes [R][256] per buffer
+    constexpr int AU = R * (KD / 4) / TH_NT;             // float4 units of the A tile per thread
+    constexpr int MU = DGRAD ? R * 64 / TH_NT : 1;       // float4 units of the mask tile per thread (256 columns)
+    static_assert(AU >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_th[];
+    char* const buf0 = smem_th;
+    char* const msk0 = smem_th + 2 * BUF;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int col0 = wave * 32;                          // this wave's output columns
+#ifdef HOS_TH_TRACE   // timing experiment: phase stamps of workgroup 0 / wave 0 over the bias array (results invalid)
+    long long* const trb = reinterpret_cast<long long*>(const_cast<float*>(a.bias));
+    int trn = 0;
+#define TH_STAMP() do { if (blockIdx.x == 0 && t == 0 && trn < 120) trb[trn++] = clock64(); } while (0)
+#else
+#define TH_STAMP() do {} while (0)
+#endif
+    TH_STAMP();
+
+    // ---- this wave's slice of the weight as B fragments (hi, lo), once
+    e8 bh[KS], bl[KS];
+    {
+        const int j = col0 + l31;                        // output column = B row
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float w[8];
+            const int k0 = 16 * s + 8 * lhi;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = 0.f;
+            if (j < a.N) {
+                if constexpr (!DGRAD) {
+                    if (k0 + 7 < a.K) {
+                        const float4 u = ld4(a.W + (size_t)j * a.ldw + k0), v = ld4(a.W + (size_t)j * a.ldw + k0 + 4);
+                        w[0] = u.x; w[1] = u.y; w[2] = u.z; w[3] = u.w; w[4] = v.x; w[5] = v.y; w[6] = v.z; w[7] = v.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) if (k0 + q < a.K) w[q] = a.W[(size_t)j * a.ldw + k0 + q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (k0 + q < a.K) w[q] = a.W[(size_t)(k0 + q) * a.ldw + j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { E h, l; split_pair<E>(w[q], h, l); bh[s][q] = h; bl[s][q] = l; }
+        }
+    }
+
+    float4 ra[AU], rm[MU];
+    auto gload = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            const int gr = tile * R + row;
+            ra[i] = (gr < a.M && c4 * 4 < a.K) ? ld4(a.A + (size_t)gr * a.lda + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (DGRAD) {
+            if (a.mask != nullptr) {
+#pragma unroll
+                for (int i = 0; i < MU; ++i) {
+                    const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
+                    const int gr = tile * R + row;
+                    rm[i] = (gr < a.M && c4 * 4 < a.N) ? ld4(a.mask + (size_t)gr * a.ldmask + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto sstore = [&](int b) {
+        char* const hi = buf0 + b * BUF;
+        char* const lo = hi + PLANE;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            e4 h, l;
+            const float xs[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { E hh, ll; split_pair<E>(xs[q], hh, ll); h[q] = hh; l[q] = ll; }
+            *reinterpret_cast<e4*>(hi + row * P + c4 * 8) = h;
+            *reinterpret_cast<e4*>(lo + row * P + c4 * 8) = l;
+        }
+        if constexpr (DGRAD) {
+            if (a.mask != nullptr) {
+#pragma unroll
+                for (int i = 0; i < MU; ++i) {
+                    const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
+                    const uint32_t m = (rm[i].x > 0.f ? 1u : 0u) | (rm[i].y > 0.f ? 0x100u : 0u) | (rm[i].z > 0.f ? 0x10000u : 0u) |
+                                       (rm[i].w > 0.f ? 0x1000000u : 0u);
+                    *reinterpret_cast<uint32_t*>(msk0 + b * MSK + row * 256 + c4 * 4) = m;
+                }
+            }
+        }
+    };
+
+    GemmArgs ef{};                                       // FWD epilogue (bias, ReLU, 16-byte stores)
+    ef.C = a.C; ef.ldc = a.ldc; ef.M = a.M; ef.N = a.N; ef.bias = a.bias; ef.epi = a.epi;
+
+    const int ntiles = (a.M + R - 1) / R;
+    const int G = gridDim.x;
+    int tile = blockIdx.x;
+    TH_STAMP();
+    if (tile < ntiles) { gload(tile); sstore(0); }
+    if (tile + G < ntiles) gload(tile + G);              // registers are free again: the second tile starts travelling
+    __syncthreads();
+    TH_STAMP();
+    int b = 0;
+    for (; tile < ntiles; tile += G, b ^= 1) {
+        const bool more = tile + G < ntiles;
+        TH_STAMP();
+        const char* hi = buf0 + b * BUF + l31 * P + lhi * 16;
+        f32x16 acc[R / 32];
+#pragma unroll
+        for (int rt = 0; rt < R / 32; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int rt = 0; rt < R / 32; ++rt) {
+                const e8 ah = *reinterpret_cast<const e8*>(hi + rt * 32 * P + s * 32);
+                const e8 al = *reinterpret_cast<const e8*>(hi + PLANE + rt * 32 * P + s * 32);
+                acc[rt] = mfma_e(al, bh[s], acc[rt]);
+                acc[rt] = mfma_e(ah, bl[s], acc[rt]);
+                acc[rt] = mfma_e(ah, bh[s], acc[rt]);
+            }
+        }
+        TH_STAMP();
+        // Stage the next tile BEFORE this tile's stores: vmcnt retires in order, so converting the prefetched registers
+        // after the epilogue would first wait for every store just issued (a full HBM write round trip per tile).
+        if (more) sstore(b ^ 1);
+        // ... and the staging registers are free: the tile after next travels during this tile's stores, the barrier and the
+        // whole next compute phase (a load issued at the top of an iteration had ~1 k cycles of cover, measured 10 k waiting)
+        if (tile + 2 * G < ntiles) gload(tile + 2 * G);
+        TH_STAMP();
+        if (col0 < a.N) {
+#pragma unroll
+            for (int rt = 0; rt < R / 32; ++rt) {
+                const int row0 = tile * R + rt * 32;
+                if constexpr (!DGRAD) {
+                    gemm_epilogue_tile<MODE_FWD>(ef, acc[rt], row0, col0, lane);
+                } else {
+                    // quad transpose -> a lane owns four consecutive columns of one row; mask bytes from LDS; 16-byte stores
+                    const int q = l31 & 3, colb = col0 + (l31 & ~3);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v0 = acc[rt][4 * g + 0], v1 = acc[rt][4 * g + 1], v2 = acc[rt][4 * g + 2], v3 = acc[rt][4 * g + 3];
+                        {
+                            const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
+                            const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+                            if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+                            const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
+                            const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
+                            if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+                        }
+                        const int lrow = q + 8 * g + 4 * lhi, row = row0 + lrow;
+                        if (row >= a.M || colb >= a.N) continue;
+                        float v[4] = {v0, v1, v2, v3};
+                        if (a.mask != nullptr) {
+                            const uint32_t m = *reinterpret_cast<const uint32_t*>(msk0 + b * MSK + (rt * 32 + lrow) * 256 + colb);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (!((m >> (8 * k)) & 1u)) v[k] = 0.f;
+                        }
+                        float* dst = a.C + (size_t)row * a.ldc + colb;
+                        if (colb + 3 < a.N && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (colb + k < a.N) dst[k] = v[k];
+                        }
+                    }
+                }
+            }
+        }
+        TH_STAMP();
+        __syncthreads();                                 // next buffer complete; this one free for the tile after next
+    }
+    TH_STAMP();
+#undef TH_STAMP
+}
+
+template <int KS, bool DGRAD>
+int launch_thin(const ThinArgs& a, hipStream_t stream) {
+    constexpr int R = DGRAD ? 32 : 64;
+    constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + 32) + (DGRAD ? 2 * (size_t)R * 256 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_gemm_kernel<KS, DGRAD>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntiles = hos_cdiv(a.M, R);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((thin_gemm_kernel<KS, DGRAD>), dim3(grid), dim3(TH_NT), smem, stream, a);
+    return hos_launch_status();
+}
+
+}  // namespace
+
+// Y[M, N] = epi(X[M, :K] . W[:N, :K]^T + bias), N <= 256, K <= 256 (K % 4 == 0), epilogue HOS_EPI_NONE or HOS_EPI_RELU.
+extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                                   int M, int N, int K, int epilogue, hos_stream_t stream) {
+    if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+    if (N > 256 || K > 256 || (epilogue != HOS_EPI_NONE && epilogue != HOS_EPI_RELU)) return HOS_E_SHAPE;
+    if ((ldx & 3) || (ldw & 3) || (K & 3) || (((uintptr_t)X | (uintptr_t)W) & 15u)) return HOS_E_ALIGN;
+    ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return K <= 128 ? launch_thin<8, false>(a, s) : launch_thin<16, false>(a, s);
+}
+
+// dX[M, K] = (dY[M, :Npad] . W[:Npad, :K]) * [mask > 0], K <= 256 output columns, Npad <= 256 (Npad % 4 == 0; rows of W and
+// columns of dY beyond the layer's width are zero by contract).  mask: the layer's input activations [M, >= K] or NULL.
+extern "C" int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
+                                     float* dX, int lddx, int M, int K, hos_stream_t stream) {
+    if (!dY || !W || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
+    if (K > 256 || Npad > 256) return HOS_E_SHAPE;
+    if ((lddy & 3) || (Npad & 3) || (mask && (ldmask & 3)) || (((uintptr_t)dY | (uintptr_t)mask) & 15u)) return HOS_E_ALIGN;
+    ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask, ldmask};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return Npad <= 128 ? launch_thin<8, true>(a, s) : launch_thin<16, true>(a, s);
+}

@@ -98,6 +98,13 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
     M = A0.shape[0] if M is None else M
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
+    if (THIN_GEMM and A1 is None and N <= 256 and 128 < K0 <= 256 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
+            and ldc is None and out is not None and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
+        # many rows through a thin layer: persistent kernel with the weight in registers (hos_thin.hip)
+        _timed(f"thin_fwd[M={M},N={N},K={K0}]", 2.0 * M * N * K0, lambda: call(
+            "hos_thin_linear_fwd", ptr(A0), A0.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, out.stride(0),
+            M, N, K0, epilogue))
+        return out
     _timed(f"gemm_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linear_fwd", ptr(A0), A0.stride(0), K0, ptr(A1), 0 if A1 is None else A1.stride(0), K1,
         ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, (0 if out is None else out.stride(0)) if ldc is None else ldc,
@@ -110,6 +117,12 @@ def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torc
     """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src > 0)."""
     M = dY.shape[0]
     wptr = ptr(W) + 4 * w_col0
+    if (THIN_GEMM and not accumulate and 128 < Npad <= 256 and 128 < K <= 256 and M >= 16384
+            and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
+        _timed(f"thin_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
+            "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
+            0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K))
+        return out
     _timed(f"gemm_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
         "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
         0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K, int(accumulate)))
@@ -161,6 +174,8 @@ def _bwd_workspace(device) -> torch.Tensor:
 
 FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"
 WGRAD_TR = os.environ.get("HOS_WGRAD_TR", "1") != "0"
+THIN_GEMM = os.environ.get("HOS_THIN_GEMM", "1") != "0"
+WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "0") == "1"       # planes WGRAD: split-K partials through the slab workspace
 
 
 class gemm_mode:
@@ -744,7 +759,7 @@ def linearp_wgrad(dZ: Planes, X: Planes, dW: torch.Tensor, db, M: int, N: int, K
     """dW[:, w_col0:w_col0+K] += dZ^T @ X[:, x_col0:x_col0+K]; db += column sums of dZ (row-major bf16 planes).
     use_ws=True sums the split-K partial tiles through a workspace in a fixed order (bit-reproducible; measured
     time-neutral at 1024x1024, slower for the 256-wide proposal MLPs) instead of fp32 atomics."""
-    ws = _wgrad_workspace(dW.device) if use_ws else None
+    ws = _wgrad_workspace(dW.device) if (use_ws or WGRAD_WS) else None
     _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
         "hos_linearp_wgrad", _pp(dZ), dZ.ld, _pp(X), X.ld, x_col0,
         ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits, ptr(ws), 0 if ws is None else ws.numel()))

@@ -102,6 +102,16 @@ int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, con
 int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
                         int M, int N, int K, float* ws, int64_t ws_floats, hos_stream_t stream);
 
+/* Thin layers over very many rows with the weight slice of every wave resident in registers (hos_thin.hip): N, K <= 256.
+ *   hos_thin_linear_fwd  : Y [M,N] = epi(X[:, :K] . W[:N, :K]^T + bias), epilogue HOS_EPI_NONE / HOS_EPI_RELU (fp16 hi/lo x3)
+ *   hos_thin_linear_dgrad: dX [M,K] = (dY[:, :Npad] . W[:Npad, :K]) * [mask > 0]  (bf16 hi/lo x3; mask NULL: none)
+ * Same results contract as hos_linear_fwd / hos_linear_dgrad in split mode.
+ * Reference: CanonicalMLP, canonical_mlps/mlp_rgb_sigma.py:49-58 (256-wide Linear + ReLU chain at M = rays x 128). */
+int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
+                        int M, int N, int K, int epilogue, hos_stream_t stream);
+int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
+                          float* dX, int lddx, int M, int K, hos_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward
  * side, bf16 for gradients), staged by LDS-DMA, 3 MFMAs per product.  The producer of a tensor does the split once;

@@ -307,3 +307,54 @@ def test_linear_wgrad_tr(dev, M, N, K, wcol0, ldw):
     assert bool((got[keep] == 0.5).all())
     assert float((db.cpu().double()[:N] - 0.25 - db64).abs().max()) < 3e-5 * float(db64.abs().max()) + 1e-7
     assert bool((db.cpu()[N:] == 0.25).all())
+
+
+@pytest.mark.parametrize("M,N,K,relu,col0", [(20000, 256, 256, True, 0), (16390, 256, 256, True, 127), (33001, 200, 132, False, 0)])
+def test_thin_linear_fwd(dev, M, N, K, relu, col0):
+    """hos_thin_linear_fwd (the route ops.linear_fwd takes for 128 < K <= 256, N <= 256 and many rows) against fp64;
+    col0 = 127 is the canonical MLP's skip layer writing into the concat buffer at an unaligned column."""
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    X = torch.relu(torch.randn(M, 256, generator=g))
+    W = torch.randn(256, 256, generator=g) / 16
+    bias = torch.randn(256, generator=g) * 0.1
+    out = torch.full((M, col0 + 256), float("nan"), device=dev)
+    ev = ops.KernelEvents()
+    ops.set_kernel_events(ev)
+    try:
+        ops.linear_fwd(X.to(dev), K, W.to(dev), bias.to(dev), N, out, ops.EPI_RELU if relu else ops.EPI_NONE, out_col0=col0)
+    finally:
+        ops.set_kernel_events(None)
+    assert all(k.startswith("thin_fwd") for k in ev.records), list(ev.records)
+    want = X[:, :K].double() @ W[:N, :K].double().t() + bias[:N].double()
+    if relu:
+        want = torch.relu(want)
+    got = out[:, col0:col0 + N].double().cpu()
+    assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    assert bool(torch.isnan(out[:, :col0]).all()) and bool(torch.isnan(out[:, col0 + N:]).all())
+
+
+@pytest.mark.parametrize("M,Npad,K,masked", [(20000, 256, 256, True), (16400, 256, 256, False), (33001, 160, 200, True)])
+def test_thin_linear_dgrad(dev, M, Npad, K, masked):
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    dY = torch.randn(M, 256, generator=g) * 1e-3
+    dY[:, Npad:] = 0.0
+    W = torch.zeros(256, 256)
+    W[:Npad] = torch.randn(Npad, 256, generator=g) / 16
+    Xact = torch.randn(M, 256, generator=g)
+    Xact = torch.where(torch.rand(M, 256, generator=g) < 0.4, torch.zeros_like(Xact), Xact.abs())
+    out = torch.full((M, 256), float("nan"), device=dev)
+    ev = ops.KernelEvents()
+    ops.set_kernel_events(ev)
+    try:
+        ops.linear_dgrad(dY.to(dev), W.to(dev), Npad, K, out, mask_src=Xact.to(dev) if masked else None)
+    finally:
+        ops.set_kernel_events(None)
+    assert all(k.startswith("thin_dgrad") for k in ev.records), list(ev.records)
+    want = dY[:, :Npad].double() @ W[:Npad, :K].double()
+    if masked:
+        want = want * (Xact[:, :K] > 0)
+    got = out[:, :K].double().cpu()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+    assert bool(torch.isnan(out[:, K:]).all())
