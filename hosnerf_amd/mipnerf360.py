@@ -544,8 +544,13 @@ class MipNeRF360(FlatModule):
                  dilation_bias: float = 0.0025, num_glo_features: int = 0, num_glo_embeddings: int = 1000,
                  learned_exposure_scaling: bool = False, near_anneal_rate: Optional[float] = None,
                  near_anneal_init: float = 0.95, single_mlp: bool = False, resample_padding: float = 0.0,
-                 use_gpu_resampling: bool = False, opaque_background: bool = False, render_levels: bool = True):
+                 use_gpu_resampling: bool = False, opaque_background: bool = False, render_levels: bool = True,
+                 train_proposals: Optional[bool] = None):
         super().__init__()
+        # Stage 3 (render_levels=False) has no interlevel loss and the resampling is detached (stop_level_grad): the proposal
+        # MLPs receive no gradient there, so their queries need not keep anything for a backward pass.
+        if train_proposals is None:
+            train_proposals = render_levels
         for name, value in list(locals().items()):
             if name not in ("self", "__class__"):
                 setattr(self, name, value)
@@ -592,7 +597,11 @@ class MipNeRF360(FlatModule):
             out = ops.resample(sdist, weights, S, dilation, anneal, bool(randomized), near, far, jitter=jit,
                                resample_padding=self.resample_padding, want_index=want_index)
             sdist, tdist = out[0], out[1]
-            res = self.mlps[lvl].query(tdist, rays_o, rays_d, radii, viewdirs, time)
+            if is_prop and not self.train_proposals:
+                with torch.no_grad():
+                    res = self.mlps[lvl].query(tdist, rays_o, rays_d, radii, viewdirs, time)
+            else:
+                res = self.mlps[lvl].query(tdist, rays_o, rays_d, radii, viewdirs, time)
             weights = ops.alpha_weights(res["density"], tdist, rays_d, self.opaque_background)
             res["sdist"], res["tdist"], res["weights"] = sdist, tdist, weights
             if want_index:
