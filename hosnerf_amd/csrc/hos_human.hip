@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ R, const float* __restrict__ T,
     const float* __restrict__ vol, int V, const float* __restrict__ bbox_min, const float* __restrict__ bbox_scale,
     long P, int K, const float* __restrict__ g_xskel, const float* __restrict__ g_mask,
-    float* __restrict__ g_vol, float* __restrict__ g_R, float* __restrict__ g_T) {
+    float* __restrict__ g_vol, float* __restrict__ g_R, float* __restrict__ g_T, float* __restrict__ aux) {
     __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6], sAcc[KMAX * 12];
     for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
     for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     const float gx_ = live ? g_xskel[pp * 3] : 0.f, gy_ = live ? g_xskel[pp * 3 + 1] : 0.f, gz_ = live ? g_xskel[pp * 3 + 2] : 0.f;
     const float gm = live ? g_mask[pp] : 0.f;
     const float gdot_xs = gx_ * xs + gy_ * ys + gz_ * zs;
+    if (aux != nullptr && live) { aux[pp * 2] = den; aux[pp * 2 + 1] = clampg * gdot_xs; }   // for sample_warp_vol_scatter_kernel
     // pass 2: per-bone gradients.  d loss / d q_i of every (point, bone) goes through LDS (16 bones at a time) and the
     // R/T gradients  g_R_i = sum_p gq_pi (x) p,  g_T_i = sum_p gq_pi  are reduced with one thread per (bone, component,
     // 64-point chunk) instead of 12 wave-wide butterfly sums per bone.
@@ -433,6 +434,85 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
             if (c < 9) __hip_atomic_fetch_add(g_R + b * 9 + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else __hip_atomic_fetch_add(g_T + b * 3 + (c - 9), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// Volume gradient of the backward warp, one BONE per workgroup row: g_vol[i] += sum_p gw_pi * tap weights of q_pi.
+// The per-point scatter inside human_sample_warp_bwd_kernel was 60 % of its time (26 bones x 8 taps of scattered 4-byte
+// global atomics per point, 485 of 816 us); a bone's 32^3 gradient volume is 128 KB and fits LDS, so the workgroups of
+// row i accumulate bone i's volume with LDS atomics over their share of the points and flush the non-zero cells once.
+// gw_pi = ((g_p . q_pi) - c_p) / den_p + gm_p with (den_p, c_p) from `aux` (written by human_sample_warp_bwd_kernel).
+__global__ __launch_bounds__(1024) void sample_warp_vol_scatter_kernel(
+    const float* __restrict__ pts, const float* __restrict__ R, const float* __restrict__ T, int V,
+    const float* __restrict__ bbox_min, const float* __restrict__ bbox_scale, long P,
+    const float* __restrict__ g_xskel, const float* __restrict__ g_mask, const float* __restrict__ aux,
+    float* __restrict__ g_vol) {
+    extern __shared__ float s_gvol[];
+    const int i = blockIdx.y;
+    const int V3 = V * V * V;
+    for (int k = threadIdx.x; k < V3; k += blockDim.x) s_gvol[k] = 0.f;
+    float r[9], tt[3], bm[3], bs[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r[k] = R[i * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tt[k] = T[i * 3 + k]; bm[k] = bbox_min[k]; bs[k] = bbox_scale[k]; }
+    __syncthreads();
+    // Consecutive lanes are consecutive samples of a ray and mostly share a voxel cell: the eight tap contributions are
+    // summed over runs of equal cells with a segmented wave scan and only the last lane of a run touches LDS (LDS float
+    // atomics retire at well under one lane per clock: 305 us for the 54 M tap updates of a step without this).
+    const int lane = threadIdx.x & 63;
+    const long span = (long)gridDim.x * blockDim.x;
+    const long p_end = ((P + span - 1) / span) * span;                 // whole waves take part in the shuffles
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < p_end; p += span) {
+        const bool live = p < P;
+        const long pp = live ? p : P - 1;
+        const float px = pts[pp * 3], py = pts[pp * 3 + 1], pz = pts[pp * 3 + 2];
+        const float qx = (r[0] * px + r[1] * py + r[2] * pz) + tt[0];
+        const float qy = (r[3] * px + r[4] * py + r[5] * pz) + tt[1];
+        const float qz = (r[6] * px + r[7] * py + r[8] * pz) + tt[2];
+        const float gw = ((g_xskel[pp * 3] * qx + g_xskel[pp * 3 + 1] * qy + g_xskel[pp * 3 + 2] * qz) - aux[pp * 2 + 1]) / aux[pp * 2] + g_mask[pp];
+        const float gx = (qx - bm[0]) * bs[0] - 1.f, gy = (qy - bm[1]) * bs[1] - 1.f, gz = (qz - bm[2]) * bs[2] - 1.f;
+        const float ix = ((gx + 1.f) / 2.f) * (float)(V - 1), iy = ((gy + 1.f) / 2.f) * (float)(V - 1), iz = ((gz + 1.f) / 2.f) * (float)(V - 1);
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const bool act = live && gw != 0.f && (fx >= -1.f && fx <= (float)V && fy >= -1.f && fy <= (float)V && fz >= -1.f && fz <= (float)V);
+        const int x0 = act ? (int)fx : 0, y0 = act ? (int)fy : 0, z0 = act ? (int)fz : 0;
+        const float wx1 = ix - fx, wy1 = iy - fy, wz1 = iz - fz;
+        const float wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy, wz0 = (fz + 1.f) - iz;
+        float contrib[8];
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+            const int dx = t8 & 1, dy = (t8 >> 1) & 1, dz = t8 >> 2;
+            contrib[t8] = act ? gw * ((dx ? wx1 : wx0) * (dy ? wy1 : wy0) * (dz ? wz1 : wz0)) : 0.f;
+        }
+        const int key = act ? ((z0 + 1) * (V + 2) + (y0 + 1)) * (V + 2) + (x0 + 1) : -1 - lane;
+        const int key_prev = __shfl_up(key, 1, 64);
+        int flag = (lane == 0 || key != key_prev) ? 1 : 0;
+        const int key_next = __shfl_down(key, 1, 64);
+        const bool tail = (lane == 63) || (key_next != key);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int f_up = __shfl_up(flag, off, 64);
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const float v_up = __shfl_up(contrib[t8], off, 64);
+                if (lane >= off && !flag) contrib[t8] += v_up;
+            }
+            if (lane >= off) flag |= f_up;
+        }
+        if (act && tail) {
+#pragma unroll
+            for (int t8 = 0; t8 < 8; ++t8) {
+                const int x = x0 + (t8 & 1), y = y0 + ((t8 >> 1) & 1), z = z0 + (t8 >> 2);
+                if (x >= 0 && x < V && y >= 0 && y < V && z >= 0 && z < V && contrib[t8] != 0.f)
+                    atomicAdd(&s_gvol[(z * V + y) * V + x], contrib[t8]);
+            }
+        }
+    }
+    __syncthreads();
+    float* const out = g_vol + (size_t)i * V3;
+    for (int k = threadIdx.x; k < V3; k += blockDim.x) {
+        const float v = s_gvol[k];
+        if (v != 0.f) __hip_atomic_fetch_add(out + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -692,14 +772,30 @@ __global__ __launch_bounds__(256) void rgbsigma_grad_kernel(const float* __restr
 extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, const float* vol, int V,
                                          const float* bbox_min, const float* bbox_scale, int64_t P, int K,
                                          const float* g_x_skel, const float* g_mask, float* g_vol, float* g_R,
-                                         float* g_T, hos_stream_t stream) {
+                                         float* g_T, float* scratch, hos_stream_t stream) {
     if (!pts || !R || !T || !vol || !bbox_min || !bbox_scale || !g_x_skel || !g_mask || !g_vol || !g_R || !g_T || P <= 0)
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || V < 2) return HOS_E_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const long sw_chunks = (P + 255) / 256;
-    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, dim3((unsigned)(sw_chunks < persist_grid() ? sw_chunks : persist_grid())), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K, g_x_skel,
-                       g_mask, g_vol, g_R, g_T);
+    const dim3 grid((unsigned)(sw_chunks < persist_grid() ? sw_chunks : persist_grid()));
+    // with a scratch [P,2] and a volume that fits LDS the scatter runs as its own bone-per-workgroup pass
+    const size_t vol_bytes = (size_t)V * V * V * sizeof(float);
+    const bool split = scratch != nullptr && vol_bytes <= 128 * 1024 && P >= 8192;
+    hipLaunchKernelGGL(human_sample_warp_bwd_kernel, grid, dim3(256), 0, s, pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K,
+                       g_x_skel, g_mask, split ? (float*)nullptr : g_vol, g_R, g_T, split ? scratch : (float*)nullptr);
+    if (split) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sample_warp_vol_scatter_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const int nb = 256 / K > 0 ? 256 / K : 1;         // one round: at most one workgroup per CU (128 KB of LDS each)
+        hipLaunchKernelGGL(sample_warp_vol_scatter_kernel, dim3(nb, K), dim3(1024), vol_bytes, s, pts, R, T, V, bbox_min,
+                           bbox_scale, (long)P, g_x_skel, g_mask, scratch, g_vol);
+    }
     return hos_launch_status();
 }
 

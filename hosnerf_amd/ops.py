@@ -591,8 +591,9 @@ class _SampleWarp(torch.autograd.Function):
         g_T = torch.zeros_like(T)
         gx = torch.zeros(P, 3, device=pts.device) if g_xskel is None else g_xskel.contiguous()
         gm = torch.zeros(P, device=pts.device) if g_mask is None else g_mask.contiguous()
+        scratch = torch.empty(P, 2, device=pts.device)
         call("hos_human_sample_warp_bwd", ptr(pts), ptr(R), ptr(T), ptr(vol), vol.shape[-1], ptr(bmin), ptr(bscale), P, K,
-             ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T))
+             ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(scratch))
         return g_vol, g_R, g_T, None, None, None, None, None, None, None, None, None
 
 
