@@ -177,7 +177,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
     for (int x = 0; x < TM; ++x)
 #pragma unroll
         for (int y = 0; y < TN; ++y)
-            gemm_epilogue_tile<MODE>(a, acc[x][y], i0 + wm * (TM * 32) + x * 32, j0 + wn * (TN * 32) + y * 32, lane);
+        {
+            const int r0 = i0 + wm * (TM * 32) + x * 32, c0 = j0 + wn * (TN * 32) + y * 32;
+            if constexpr (MODE == MODE_WGRAD) {
+                if (a.kt_per_split >= a.nk) {
+                    // a single split owns the whole reduction: plain 16-byte read-add-write instead of fp32 atomics
+                    // (the decoder's outer-product gradients are 134 MB of them per step)
+                    GemmArgs e = a;
+                    e.mask = nullptr; e.accumulate = 1;
+                    gemm_epilogue_tile<MODE_DGRAD>(e, acc[x][y], r0, c0, lane);
+                } else {
+                    gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
+                }
+            } else if constexpr (MODE == MODE_DGRAD) {
+                // split-K DGRAD (few rows, long weight stream): partial tiles are added with atomics into a zeroed C
+                if (a.kt_per_split < a.nk) gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
+                else gemm_epilogue_tile<MODE_DGRAD>(a, acc[x][y], r0, c0, lane);
+            } else {
+                gemm_epilogue_tile<MODE>(a, acc[x][y], r0, c0, lane);
+            }
+        }
 
     if constexpr (MODE == MODE_WGRAD) {
         if (do_db) {
@@ -276,8 +295,23 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     a.nk = Npad / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
     if (g_gemm_mode == HOS_GEMM_BF16X3 && K > 32) return hos_gemm3_launch(a, MODE_DGRAD, 1, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
+        // A handful of rows against a long weight stream (the volume decoder: 1..8 voxels x [1024, 32768] weights): 32-row
+        // tiles and a split reduction put 3-4 workgroups on every CU, the 128-row tile streamed at ~0.8 TB/s.
+        a.tiles_m = 1; a.tiles_n = hos_cdiv(K, 128);
+        int splits = a.nk / 4 < 4 ? a.nk / 4 : 4;
+        if (a.tiles_n * splits < 512 && a.nk / 8 >= 2) splits = a.nk / 8 < 8 ? a.nk / 8 : 8;
+        a.kt_per_split = hos_cdiv(a.nk, splits);
+        splits = hos_cdiv(a.nk, a.kt_per_split);
+        if (splits > 1) {
+            hipError_t e = hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+        return launch<32, 128, MODE_DGRAD>(a, splits, s);
+    }
     a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(K, 128);
-    return launch<128, 128, MODE_DGRAD>(a, 1, static_cast<hipStream_t>(stream));
+    return launch<128, 128, MODE_DGRAD>(a, 1, s);
 }
 
 extern "C" int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* dW, int ldw,
