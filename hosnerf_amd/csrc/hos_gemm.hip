@@ -17,6 +17,7 @@
 #include "hos_common.h"
 
 #include "hos_gemm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -296,7 +297,8 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
     if (g_gemm_mode == HOS_GEMM_BF16X3 && K > 32) return hos_gemm3_launch(a, MODE_DGRAD, 1, static_cast<hipStream_t>(stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
+    static const bool few_rows_split = !(getenv("HOS_DGRAD_SPLIT") && atoi(getenv("HOS_DGRAD_SPLIT")) == 0);
+    if (few_rows_split && M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
         // A handful of rows against a long weight stream (the volume decoder: 1..8 voxels x [1024, 32768] weights): 32-row
         // tiles and a split reduction put 3-4 workgroups on every CU, the 128-row tile streamed at ~0.8 TB/s.
         a.tiles_m = 1; a.tiles_n = hos_cdiv(K, 128);

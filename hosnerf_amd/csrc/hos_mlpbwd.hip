@@ -14,6 +14,7 @@
 //   roofline: HBM.  12 B x M x 128 per launch; MFMA time is ~1/3 of the memory time at 11 B/clk/CU.
 // Reference: the autograd backward of nn.Linear + ReLU in core/nets/human_nerf/non_rigid_motion_mlps/mlp_offset.py:54-70.
 #include "hos_gemm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -371,6 +372,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __rest
     }
 }
 
+static inline int reduce_split() {
+    static const int v = getenv("HOS_MB_RSPLIT") ? atoi(getenv("HOS_MB_RSPLIT")) : MB_RSPLIT;
+    return v > 0 ? v : MB_RSPLIT;
+}
+
 template <int NT, int KT, bool DG>
 int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
     constexpr int N_ = NT * 32, K_ = KT * 32;
@@ -391,7 +397,7 @@ int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
     hipLaunchKernelGGL((mlp_bwd_kernel<NT, KT, DG>), dim3(grid), dim3(MB_NT), smem, stream, a);
 #ifndef HOS_MB_TRACE
     if (a.ws != nullptr)
-        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), DG ? MB_RSPLIT : 8), dim3(256), 0, stream,
+        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), reduce_split()), dim3(256), 0, stream,
                            a.ws, grid, N_, K_, nk, a.dW, a.lddw, a.db, a.N, a.K);
 #endif
     return hos_launch_status();
