@@ -297,13 +297,18 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     a.mask = Xact; a.ldmask = ldx; a.accumulate = accumulate;
     if (g_gemm_mode == HOS_GEMM_BF16X3 && K > 32) return hos_gemm3_launch(a, MODE_DGRAD, 1, static_cast<hipStream_t>(stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool few_rows_split = !(getenv("HOS_DGRAD_SPLIT") && atoi(getenv("HOS_DGRAD_SPLIT")) == 0);
-    if (few_rows_split && M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
-        // A handful of rows against a long weight stream (the volume decoder: 1..8 voxels x [1024, 32768] weights): 32-row
-        // tiles and a split reduction put 3-4 workgroups on every CU, the 128-row tile streamed at ~0.8 TB/s.
+    // A handful of rows against a long weight stream (the volume decoder: 1..8 voxels x [1024, 32768] weights): 32-row tiles
+    // put 3 workgroups on a CU instead of 2 (the 128-row tile streamed the weights at ~0.8 TB/s).  HOS_DGRAD_SPLIT=1 also
+    // splits the reduction (atomics into a zeroed output: +1 % on a stage-2 step, but the result is no longer
+    // bit-reproducible from call to call, so it is off by default).
+    static const bool few_rows_split = getenv("HOS_DGRAD_SPLIT") && atoi(getenv("HOS_DGRAD_SPLIT")) == 1;
+    if (M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
         a.tiles_m = 1; a.tiles_n = hos_cdiv(K, 128);
-        int splits = a.nk / 4 < 4 ? a.nk / 4 : 4;
-        if (a.tiles_n * splits < 512 && a.nk / 8 >= 2) splits = a.nk / 8 < 8 ? a.nk / 8 : 8;
+        int splits = 1;
+        if (few_rows_split) {
+            splits = a.nk / 4 < 4 ? a.nk / 4 : 4;
+            if (a.tiles_n * splits < 512 && a.nk / 8 >= 2) splits = a.nk / 8 < 8 ? a.nk / 8 : 8;
+        }
         a.kt_per_split = hos_cdiv(a.nk, splits);
         splits = hos_cdiv(a.nk, a.kt_per_split);
         if (splits > 1) {
