@@ -175,7 +175,8 @@ def _bwd_workspace(device) -> torch.Tensor:
 FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"
 WGRAD_TR = os.environ.get("HOS_WGRAD_TR", "1") != "0"
 THIN_GEMM = os.environ.get("HOS_THIN_GEMM", "1") != "0"
-WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "0") == "1"       # planes WGRAD: split-K partials through the slab workspace
+WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "1") == "1"       # planes WGRAD: split-K partials through the slab workspace
+WGRAD_WS_MIN = int(os.environ.get("HOS_WGRAD_WS_MIN", "0"))  # ... for gradients of at least this many elements
 
 
 class gemm_mode:
@@ -758,9 +759,10 @@ def _wgrad_workspace(device: torch.device) -> torch.Tensor:
 def linearp_wgrad(dZ: Planes, X: Planes, dW: torch.Tensor, db, M: int, N: int, K: int, w_col0: int = 0, splits: int = 0,
                   x_col0: int = 0, use_ws: bool = False):
     """dW[:, w_col0:w_col0+K] += dZ^T @ X[:, x_col0:x_col0+K]; db += column sums of dZ (row-major bf16 planes).
-    use_ws=True sums the split-K partial tiles through a workspace in a fixed order (bit-reproducible; measured
-    time-neutral at 1024x1024, slower for the 256-wide proposal MLPs) instead of fp32 atomics."""
-    ws = _wgrad_workspace(dW.device) if (use_ws or WGRAD_WS) else None
+    The split-K partial tiles go through a slab workspace and are summed in a fixed order by default (bit-reproducible and,
+    with the eight-loads-per-round reduce kernel, ~1 % faster on the stage-1 step than fp32 atomics); HOS_WGRAD_WS=0 selects
+    the atomics."""
+    ws = _wgrad_workspace(dW.device) if (use_ws or (WGRAD_WS and N * K >= WGRAD_WS_MIN)) else None
     _timed(f"gemmp_wgrad[M={N},N={K},K={M}]", 2.0 * M * N * K, lambda: call(
         "hos_linearp_wgrad", _pp(dZ), dZ.ld, _pp(X), X.ld, x_col0,
         ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, splits, ptr(ws), 0 if ws is None else ws.numel()))
