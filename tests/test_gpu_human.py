@@ -358,3 +358,36 @@ def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     got = out[:, :K].double().cpu()
     assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
     assert bool(torch.isnan(out[:, K:]).all())
+
+
+@pytest.mark.parametrize("M", [1, 37, 64, 129])
+def test_thin_and_fused_entry_points_small_m(dev, M):
+    """The C-ABI entries are routed to only for many rows, but they are complete kernels: ragged / tiny row counts through
+    the library calls directly (one partial tile, fewer tiles than workgroups)."""
+    from hosnerf_amd._lib import call, ptr
+    g = torch.Generator().manual_seed(M)
+    N = K = 256
+    X = torch.relu(torch.randn(M, K, generator=g)); W = torch.randn(N, K, generator=g) / 16; b = torch.randn(N, generator=g) * 0.1
+    dY = torch.randn(M, N, generator=g) * 1e-3
+    Xd, Wd, bd, dYd = X.to(dev), W.to(dev), b.to(dev), dY.to(dev)
+    Y = torch.full((M, N), float("nan"), device=dev)
+    call("hos_thin_linear_fwd", ptr(Xd), K, ptr(Wd), K, ptr(bd), ptr(Y), N, M, N, K, 1)
+    want = torch.relu(X.double() @ W.double().t() + b.double())
+    assert float((Y.double().cpu() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    dX = torch.full((M, K), float("nan"), device=dev)
+    call("hos_thin_linear_dgrad", ptr(dYd), N, ptr(Wd), K, N, ptr(Xd), K, ptr(dX), K, M, K)
+    want = (dY.double() @ W.double()) * (X > 0)
+    assert float((dX.double().cpu() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
+    call("hos_linear_wgrad_tr", ptr(dYd), N, ptr(Xd), K, ptr(dW), K, ptr(db), M, N, K, None, 0)
+    want = dY.double().t() @ X.double()
+    assert float((dW.double().cpu() - want).abs().max()) < 3e-5 * float(want.abs().max())
+    assert float((db.double().cpu() - dY.double().sum(0)).abs().max()) < 3e-5 * float(dY.double().sum(0).abs().max()) + 1e-8
+    # fused 128-wide backward, no workspace (atomics path)
+    n = k = 128
+    dW2 = torch.zeros(n, k, device=dev); db2 = torch.zeros(n, device=dev); dX2 = torch.empty(M, k, device=dev)
+    call("hos_linear_bwd_fused", ptr(dYd), N, ptr(Xd), K, ptr(Wd), K, ptr(dX2), k, ptr(dW2), k, ptr(db2), M, n, k, 1, None, 0)
+    want = (dY[:, :n].double() @ W[:n, :k].double()) * (X[:, :k] > 0)
+    assert float((dX2.double().cpu() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    want = dY[:, :n].double().t() @ X[:, :k].double()
+    assert float((dW2.double().cpu() - want).abs().max()) < 3e-5 * float(want.abs().max())
