@@ -62,13 +62,42 @@ def test_stage1_vs_torch_rocm():
         torch.nn.utils.clip_grad_norm_(params, 0.001)
         topt.step()
 
-    t_torch = _time(torch_step, 2, 5)
     model = MipNeRF360(_basedir(), opaque_background=True)
     model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
     model = model.to(dev)
     opt = FusedAdam(model, lr=2e-3, max_grad_norm=0.001)
     hb = dict(batch)
     hb["times"] = 0.5
+
+    # ---- FULL-SIZE parity first (BASELINE configs[1]: 1024 rays, 64/64/32 samples): same weights, rays and per-ray
+    # jitters through the oracle's op graph on this device and through the HIP path; the north-star tolerance on RGB.
+    g = torch.Generator().manual_seed(11)
+    jit = [torch.rand(B, generator=g).to(dev) for _ in range(3)]
+    topt.zero_grad()
+    rend_o, hist_o = ob.mipnerf360_forward(sd, batch, 0.5, True, 0.1, 1e6, transitions_times=[0.4], jitters=[j.view(B, 1).cpu() for j in jit])
+    loss_o, _ = ob.stage1_loss(rend_o[-1]["rgb"], batch["target"], hist_o)
+    loss_o.backward()
+    opt.zero_grad()
+    rend_h, hist_h = model(hb, 0.5, True, True, 0.1, 1e6, jitters=jit)
+    loss_h, _ = stage1_loss(rend_h[-1]["rgb"], hb["target"], hist_h)
+    loss_h.backward()
+    par = {"rays": B, "rgb_linf": float((rend_h[-1]["rgb"] - rend_o[-1]["rgb"]).abs().max()),
+           "loss_rel": abs(float(loss_h.detach()) - float(loss_o.detach())) / abs(float(loss_o.detach()))}
+    assert par["rgb_linf"] < 1e-4, par
+    for lvl in range(3):
+        par[f"tdist_linf_level{lvl}"] = float((hist_h[lvl]["tdist"] - hist_o[lvl]["tdist"]).abs().max() / hist_o[lvl]["tdist"].abs().max())
+    assert par["loss_rel"] < 1e-4, par
+    hg = {k: v.grad for k, v in model.named_parameters()}
+    for name in ("mlps.2.pts_linear.3.weight", "mlps.2.pts_linear.7.weight", "mlps.2.density_layer.weight" if "mlps.2.density_layer.weight" in hg else "mlps.2.pts_linear.0.weight",
+                 "mlps.0.pts_linear.1.weight", "mlps.1.pts_linear.2.weight"):
+        go, gh = sd[name].grad, hg[name]
+        par["grad " + name] = float((gh.reshape(go.shape) - go).abs().max()) / max(1e-20, float(go.abs().max()))
+        assert par["grad " + name] < 5e-3, par
+    _record("stage1_fullsize_parity", par)
+    del rend_o, hist_o, rend_h, hist_h, hg
+    opt.zero_grad()
+
+    t_torch = _time(torch_step, 2, 5)
 
     def hip_step():
         opt.zero_grad()
