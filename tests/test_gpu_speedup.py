@@ -205,3 +205,80 @@ def test_stage2_vs_torch_rocm():
     t_hip = _time(hip_step, 4, 16)
     _record("stage2_human", {"rays": B, "torch_rocm_rays_per_s": B / t_torch, "hip_eager_rays_per_s": B / t_hip, "speedup": t_torch / t_hip})
     assert t_torch / t_hip > 2.0, (t_torch, t_hip)
+
+
+def test_stage3_fullsize_parity_and_speedup():
+    """Stage 3 (both branches + z-merged composite) at the bench size of 2048 rays: RGB against the oracle's op graph on the
+    same device (same weights, rays and jitters), then one training step of each timed."""
+    import oracle.background as ob_
+    from hosnerf_amd.hosnerf import HOSNeRF
+    from hosnerf_amd.human_nerf import default_cfg
+    from hosnerf_amd.train import FusedAdam, batch_to_device, human_lr_ranges, stage3_losses
+    dev = torch.device("cuda")
+    B = 2048
+    b = synth.human_batch(B, seed=778, time=0.5, is_train=True, iter_val=3e5)
+    b["ray_grid"] = torch.cat([torch.rand(B, 2) * 100, torch.randn(B, 2), torch.ones(B, 1)], -1)
+    b["newsmpl_to_camera_prev"] = torch.eye(4)
+    b["newsmpl_to_camera_prev"][2, 3] = 3.0
+    b["intrinsics_prev"] = torch.tensor([[500.0, 0, 50], [0, 500.0, 50], [0, 0, 1]])
+    gb = batch_to_device(b, dev)
+    gb_ref = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()}
+    g = torch.Generator().manual_seed(5)
+    t_rand = torch.rand(B, 128, generator=g).to(dev)
+    jit = [torch.rand(B, generator=g) for _ in range(3)]
+    bsd = {k: v.to(dev).requires_grad_(True) for k, v in synth.background_state_dict(777, 2).items()}
+    hsd = {k: v.to(dev).requires_grad_(True) for k, v in synth.human_state_dict(777, 2).items()}
+    bb = {"rays_o": gb_ref["rays_o_bkg"], "rays_d": gb_ref["rays_d_bkg"], "viewdirs": gb_ref["viewdirs_bkg"], "radii": gb_ref["radii"], "times": b["time"]}
+
+    def oracle_render(jitters):
+        _, hist = ob_.mipnerf360_forward(bsd, bb, 1.0, True, 0.1, 1e6, transitions_times=[0.4], jitters=jitters, render=False)
+        human = oh.human_forward(hsd, gb_ref, transitions_times=[0.4], t_rand=t_rand, stage=3)
+        rgb, fg, order, hw, _ = oh.stage3_composite(hist[-1]["tdist"], hist[-1]["rgb"], hist[-1]["density"], human, bb["rays_o"], bb["rays_d"],
+                                                    gb_ref["newsmpl_to_scale_world"])
+        return rgb, fg, hw, human
+
+    cfg = default_cfg(_basedir())
+    cfg.perturb = 1.0
+    hos = HOSNeRF(cfg)
+    hos.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+    hos.human.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+    hos = hos.to(dev)
+    with torch.no_grad():
+        rgb_o, fg_o, _, _ = oracle_render([j.view(B, 1) for j in jit])
+        out = hos.render(gb, randomized=True, is_train=True, jitters=[j.to(dev) for j in jit], t_rand=t_rand)
+    fg_h = out["idx_fg"].bool()
+    # a ray whose mask sum sits within fp32 noise of the 5e-3 threshold may flip sides; everything else must agree
+    flips = int((fg_h != fg_o).sum())
+    same = fg_h == fg_o
+    err = float((out["rgb"] - rgb_o)[same].abs().max())
+    _record("stage3_fullsize_parity", {"rays": B, "rgb_linf": err, "fg_rays": int(fg_o.sum()), "fg_flips": flips})
+    assert flips <= 2 and err < 1e-4, (flips, err)
+
+    params = list(bsd.values()) + list(hsd.values())
+    topt = torch.optim.Adam(params, lr=5e-4)
+
+    def torch_step():
+        topt.zero_grad()
+        rgb, fg, hw, human = oracle_render(None)
+        hw_full = torch.zeros(B, hw.shape[1], device=dev).masked_scatter(fg[:, None].expand(B, hw.shape[1]), hw)
+        o = dict(human, rgb=rgb, idx_fg=fg.to(torch.int32), human_weights_sorted=hw_full)
+        loss, _ = stage3_losses(o, gb_ref)
+        loss.backward()
+        topt.step()
+
+    t_torch = _time(torch_step, 1, 3)
+    del bsd, hsd, params, topt
+    torch.cuda.empty_cache()
+    ob1 = FusedAdam(hos.model, lr=5e-4)
+    oh1 = FusedAdam(hos.human, lr=5e-4, lr_ranges=human_lr_ranges(hos.human))
+
+    def hip_step():
+        ob1.zero_grad(); oh1.zero_grad()
+        o = hos.render(gb, randomized=True, is_train=True)
+        loss, _ = stage3_losses(o, gb)
+        loss.backward()
+        ob1.step(5e-4); oh1.step(5e-4)
+
+    t_hip = _time(hip_step, 3, 10)
+    _record("stage3", {"rays": B, "torch_rocm_rays_per_s": B / t_torch, "hip_eager_rays_per_s": B / t_hip, "speedup": t_torch / t_hip})
+    assert t_torch / t_hip > 2.0, (t_torch, t_hip)
