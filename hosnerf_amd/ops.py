@@ -98,7 +98,7 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
     M = A0.shape[0] if M is None else M
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
-    if (THIN_GEMM and A1 is None and N <= 256 and 128 < K0 <= 256 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
+    if (THIN_GEMM and A1 is None and 128 < N <= 256 and K0 <= 256 and K0 % 4 == 0 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
             and ldc is None and out is not None and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
         # many rows through a thin layer: persistent kernel with the weight in registers (hos_thin.hip)
         _timed(f"thin_fwd[M={M},N={N},K={K0}]", 2.0 * M * N * K0, lambda: call(
@@ -117,7 +117,7 @@ def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torc
     """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src > 0)."""
     M = dY.shape[0]
     wptr = ptr(W) + 4 * w_col0
-    if (THIN_GEMM and not accumulate and 128 < Npad <= 256 and 128 < K <= 256 and M >= 16384
+    if (THIN_GEMM and not accumulate and Npad <= 256 and Npad % 4 == 0 and 128 < K <= 256 and M >= 16384
             and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
         _timed(f"thin_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
             "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
