@@ -283,6 +283,7 @@ def test_linear_bwd_fused(dev, M, N, K, relu, wcol0, ldw):
 def test_linear_wgrad_tr(dev, M, N, K, wcol0, ldw):
     """hos_linear_wgrad_tr (the route ops.linear_wgrad takes for 128 < N <= 256 and many rows) against fp64."""
     from hosnerf_amd import ops
+    ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
     assert ops.WGRAD_TR
     g = torch.Generator().manual_seed(M + K)
     Np = (N + 31) // 32 * 32
@@ -314,6 +315,7 @@ def test_thin_linear_fwd(dev, M, N, K, relu, col0):
     """hos_thin_linear_fwd (the route ops.linear_fwd takes for 128 < K <= 256, N <= 256 and many rows) against fp64;
     col0 = 127 is the canonical MLP's skip layer writing into the concat buffer at an unaligned column."""
     from hosnerf_amd import ops
+    ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
     g = torch.Generator().manual_seed(M + N)
     X = torch.relu(torch.randn(M, 256, generator=g))
     W = torch.randn(256, 256, generator=g) / 16
@@ -337,6 +339,7 @@ def test_thin_linear_fwd(dev, M, N, K, relu, col0):
 @pytest.mark.parametrize("M,Npad,K,masked", [(20000, 256, 256, True), (16400, 256, 256, False), (33001, 160, 200, True)])
 def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     from hosnerf_amd import ops
+    ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
     g = torch.Generator().manual_seed(M + K)
     dY = torch.randn(M, 256, generator=g) * 1e-3
     dY[:, Npad:] = 0.0
