@@ -117,11 +117,15 @@ def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torc
     """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src > 0)."""
     M = dY.shape[0]
     wptr = ptr(W) + 4 * w_col0
-    if (THIN_GEMM and not accumulate and Npad <= 256 and Npad % 4 == 0 and 128 < K <= 256 and M >= 16384
+    if (THIN_GEMM and not accumulate and Npad <= 256 and Npad % 4 == 0 and K > 128 and M >= 16384
             and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
-        _timed(f"thin_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
-            "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
-            0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K))
+        # output columns in chunks of <= 256 (the skip layer's [P,384] input gradient is two launches)
+        for k0 in range(0, K, 256):
+            kc = min(256, K - k0)
+            _timed(f"thin_dgrad[M={M},N={kc},K={Npad}]", 2.0 * M * kc * Npad, lambda: call(
+                "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr + 4 * k0, W.stride(0), Npad,
+                None if mask_src is None else ptr(mask_src) + 4 * k0, 0 if mask_src is None else mask_src.stride(0),
+                ptr(out) + 4 * k0, out.stride(0), M, kc))
         return out
     _timed(f"gemm_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
         "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),

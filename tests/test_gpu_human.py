@@ -336,18 +336,20 @@ def test_thin_linear_fwd(dev, M, N, K, relu, col0):
     assert bool(torch.isnan(out[:, :col0]).all()) and bool(torch.isnan(out[:, col0 + N:]).all())
 
 
-@pytest.mark.parametrize("M,Npad,K,masked", [(20000, 256, 256, True), (16400, 256, 256, False), (33001, 160, 200, True)])
+@pytest.mark.parametrize("M,Npad,K,masked", [(20000, 256, 256, True), (16400, 256, 256, False), (33001, 160, 200, True),
+                                               (16500, 256, 384, False), (16500, 256, 380, True)])
 def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     from hosnerf_amd import ops
     ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
     g = torch.Generator().manual_seed(M + K)
     dY = torch.randn(M, 256, generator=g) * 1e-3
     dY[:, Npad:] = 0.0
-    W = torch.zeros(256, 256)
-    W[:Npad] = torch.randn(Npad, 256, generator=g) / 16
-    Xact = torch.randn(M, 256, generator=g)
-    Xact = torch.where(torch.rand(M, 256, generator=g) < 0.4, torch.zeros_like(Xact), Xact.abs())
-    out = torch.full((M, 256), float("nan"), device=dev)
+    KW = max(256, (K + 3) // 4 * 4)
+    W = torch.zeros(256, KW)
+    W[:Npad] = torch.randn(Npad, KW, generator=g) / 16
+    Xact = torch.randn(M, KW, generator=g)
+    Xact = torch.where(torch.rand(M, KW, generator=g) < 0.4, torch.zeros_like(Xact), Xact.abs())
+    out = torch.full((M, KW), float("nan"), device=dev)
     ev = ops.KernelEvents()
     ops.set_kernel_events(ev)
     try:
