@@ -40,6 +40,7 @@ PROTOTYPES = {
     "hos_rays_aabb": [_P, _P, _L, _P, _P, _P, _P, _P],
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],
     "hos_deconv3d_im2col": [_P, _I, _I, _P, _P],
+    "hos_outer_accum": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_split_planes": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_linearp_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _I, _F, _P],
     "hos_split_planes2": [_P, _I, _I, _I, _P, _I, _P, _I, _P],

@@ -240,7 +240,10 @@ class _Deconv3d(torch.autograd.Function):
         with gemm_mode(GEMM_FP32):
             in_place = weight.grad is not None and weight.grad.is_contiguous()
             gW = weight.grad.view(Cin, Cout * 64) if in_place else torch.zeros(Cin, Cout * 64, device=g.device)
-            linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)
+            if M <= 64:      # a few voxels against 33-134 MB of weights: outer-product stream, not a tiled GEMM
+                call("hos_outer_accum", ptr(x), x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW), gW.stride(0), M, Cin, Cout * 64)
+            else:
+                linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)
         db = dpre.sum(0)
         if in_place and bias.grad is not None:
             bias.grad += db

@@ -180,6 +180,10 @@ int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, int Cout, f
 /* dycol[D^3][Cout*64] = gather of dpre[(2D)^3][Cout] (gradient w.r.t. the pre-activation output); zeros where a tap
  * leaves the output volume. */
 int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream);
+/* Weight gradient of the decoder's first layers (1, 8, 64 input voxels): gW [K, ldw] += x[M, :K]^T . dy[M, :N], M <= 64,
+ * exact fp32, one read-add-write pass over the weights.  Reference: deconv_vol_decoder.py:34-42 (ConvTranspose3d autograd). */
+int hos_outer_accum(const float* x, int ldx, const float* dy, int lddy, float* gW, int ldw, int M, int K, int N,
+                    hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).
