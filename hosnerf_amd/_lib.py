@@ -72,11 +72,20 @@ PROTOTYPES = {
     "hos_raw2outputs_bwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],
     "hos_merge_composite_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "hos_merge_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "hos_pose_refine_saved_floats": [],
+    "hos_pose_refine_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "hos_pose_refine_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "hos_motion_basis_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "hos_motion_basis_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "hos_train_losses_workspace_floats": [],
+    "hos_train_losses_fwd": [_P, _P, _L, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _F, _F, _F, _P, _P, _P],
+    "hos_train_losses_bwd": [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P, _I, _P, _P, _L, _P, _F, _F, _F, _P, _P, _P, _P, _P],
     "hos_sumsq": [_P, _L, _P, _P],
     "hos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _F, _P],
     "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
 }
-_RESTYPES = {"hos_error_string": c_char_p}
+_RESTYPES = {"hos_error_string": c_char_p, "hos_train_losses_workspace_floats": c_int64,
+             "hos_pose_refine_saved_floats": c_int64}
 
 _lib = None
 

@@ -82,7 +82,25 @@ class FlatStore:
         self.rebind()
 
     def zero_grad(self):
+        self.ensure_bound()
         self.grad.zero_()
+
+    def ensure_bound(self):
+        """Every parameter's `.grad` must alias the flat gradient buffer: the HIP weight-gradient kernels write into
+        `self.grad`, not through autograd.  `Optimizer.zero_grad()` / `nn.Module.zero_grad()` default to set_to_none=True
+        and would detach them (the stage would silently stop training) -- re-point any that were dropped or replaced."""
+        base, end = self.grad.data_ptr(), self.grad.data_ptr() + 4 * self.grad.numel()
+        strays, dirty = [], False
+        for p, _, _, _ in self._bindings:
+            g = p.grad
+            if g is None or not (base <= g.data_ptr() < end):
+                dirty = True
+                if g is not None and g.shape == p.shape:        # a gradient autograd accumulated outside the flat buffer: keep it
+                    strays.append((p, g))
+        if dirty:
+            self.rebind()
+            for p, g in strays:
+                p.grad.add_(g)
 
     def adopt(self, other: "FlatStore") -> int:
         """Append another store's regions to this one (before materialisation); returns the base offset."""

@@ -27,6 +27,12 @@ class HOSNeRF(nn.Module):
         self.model = MipNeRF360(cfg.basedir, opaque_background=True, render_levels=False)    # S3/configs/HOSNeRF/Backpack.gin
         self.human = Network(cfg, stage=3)
 
+    def zero_grad(self, set_to_none: bool = False):
+        """The gradients live in the two flat buffers (HIP weight-gradient kernels write there, not through autograd):
+        zero them and keep every `p.grad` aliased -- nn.Module's default (set_to_none=True) would detach them."""
+        self.model.store.zero_grad()
+        self.human.store.zero_grad()
+
     def render(self, batch: Dict[str, torch.Tensor], randomized: bool = True, is_train: bool = True,
                jitters=None, t_rand=None, prologue=None, with_cycle: bool = True) -> Dict[str, torch.Tensor]:
         """M:1507-1596 on one ray batch (keys of SURVEY Appendix B).  Returns the human dict + `rgb` [B,3],

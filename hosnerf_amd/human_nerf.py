@@ -1,7 +1,8 @@
 """State-conditional human-object renderer (HumanNeRF-style) on MI355X.
 
-Drop-in mirror of `core/nets/human_nerf/network.py::Network` of the reference (stage 3, N:27-698; the
-stage-2 variant composites inside, `stage=2`): same constructor (`Network(cfg)`), same
+Drop-in mirror of `core/nets/human_nerf/network.py::Network` of the reference (stage 3, N:27-698; `stage=2` selects
+the stage-2 file's variant, 2nd_State_Conditional_Human-Object/core/nets/human_nerf/network.py:273-299, 538-556, which
+composites its own samples with `_raw2outputs` + background colour and returns `rgb, alpha, depth, weights`): same constructor (`Network(cfg)`), same
 `forward(rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec, near, far, iter_val, **kwargs)`
 signature (swallows arbitrary extra kwargs), same output dict, same state_dict keys
 (`mweight_vol_decoder.*`, `non_rigid_mlp.*`, `non_rigid_forward_mlp.*`, `cnl_mlp.*`, `pose_decoder.*`,
@@ -549,8 +550,15 @@ class Network(FlatModule):
                 cnl, _ = self._nonrigid_fwd(self._nr, x_skel, cond, band_w, save=False)
                 raw, _ = self._canonical_fwd(cnl, state, save=False)
             b = z.shape[0]
-            ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
-                   "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
+            if self.stage == 2:
+                # N2:273-299, 538-556: the stage-2 network composites its own samples (last interval 1e10, masked alphas,
+                # background colour added) and returns the maps instead of the per-sample radiance
+                rgb_map, acc_map, weights, depth_map = ops.raw2outputs(raw.view(b, N, 4), z, rays_d[sl], mask.view(b, N),
+                                                                       kwargs["bgcolor"].to(dev))
+                ret = {"rgb": rgb_map, "alpha": acc_map, "depth": depth_map, "weights": weights}
+            else:
+                ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
+                       "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
 
             def fwd_branch(c_pts, Rf_, Tf_, cond_):
                 if grad:
@@ -570,13 +578,14 @@ class Network(FlatModule):
                 else:
                     ret["deform_pts_final"] = pts[0, 0][None]
                     ret["observe_pts"] = pts[0, 0][None]
-            if not flow:
+            if not flow and self.stage != 2:
                 ret["z_vals"] = z
                 ret["rays_d"] = rays_d[sl]
             for k, v in ret.items():
                 outs.setdefault(k, []).append(v)
         all_ret = {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in outs.items()}
-        all_ret["bgcolor"] = kwargs.get("bgcolor")
+        if self.stage != 2:
+            all_ret["bgcolor"] = kwargs.get("bgcolor")                               # N:696
         return all_ret
 
 
@@ -609,5 +618,5 @@ class _CanonicalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g_cnl = ctx.net._canonical_bwd(ctx.saved, ctx.cnl, ctx.raw, g.contiguous(), ctx.state)
-        ctx.saved = None
+        ctx.saved = ctx.raw = None                       # break the output -> grad_fn -> ctx -> output cycle right away
         return None, None, g_cnl, None

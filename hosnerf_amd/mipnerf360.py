@@ -510,7 +510,7 @@ class _MLPFn(torch.autograd.Function):
     def backward(ctx, g_density, g_rgb):
         mlp = ctx.mlp
         mlp._backward_impl(ctx.saved, ctx.density, ctx.rgb, g_density, None if ctx.rgb is None else g_rgb, ctx.state)
-        ctx.saved = None
+        ctx.saved = ctx.density = ctx.rgb = None        # break the output -> grad_fn -> ctx -> output cycle right away
         return None, None, None, None, None, None, None
 
 

@@ -577,6 +577,138 @@ def merge_composite(bkg_tdist, bkg_rgb, bkg_density, human_rgbsigma, newsmpl_pts
                                  rays_o_bkg.contiguous(), rd, newsmpl_to_scale_world.contiguous().float(), tiny, thre_fg)
 
 
+# ------------------------------------------------------------------------------------------ per-frame prologue (P2, P3)
+POSE_PARAM_ORDER = ("block_mlps.0", "block_mlps.2", "block_mlps.4", "block_mlps_dstR.0", "block_mlps_dstR.2", "block_mlps_dstT.0",
+                    "block_mlps_dstT.2")          # (weight, bias) pairs in this order = the 14 pointers of hos_pose_refine_*
+
+
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[ptr(t) for t in tensors])
+
+
+class _PoseRefine(torch.autograd.Function):
+    """(Rs', Ts') = refine(Rs, Ts, posevec) for F frames: BodyPoseRefiner + Rodrigues + N:589-605 in one launch; the
+    backward accumulates the pose decoder's parameter gradients straight into `grads` (views of the flat gradient buffer)."""
+
+    @staticmethod
+    def forward(ctx, token, Rs, Ts, posevec, weights, grads):
+        F_, K = Rs.shape[0], Rs.shape[1]
+        Rs, Ts, posevec = Rs.contiguous(), Ts.contiguous(), posevec.contiguous()
+        Ro, To = torch.empty_like(Rs), torch.empty_like(Ts)
+        saved = torch.empty(F_, int(_lib.load().hos_pose_refine_saved_floats()), device=Rs.device)
+        width = weights[0].shape[0]
+        call("hos_pose_refine_fwd", ptr(posevec), ptr(Rs), ptr(Ts), _ptr_array(weights), F_, K, width, ptr(Ro), ptr(To), ptr(saved))
+        ctx.save_for_backward(Rs, posevec, saved)
+        ctx.weights, ctx.grads, ctx.dims = weights, grads, (F_, K, width)
+        return Ro, To
+
+    @staticmethod
+    def backward(ctx, gR, gT):
+        Rs, posevec, saved = ctx.saved_tensors
+        F_, K, width = ctx.dims
+        gR = torch.zeros_like(Rs) if gR is None else gR.contiguous()
+        gT = torch.zeros(F_, K, 3, device=Rs.device) if gT is None else gT.contiguous()
+        call("hos_pose_refine_bwd", ptr(gR), ptr(gT), ptr(posevec), ptr(Rs), ptr(saved), _ptr_array(ctx.weights), _ptr_array(ctx.grads),
+             F_, K, width)
+        return None, None, None, None, None, None
+
+
+def pose_refine(token, Rs, Ts, posevec, weights, grads):
+    """weights / grads: the 14 pose-decoder tensors (POSE_PARAM_ORDER x (weight, bias)) and their gradient buffers."""
+    return _PoseRefine.apply(token, Rs, Ts, posevec, list(weights), list(grads))
+
+
+class _MotionBasis(torch.autograd.Function):
+    """U:134-174 for F frames in one launch: (R_bwd, T_bwd, R_fwd, T_fwd), each [F,K,...]; differentiable w.r.t. Rs, Ts."""
+
+    @staticmethod
+    def forward(ctx, Rs, Ts, cnl_gtfms):
+        F_, K = Rs.shape[0], Rs.shape[1]
+        Rs, Ts, cnl = Rs.contiguous(), Ts.contiguous(), cnl_gtfms.contiguous()
+        dev = Rs.device
+        Rb, Tb = torch.empty(F_, K, 3, 3, device=dev), torch.empty(F_, K, 3, device=dev)
+        Rf, Tf = torch.empty(F_, K, 3, 3, device=dev), torch.empty(F_, K, 3, device=dev)
+        call("hos_motion_basis_fwd", ptr(Rs), ptr(Ts), ptr(cnl), F_, K, ptr(Rb), ptr(Tb), ptr(Rf), ptr(Tf))
+        ctx.save_for_backward(Rs, Ts, cnl)
+        return Rb, Tb, Rf, Tf
+
+    @staticmethod
+    def backward(ctx, gRb, gTb, gRf, gTf):
+        Rs, Ts, cnl = ctx.saved_tensors
+        F_, K = Rs.shape[0], Rs.shape[1]
+        c = lambda g: None if g is None else g.contiguous()
+        gRs, gTs = torch.empty_like(Rs), torch.empty_like(Ts)
+        call("hos_motion_basis_bwd", ptr(c(gRb)), ptr(c(gTb)), ptr(c(gRf)), ptr(c(gTf)), ptr(Rs), ptr(Ts), ptr(cnl), F_, K, ptr(gRs), ptr(gTs))
+        return gRs, gTs, None
+
+
+def motion_basis(Rs, Ts, cnl_gtfms):
+    return _MotionBasis.apply(Rs, Ts, cnl_gtfms)
+
+
+# ------------------------------------------------------------------------------------------ training losses (C4)
+_LOSS_WS = {}
+
+
+def _loss_workspace(device) -> torch.Tensor:
+    """Block partials + completion ticket of hos_train_losses_fwd (zero-initialised once: the kernel re-arms the ticket)."""
+    key = str(device)
+    if key not in _LOSS_WS:
+        _LOSS_WS[key] = torch.zeros(int(_lib.load().hos_train_losses_workspace_floats()), device=device)
+    return _LOSS_WS[key]
+
+
+class _TrainLosses(torch.autograd.Function):
+    """total = w_mse*mse + w_flow*flow + w_cycle*cycle (M:1690-1716 / M2:918-944) in one launch, gradients in another.
+    Inputs that are None switch their term off.  Returns (total [], parts [8] = total, mse, flow, cycle, ...)."""
+
+    @staticmethod
+    def forward(ctx, rgb, target, mse_const, mse_count, pts_prev, weights, ray_grid, fg, cam, Kin, observe, deform, n_cyc_dev,
+                w_mse, w_flow, w_cycle):
+        B = rgb.shape[0]
+        S = 0 if pts_prev is None else pts_prev.shape[1]
+        n_cyc = 0 if observe is None else observe.shape[0]
+        out = torch.empty(8, device=rgb.device)
+        call("hos_train_losses_fwd", ptr(rgb), ptr(target), B, float(mse_const), float(mse_count), ptr(pts_prev), ptr(weights),
+             ptr(ray_grid), ptr(fg, torch.int32), ptr(cam), ptr(Kin), S, ptr(observe), ptr(deform), n_cyc, ptr(n_cyc_dev, torch.int32),
+             float(w_mse), float(w_flow), float(w_cycle), ptr(_loss_workspace(rgb.device)), ptr(out))
+        ctx.save_for_backward(rgb, target, pts_prev, weights, ray_grid, fg, cam, Kin, observe, deform, n_cyc_dev, out)
+        ctx.cfg = (float(mse_count), float(w_mse), float(w_flow), float(w_cycle))
+        parts = out.detach().clone()
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        rgb, target, pts_prev, weights, ray_grid, fg, cam, Kin, observe, deform, n_cyc_dev, out = ctx.saved_tensors
+        mse_count, w_mse, w_flow, w_cycle = ctx.cfg
+        B = rgb.shape[0]
+        S = 0 if pts_prev is None else pts_prev.shape[1]
+        n_cyc = 0 if observe is None else observe.shape[0]
+        need = ctx.needs_input_grad
+        g_rgb = torch.empty_like(rgb) if need[0] else None
+        g_pts = torch.empty_like(pts_prev) if (pts_prev is not None and need[4]) else None
+        g_w = torch.empty_like(weights) if (weights is not None and need[5]) else None
+        g_def = torch.empty_like(deform) if (deform is not None and need[11]) else None
+        call("hos_train_losses_bwd", ptr(g_total.contiguous()), ptr(out), ptr(rgb), ptr(target), B, mse_count, ptr(pts_prev), ptr(weights),
+             ptr(ray_grid), ptr(fg, torch.int32), ptr(cam), ptr(Kin), S, ptr(observe), ptr(deform), n_cyc, ptr(n_cyc_dev, torch.int32),
+             w_mse, w_flow, w_cycle, ptr(g_rgb), ptr(g_pts), ptr(g_w), ptr(g_def))
+        return (g_rgb, None, None, None, g_pts, g_w, None, None, None, None, None, g_def, None, None, None, None)
+
+
+def train_losses(rgb, target, mse_const=0.0, mse_count=None, pts_prev=None, weights=None, ray_grid=None, fg=None, cam_prev=None,
+                 intrinsics_prev=None, observe=None, deform=None, n_cyc_dev=None, w_mse=0.2, w_flow=0.01, w_cycle=0.01):
+    """Returns (total, parts[8]) with parts = [total, mse, flow, cycle (unweighted), 1/flow-denominator, 1/n_cyc, sum M, n_cyc]."""
+    c = lambda t: None if t is None else t.contiguous()
+    mse_count = float(rgb.numel()) if mse_count is None else mse_count
+    if pts_prev is None:
+        weights = ray_grid = fg = cam_prev = intrinsics_prev = None
+    return _TrainLosses.apply(c(rgb), c(target).to(rgb.dtype), mse_const, mse_count, c(pts_prev), c(weights), c(ray_grid),
+                              None if fg is None else fg.to(torch.int32).contiguous(), c(cam_prev), c(intrinsics_prev),
+                              c(observe), c(deform), n_cyc_dev, w_mse, w_flow, w_cycle)
+
+
 # ------------------------------------------------------------------------------------------ human branch, backward
 class _SampleWarp(torch.autograd.Function):
     """(z, pts, x_skel, mask) with gradients to the motion-weight volume and the backward motion basis."""

@@ -22,13 +22,44 @@ except Exception:
 from .hosnerf import HOSNeRF
 from .human_nerf import Network, default_cfg
 from .mipnerf360 import MipNeRF360
-from .train import FusedAdam, human_lr_ranges, stage1_loss, stage1_lr, stage3_losses
+from .train import (FusedAdam, FusedAdamOptimizer, human_lr_decay, human_lr_ranges, stage1_loss, stage1_lr, stage2_losses,
+                    stage3_losses)
 
 
-class LitMipNeRF360(_Base):
+class _LitFlat(_Base):
+    """Shared plumbing of the three stage modules: the flat stores behind `self._flat_modules()` own the gradients, so
+    `zero_grad` / `optimizer_zero_grad` (whatever `set_to_none` says) zero the flat buffers and keep every `p.grad` aliased
+    to them -- nn.Module / Lightning defaults would drop the aliases and the HIP weight gradients would never reach Adam."""
+
+    def _flat_modules(self):
+        raise NotImplementedError
+
+    def zero_grad(self, set_to_none: bool = False):
+        for m in self._flat_modules():
+            m.store.zero_grad()
+
+    def optimizer_zero_grad(self, *args, **kwargs):                 # Lightning hook (epoch, batch_idx, optimizer[, idx])
+        self.zero_grad()
+
+    def _global_step(self) -> int:
+        tr = getattr(self, "trainer", None) if _Base is not nn.Module else None
+        return int(getattr(tr, "global_step", self._step))
+
+    def optimizer_step(self, epoch=None, batch_idx=None, optimizer=None, *args, optimizer_closure=None, **kwargs):
+        """Lightning hook: run the step, then write the schedule's next learning rates into the param groups -- the
+        reference does both in this hook (M1:541-569, M2:606-634, M:1631-1658)."""
+        closure = optimizer_closure if optimizer_closure is not None else (args[1] if len(args) > 1 and callable(args[1]) else None)
+        optimizer.step(closure=closure)
+        self.apply_lr(optimizer, self._global_step())
+
+    def apply_lr(self, optimizer, step: int):
+        raise NotImplementedError
+
+
+class LitMipNeRF360(_LitFlat):
     """Stage 1 (S1/src/model/mipnerf360/model.py:464-563): `self.model = MipNeRF360(basedir)`; one step =
-    forward + Charbonnier/interlevel/distortion losses.  `configure_optimizers` returns a torch Adam over the
-    parameters (their `.grad`s are views of the flat gradient buffer); `fused_optimizer()` the one-launch variant."""
+    forward + Charbonnier/interlevel/distortion losses.  `configure_optimizers` returns the flat fused Adam behind a
+    `torch.optim.Optimizer` face (zero_grad-safe, see train.FusedAdamOptimizer); `fused_optimizer()` the bare object."""
 
     def __init__(self, basedir, lr_init: float = 2.0e-3, lr_final: float = 2.0e-5, lr_delay_steps: int = 512,
                  lr_delay_mult: float = 0.01, max_steps: int = 500000, grad_max_norm: float = 0.001,
@@ -39,8 +70,11 @@ class LitMipNeRF360(_Base):
         self.model = MipNeRF360(basedir, opaque_background=True)
         self._step = 0
 
+    def _flat_modules(self):
+        return [self.model]
+
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
-        step = getattr(getattr(self, "trainer", None), "global_step", self._step) if _Base is not nn.Module else self._step
+        step = self._global_step()
         rend, hist = self.model(batch, step / self.max_steps, True, True, self.near, self.far)
         loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
         self._step += 1
@@ -49,33 +83,70 @@ class LitMipNeRF360(_Base):
     def learning_rate(self, step: int) -> float:
         return stage1_lr(step, self.max_steps, self.lr_init, self.lr_final, self.lr_delay_steps, self.lr_delay_mult)
 
+    def apply_lr(self, optimizer, step: int):
+        for g in optimizer.param_groups:
+            g["lr"] = self.learning_rate(step)
+
     def configure_optimizers(self):
-        return torch.optim.Adam(self.parameters(), lr=self.lr_init, betas=(0.9, 0.999), eps=1e-8)
+        # norm clipping (`gradient_clip_val=grad_max_norm`, S1/run.py:155) is applied by the trainer in the reference;
+        # here it is part of the fused step
+        return FusedAdamOptimizer(self.model, lr=self.lr_init, max_grad_norm=self.grad_max_norm)
 
     def fused_optimizer(self) -> FusedAdam:
         return FusedAdam(self.model, lr=self.lr_init, max_grad_norm=self.grad_max_norm)
 
 
-class LitHumanObject(_Base):
-    """Stage 2: `self.human = Network(cfg)` (core/nets/human_nerf/network.py); the photometric / LPIPS losses of the
-    reference's stage-2 trainer stay outside (they need its patch sampler); this wrapper owns renderer + optimiser."""
+class LitHumanObject(_LitFlat):
+    """Stage 2 (2nd_State_Conditional_Human-Object/src/model/mipnerf360/model.py:447-634): `self.human = Network(cfg)` with
+    the in-network composite; `training_step` = network forward + `get_loss` (0.2 MSE on the unpacked patches + 0.01 flow +
+    0.01 cycle; the LPIPS term needs the VGG weights and stays with the reference), `optimizer_step` = Adam + the
+    0.1 ** (step / 500k) decay of every group's base learning rate."""
+
+    LR = 6.667e-4           # configs/default.yaml train.lr (cnl_mlp, human_stateembeds); the other modules train at LR / 10
 
     def __init__(self, basedir, cfg=None):
         super().__init__()
         self.cfg = default_cfg(basedir) if cfg is None else cfg
         self.human = Network(self.cfg, stage=2)
+        self._step = 0
+
+    def _flat_modules(self):
+        return [self.human]
 
     def forward(self, **batch):
         return self.human(**batch)
 
+    def _base_lr(self) -> float:
+        tr = getattr(self.cfg, "train", None)
+        return float(getattr(tr, "lr", self.LR)) if tr is not None else self.LR
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
+        """M2:571-605.  `batch` is the dataset item (leading DataLoader dimension already stripped) after
+        `train.prepare_patch_targets` + `train.batch_to_device`."""
+        batch = dict(batch)
+        batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M2:576
+        out = self.human(**batch)
+        loss, _ = stage2_losses(out, batch)
+        self._step += 1
+        return loss
+
+    def apply_lr(self, optimizer, step: int):
+        for g in optimizer.param_groups:
+            g["lr"] = self._base_lr() * human_lr_decay(step, int(getattr(getattr(self.cfg, "train", None), "lrate_decay", 500)))
+
+    def configure_optimizers(self):
+        return FusedAdamOptimizer(self.fused_optimizer())
+
     def fused_optimizer(self) -> FusedAdam:
-        return FusedAdam(self.human, lr=self.cfg.train.lr_cnl_mlp if hasattr(self.cfg, "train") else 6.667e-5,
-                         lr_ranges=human_lr_ranges(self.human))
+        lr = self._base_lr()
+        return FusedAdam(self.human, lr=lr, lr_ranges=human_lr_ranges(self.human, lr_cnl=lr, lr_other=lr / 10.0))
 
 
-class LitHOSNeRF(_Base):
+class LitHOSNeRF(_LitFlat):
     """Stage 3 (S3/src/model/mipnerf360/model.py:1501-1656): both renderers + the merged composite; one step =
     render + 0.2 MSE + 0.01 flow + 0.01 cycle (the LPIPS term needs the VGG weights and stays with the reference)."""
+
+    LR = 6.667e-5           # configs/default.yaml train.lr_bkgd / lr_cnl_mlp; the other human modules train at LR / 10
 
     def __init__(self, basedir, cfg=None):
         super().__init__()
@@ -86,13 +157,27 @@ class LitHOSNeRF(_Base):
         self.model = net.model
         self.human = net.human
         object.__setattr__(self, "net", net)
+        self._step = 0
+
+    def _flat_modules(self):
+        return [self.model, self.human]
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
+        batch = dict(batch)
+        batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M:1506
         out = self.net.render(batch, randomized=True, is_train=True)
         loss, _ = stage3_losses(out, batch)
+        self._step += 1
         return loss
 
-    def fused_optimizers(self, lr: float = 6.667e-5):
+    def apply_lr(self, optimizer, step: int):
+        for g in optimizer.param_groups:
+            g["lr"] = self.LR * human_lr_decay(step, int(getattr(getattr(self.cfg, "train", None), "lrate_decay", 500)))
+
+    def configure_optimizers(self):
+        return FusedAdamOptimizer(list(self.fused_optimizers()))
+
+    def fused_optimizers(self, lr: float = LR):
         return (FusedAdam(self.net.model, lr=lr), FusedAdam(self.net.human, lr=lr, lr_ranges=human_lr_ranges(self.net.human)))
 
 
@@ -108,15 +193,30 @@ def select_model(model_name: str, basedir, **kwargs):
 
 
 # ------------------------------------------------------------------------------------------ checkpoints
-def lightning_checkpoint(lit: nn.Module, global_step: int = 0, epoch: int = 0) -> Dict:
+def lightning_checkpoint(lit: nn.Module, global_step: int = 0, epoch: int = 0, optimizer=None) -> Dict:
     """The part of a Lightning `.ckpt` the reference reads back (`pl_load(path)['state_dict']`, S3/run.py:206-212, and
-    `trainer.fit(ckpt_path=...)`): the module's `state_dict` under the reference's key names, on the host."""
-    return {"state_dict": {k: v.detach().cpu().clone() for k, v in lit.state_dict().items()},
-            "global_step": int(global_step), "epoch": int(epoch), "pytorch-lightning_version": "hosnerf_amd"}
+    `trainer.fit(ckpt_path=...)`): the module's `state_dict` under the reference's key names, on the host, plus --
+    like Lightning's `optimizer_states` -- the optimiser's moments and step count (flat layout, `FusedAdam.state_dict`)
+    so that a resumed run continues with the same Adam state instead of restarting the bias correction at t = 1."""
+    ck = {"state_dict": {k: v.detach().cpu().clone() for k, v in lit.state_dict().items()},
+          "global_step": int(global_step), "epoch": int(epoch), "pytorch-lightning_version": "hosnerf_amd"}
+    if optimizer is not None:
+        opts = optimizer if isinstance(optimizer, (list, tuple)) else [optimizer]
+        ck["optimizer_states"] = [o.state_dict() for o in opts]
+    return ck
 
 
-def save_checkpoint(lit: nn.Module, path: str, global_step: int = 0, epoch: int = 0) -> None:
-    torch.save(lightning_checkpoint(lit, global_step, epoch), path)
+def save_checkpoint(lit: nn.Module, path: str, global_step: int = 0, epoch: int = 0, optimizer=None) -> None:
+    torch.save(lightning_checkpoint(lit, global_step, epoch, optimizer), path)
+
+
+def load_optimizer_states(path: str, optimizer) -> int:
+    """Restore the optimiser state(s) saved by `save_checkpoint(..., optimizer=...)`; returns the checkpoint's global step."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    opts = optimizer if isinstance(optimizer, (list, tuple)) else [optimizer]
+    for o, sd in zip(opts, ckpt.get("optimizer_states", [])):
+        o.load_state_dict(sd)
+    return int(ckpt.get("global_step", 0))
 
 
 def load_checkpoint(lit: nn.Module, path: str, strict: bool = False):

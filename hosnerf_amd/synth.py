@@ -307,3 +307,31 @@ def human_state_dict(seed: int = 777, n_states: int = 2, small_decoder_scale: fl
         lin(f"pose_decoder.block_mlps_{head}.0", 256, 256)
         lin(f"pose_decoder.block_mlps_{head}.2", 75, 256, bound=1e-3)
     return sd
+
+
+def add_patch_supervision(b: Dict[str, torch.Tensor], n_patches: int = 2, size: int = 32, seed: int = 777) -> Dict[str, torch.Tensor]:
+    """The supervision part of a stage-2 / stage-3 training item (S2/core/data/human_nerf/train.py:
+    405-455, 523-586) for the rays of `human_batch`: `patch_masks` [Np,size,size] bool with exactly as many set pixels as
+    there are rays (full patches when B = Np*size*size, otherwise a random subset per patch -- the reference's patches
+    keep only the pixels whose rays hit the subject's box), `target_patches`, `patch_div_indices`, and the flow inputs
+    `ray_grid` [B,5] = (x, y, flow_x, flow_y, valid), `newsmpl_to_camera_prev`, `intrinsics_prev`."""
+    rs = np.random.RandomState(seed + 1000)
+    B = b["near"].shape[0]
+    per = [B // n_patches + (1 if i < B % n_patches else 0) for i in range(n_patches)]
+    assert max(per) <= size * size, "more rays than patch pixels"
+    masks = np.zeros((n_patches, size * size), bool)
+    for i, n in enumerate(per):
+        masks[i, np.sort(rs.permutation(size * size)[:n])] = True
+    out = dict(b)
+    out["patch_masks"] = torch.from_numpy(masks.reshape(n_patches, size, size))
+    out["target_patches"] = torch.from_numpy(rs.uniform(0, 1, size=(n_patches, size, size, 3)).astype(np.float32))
+    out["patch_div_indices"] = torch.from_numpy(np.concatenate([[0], np.cumsum(per)]).astype(np.int64))
+    out.pop("target_rgbs", None)
+    grid = np.concatenate([rs.uniform(0, 100, size=(B, 2)), rs.standard_normal((B, 2)), (rs.uniform(size=(B, 1)) > 0.2).astype(np.float64)], -1)
+    out["ray_grid"] = torch.from_numpy(grid.astype(np.float32))
+    cam = np.eye(4, dtype=np.float32)
+    cam[:3, :3] = np.diag([1.0, -1.0, -1.0])                # x right, y down, z forward, at the camera `human_batch` aims from
+    cam[:3, 3] = -cam[:3, :3] @ np.array([0.3, 0.2, 3.0], np.float32)
+    out["newsmpl_to_camera_prev"] = torch.from_numpy(cam)
+    out["intrinsics_prev"] = torch.tensor([[500.0, 0.0, 50.0], [0.0, 500.0, 50.0], [0.0, 0.0, 1.0]])
+    return out

@@ -96,6 +96,7 @@ class FusedAdam:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def step(self, lr: Optional[float] = None, dynamic: bool = False):
+        self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
         g = self.module.flat_grad
         world = allreduce_flat_grad(self.module, self.group)
         if dynamic:
@@ -123,12 +124,54 @@ class FusedAdam:
                           self.betas[0], self.betas[1], self.eps, self.step_count, 1.0 / world, sumsq, self.max_grad_norm)
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        """Flat layout (version 1): the two moment buffers in the order of the module's flat parameter buffer."""
+        return {"layout": "hosnerf_amd.flat.v1", "numel": int(self.exp_avg.numel()), "exp_avg": self.exp_avg.detach().cpu().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "step": self.step_count, "lr": self.lr}
 
     def load_state_dict(self, sd):
+        if sd.get("layout", "hosnerf_amd.flat.v1") != "hosnerf_amd.flat.v1" or int(sd.get("numel", self.exp_avg.numel())) != self.exp_avg.numel():
+            raise ValueError("optimizer state was saved for a different flat parameter layout")
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+
+
+class FusedAdamOptimizer(torch.optim.Optimizer):
+    """`torch.optim.Optimizer` face of one or more FusedAdams -- what `configure_optimizers` hands to a Lightning-style loop
+    (the reference builds ONE torch Adam over both stage-3 modules with name-keyed learning rates, optimizer.py:19-60).
+    One param group per flat module; `zero_grad()` (whatever `set_to_none` says) zeroes the flat gradient buffers and keeps
+    every `p.grad` aliased to them, `step()` runs the one-launch Adam of each module with its group's current `lr`
+    (schedulers / `optimizer_step` hooks write `param_groups[i]['lr']` like they do for torch's Adam), `state_dict()`
+    carries the moments in the flat layout."""
+
+    def __init__(self, modules, **kw):
+        mods = list(modules) if isinstance(modules, (list, tuple)) else [modules]
+        self.fused = [m if isinstance(m, FusedAdam) else FusedAdam(m, **kw) for m in mods]
+        groups = [{"params": list(f.module.parameters()), "lr": f.lr, "name": type(f.module).__name__} for f in self.fused]
+        super().__init__(groups, dict(lr=self.fused[0].lr, betas=self.fused[0].betas, eps=self.fused[0].eps))
+
+    def zero_grad(self, set_to_none: bool = False):
+        for f in self.fused:
+            f.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for f, g in zip(self.fused, self.param_groups):
+            f.step(float(g["lr"]))
+        return loss
+
+    def state_dict(self):
+        return {"fused": [f.state_dict() for f in self.fused], "lr": [float(g["lr"]) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        for f, fsd in zip(self.fused, sd["fused"]):
+            f.load_state_dict(fsd)
+        for g, lr in zip(self.param_groups, sd.get("lr", [])):
+            g["lr"] = float(lr)
 
 
 def shard_rays(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[str, torch.Tensor]:
@@ -141,7 +184,7 @@ def shard_rays(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[st
     return out
 
 
-HOST_KEYS = ("time", "times", "iter_val", "is_train", "img_width", "img_height", "frame_name")
+HOST_KEYS = ("time", "times", "iter_val", "is_train", "img_width", "img_height", "frame_name", "mse_const", "mse_count")
 
 
 def batch_to_device(batch: Dict, device) -> Dict:
@@ -193,38 +236,82 @@ def human_lr_ranges(net, lr_cnl: float = 6.667e-5, lr_other: float = 6.667e-6):
     return [(0, start, lr_other / lr_cnl), (start, net.flat_param.numel() - start, 1.0)]
 
 
+def prepare_patch_targets(batch: Dict) -> Dict:
+    """Host-side data preparation (what the dataset knows when it builds the item, S2/core/data/human_nerf/train.py:585-586):
+    `target_rgbs` [N_rays,3] = the target colours of the sampled rays, and the two constants of the patch MSE --
+    `_unpack_imgs` (M2:41-50) fills the patch pixels outside the ray mask with the background colour, so they contribute
+    `mse_const` = sum |bgcolor/255 - target|^2 over those pixels to the numerator and every patch pixel to `mse_count`.
+    Runs on CPU tensors before `batch_to_device`, so the step itself needs no boolean indexing (no host round trip)."""
+    if "patch_masks" not in batch:
+        return batch
+    pm = batch["patch_masks"].bool()
+    tp = batch["target_patches"]
+    out = dict(batch)
+    if "target_rgbs" not in out:
+        out["target_rgbs"] = tp[pm]
+    bg = (batch["bgcolor"].to(tp.dtype) / 255.0).expand(tp.shape)
+    out["mse_const"] = float(((bg - tp) ** 2)[~pm].sum())
+    out["mse_count"] = float(tp.numel())
+    return out
+
+
+def _loss_parts(parts: torch.Tensor) -> Dict[str, torch.Tensor]:
+    return {"mse": parts[1], "flow": parts[2], "cycle": parts[3]}
+
+
 def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
                   w_flow: float = 0.01, w_cycle: float = 0.01):
     """M:1690-1716 `get_loss` without the LPIPS term (third-party VGG, out of scope): 0.2*MSE + 0.01*flow + 0.01*cycle
-    (configs/default.yaml lossweights).  Returns (total, {name: unweighted term}).
+    (configs/default.yaml lossweights) -- one HIP launch (hos_train_losses_fwd), gradients in another.
+    Returns (total, {name: unweighted term}).
 
     The reference selects the foreground rows first (`ray_grid[idx_fg]`, `human_weights_onlyfg`, M:1704) -- a boolean
-    index, i.e. a device->host round trip per step, next to its four `.item()` reads (M:1617-1622).  Here the flow term
-    (M:1680-1688 + img2mae M:61-71) runs over ALL rays with the foreground flag folded into the flow mask: rows of
-    background rays have zero composite weight in `human_weights_sorted`, so the numerator is unchanged, and the
-    denominator sum(M) over the selected [B_fg, S, 1] block is S * sum_fg(M_ray).  No synchronisation, fixed shapes."""
+    index, i.e. a device->host round trip per step, next to its four `.item()` reads (M:1617-1622).  The kernel runs over
+    ALL rays with the foreground flag folded into the flow mask: rows of background rays have zero composite weight in
+    `human_weights_sorted`, so the numerator is unchanged, and the denominator sum(M) over the selected [B_fg, S, 1] block
+    is S * sum_fg(M_ray).  No synchronisation, fixed shapes; the cycle set's row count may live on the device."""
     rgb = out["rgb"]
     target = batch["target_rgbs"] if "target_rgbs" in batch else batch["target_patches"].reshape(-1, 3)
-    losses = {"mse": torch.mean((rgb - target) ** 2)}                             # _unpack_imgs is a reshape (M:41-50)
-    flow = rgb.new_zeros(())
-    if "deform_pts_prev_final" in out and "ray_grid" in batch:                  # time > 0.005 and training
-        pts = out["deform_pts_prev_final"]                                       # [B,S,3]
-        S = pts.shape[1]
-        A = batch["newsmpl_to_camera_prev"]
-        grid = batch["ray_grid"][:, None, :]                                     # [B,1,5]: x, y, flow_x, flow_y, valid
-        M = grid[..., 4:5] * out["idx_fg"].to(rgb.dtype)[:, None, None]          # [B,1,1]
-        on = M > 0
-        cam = pts @ A[:3, :3].T + A[:3, 3]
-        uvw = cam @ batch["intrinsics_prev"].T
-        depth = torch.where(on, uvw[..., 2:3], torch.ones_like(uvw[..., 2:3]))   # rows that do not count stay finite
-        uv = uvw[..., :2] / depth
-        err = torch.abs(uv - grid[..., :2] - grid[..., 2:4]) * out["human_weights_sorted"][..., None]
-        flow = torch.sum(torch.where(on, err, torch.zeros_like(err))) / (S * torch.sum(M) + 1e-8) / 2
-    losses["flow"] = flow
-    dis = out["observe_pts"] - out["deform_pts_final"]
-    losses["cycle"] = torch.mean(torch.sum(dis**2, 1) / 2.0)
-    total = w_mse * losses["mse"] + w_flow * losses["flow"] + w_cycle * losses["cycle"]
-    return total, {k: v.detach() for k, v in losses.items()}
+    flow = "deform_pts_prev_final" in out and "ray_grid" in batch                 # time > 0.005 and training
+    total, parts = ops.train_losses(
+        rgb, target, batch.get("mse_const", 0.0), batch.get("mse_count"),
+        pts_prev=out["deform_pts_prev_final"] if flow else None, weights=out["human_weights_sorted"] if flow else None,
+        ray_grid=batch.get("ray_grid"), fg=out["idx_fg"], cam_prev=batch.get("newsmpl_to_camera_prev"),
+        intrinsics_prev=batch.get("intrinsics_prev"), observe=out["observe_pts"], deform=out["deform_pts_final"],
+        n_cyc_dev=out.get("cycle_count"), w_mse=w_mse, w_flow=w_flow, w_cycle=w_cycle)
+    return total, _loss_parts(parts)
+
+
+def stage2_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
+                  w_flow: float = 0.01, w_cycle: float = 0.01):
+    """2nd_State_Conditional_Human-Object/src/model/mipnerf360/model.py:918-944 `get_loss` without the LPIPS term:
+    0.2 * MSE on the unpacked patches + 0.01 * flow (weighted by the network's own composite `weights`, all rays)
+    + 0.01 * cycle.  `batch` carries `target_rgbs` / `mse_const` / `mse_count` from `prepare_patch_targets`."""
+    flow = "deform_pts_prev_final" in out and "ray_grid" in batch
+    total, parts = ops.train_losses(
+        out["rgb"], batch["target_rgbs"], batch.get("mse_const", 0.0), batch.get("mse_count"),
+        pts_prev=out["deform_pts_prev_final"] if flow else None, weights=out["weights"] if flow else None,
+        ray_grid=batch.get("ray_grid"), fg=None, cam_prev=batch.get("newsmpl_to_camera_prev"),
+        intrinsics_prev=batch.get("intrinsics_prev"), observe=out["observe_pts"], deform=out["deform_pts_final"],
+        n_cyc_dev=out.get("cycle_count"), w_mse=w_mse, w_flow=w_flow, w_cycle=w_cycle)
+    return total, _loss_parts(parts)
+
+
+def human_lr_decay(step: int, lrate_decay: int = 500) -> float:
+    """`optimizer_step` of the human stages (M2:606-634, M:1631-1656): every group's lr = base * 0.1 ** (step / (lrate_decay * 1000))."""
+    return 0.1 ** (step / (lrate_decay * 1000.0))
+
+
+def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, t_rand=None):
+    """One stage-2 optimisation step (M2:571-605 training_step + :606-634 optimizer_step): the human-object network with its
+    in-network composite, 0.2 MSE on the unpacked patches + 0.01 flow + 0.01 cycle, backward, flat Adam with the
+    per-module learning rates.  `batch` comes from `prepare_patch_targets` + `batch_to_device`."""
+    opt.zero_grad()
+    out = net(t_rand=t_rand, **batch)
+    loss, parts = stage2_losses(out, batch)
+    loss.backward()
+    opt.step(lr)
+    return loss.detach(), parts
 
 
 def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):

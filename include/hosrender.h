@@ -356,6 +356,68 @@ int hos_merge_composite_bwd(const float* g_rgb, const float* g_human_weights_sor
                             hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-frame prologue of the human-object branch, F frames per launch (the current
+ * frame and, for the flow set, the previous one).  One workgroup per frame: latency-bound bookkeeping
+ * on 26 joints that the reference spreads over ~120 torch launches per step.
+ * ------------------------------------------------------------------------------------------ */
+/* BodyPoseRefiner (pose_decoders/mlp_delta_body_pose.py:14-73; trunk 75->256->256->256, heads 256->256->75,
+ * ReLU) + RodriguesModule (U:66-92, theta = sqrt(1e-5 + |r|^2)) + N:589-605: Rs_out[0] = Rs[0],
+ * Rs_out[i] = Rs[i] dR[i-1], Ts_out[i] = Ts[i] + dT[i-1].
+ * posevec [F,75], Rs [F,K,3,3], Ts [F,K,3]; K = 26, width = 256.
+ * weights14 / grads14: HOST arrays of 14 device pointers in the order (weight, bias) of
+ *   block_mlps.0, block_mlps.2, block_mlps.4, block_mlps_dstR.0, block_mlps_dstR.2, block_mlps_dstT.0,
+ *   block_mlps_dstT.2  (weights row-major [out,in], contiguous).
+ * saved: [F, hos_pose_refine_saved_floats()] activations kept for the backward pass.
+ * The backward ACCUMULATES (+=) the parameter gradients into grads14 (single workgroup, no atomics). */
+long long hos_pose_refine_saved_floats(void);
+int hos_pose_refine_fwd(const float* posevec, const float* Rs, const float* Ts, const float* const* weights14,
+                        int F, int K, int width, float* Rs_out, float* Ts_out, float* saved, hos_stream_t stream);
+int hos_pose_refine_bwd(const float* g_Rs_out, const float* g_Ts_out, const float* posevec, const float* Rs,
+                        const float* saved, const float* const* weights14, float* const* grads14, int F, int K, int width,
+                        hos_stream_t stream);
+
+/* MotionBasisComputer.forward (U:134-174): G_dst = kinematic chain of [R_i|T_i] over the SMPL tree (U:100-103);
+ * backward bases [R_bwd|T_bwd] = G_cnl G_dst^-1 (observation -> canonical, used by the backward LBS warp N:304-355),
+ * forward bases [R_fwd|T_fwd] = G_dst G_cnl^-1 (N:357-399).  cnl_gtfms [K,4,4] row-major (shared by the frames).
+ * The affine inverses are closed form (adjugate / determinant) -- the function torch.inverse computes by LU.
+ * The backward takes the gradients w.r.t. the four outputs (any may be NULL) and writes g_dst_Rs / g_dst_Ts. */
+int hos_motion_basis_fwd(const float* dst_Rs, const float* dst_Ts, const float* cnl_gtfms, int F, int K,
+                         float* R_bwd, float* T_bwd, float* R_fwd, float* T_fwd, hos_stream_t stream);
+int hos_motion_basis_bwd(const float* g_R_bwd, const float* g_T_bwd, const float* g_R_fwd, const float* g_T_fwd,
+                         const float* dst_Rs, const float* dst_Ts, const float* cnl_gtfms, int F, int K,
+                         float* g_dst_Rs, float* g_dst_Ts, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training losses of the human-object stages, values and gradients on the
+ * device, no host round trip, deterministic summation order.
+ * Replaces `get_loss` M:1690-1716 (stage 3) and 2nd_State_Conditional_Human-Object/src/model/mipnerf360/
+ * model.py:918-944 (stage 2) minus their LPIPS term: `img2mse` + `_unpack_imgs` (M:36, M:41-50), `flow_func`
+ * M:1680-1688 with `img2mae` M:61-71, and the cycle term M:1707-1709.
+ *   mse   = (sum_rays |rgb - target|^2 + mse_const) / mse_count     (mse_const: the patch pixels outside the
+ *           ray mask, which `_unpack_imgs` fills with the background colour; 0 in stage 3)
+ *   flow  = sum |uv(pts_prev) - ray_grid[:, :2] - ray_grid[:, 2:4]| * weights * M / (S * sum_b M_b + 1e-8) / 2,
+ *           M_b = ray_grid[b,4] (* fg[b] if fg != NULL: the stage-3 row selection M:1704); pts_prev NULL -> 0
+ *   cycle = mean over the first n rows of |observe - deform|^2 / 2, n = min(n_cyc, *n_cyc_dev) (n_cyc_dev may
+ *           be NULL); n == 0 -> 0 (the reference's single-point fallback N:534-536 gives the same 0)
+ * out8 = {total, mse, flow, cycle, 1/flow-denominator, 1/n, sum_b M_b, n}.
+ * workspace: hos_train_losses_workspace_floats() floats, zeroed once by the caller (re-armed by the kernel). */
+long long hos_train_losses_workspace_floats(void);
+int hos_train_losses_fwd(const float* rgb, const float* target, long long n_rays, float mse_const, float mse_count,
+                         const float* pts_prev, const float* weights, const float* ray_grid, const int32_t* fg,
+                         const float* cam_prev, const float* intrinsics_prev, int S,
+                         const float* observe, const float* deform, long long n_cyc, const int32_t* n_cyc_dev,
+                         float w_mse, float w_flow, float w_cycle, float* workspace, float* out8,
+                         hos_stream_t stream);
+/* Gradients of `total` (scaled by *g_total, 1 if NULL) w.r.t. rgb [n_rays,3], pts_prev [n_rays,S,3],
+ * weights [n_rays,S] and deform [n_cyc,3] (rows >= n are zeroed); any output may be NULL. */
+int hos_train_losses_bwd(const float* g_total, const float* out8, const float* rgb, const float* target, long long n_rays,
+                         float mse_count, const float* pts_prev, const float* weights, const float* ray_grid,
+                         const int32_t* fg, const float* cam_prev, const float* intrinsics_prev, int S,
+                         const float* observe, const float* deform, long long n_cyc, const int32_t* n_cyc_dev,
+                         float w_mse, float w_flow, float w_cycle,
+                         float* g_rgb, float* g_pts_prev, float* g_weights, float* g_deform, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Optimiser over flat buffers (torch.optim.Adam semantics, M1:536-539; PL norm clipping,
  * S1/run.py:155 gradient_clip_val).
  * ------------------------------------------------------------------------------------------ */

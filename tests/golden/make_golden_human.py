@@ -115,6 +115,22 @@ def golden_human_forward(net, cfg):
             if k in res and res[k] is not None:
                 out[p + k] = res[k]
     cfg.perturb = 0.0
+    # ---- stage 2: the reference's stage-2 Network (composites inside, N2:273-299, 538-556), same weights and items
+    cfg2, net2 = refload.human_network(2, transitions=(0.4,))
+    print(net2.load_state_dict(synth.human_state_dict(777, 2), strict=True))
+    net2.eval()
+    for tag, time, is_train, it, perturb in (("evalA", 0.5, False, 3e5, 0.0), ("trainA", 0.5, True, 3e5, 1.0),
+                                             ("earlyB", 0.3, True, 1000.0, 0.0), ("t0C", 0.0, True, 3e5, 0.0)):
+        b = synth.human_batch(8, seed=21, time=time, is_train=is_train, iter_val=it)
+        cfg2.perturb = perturb
+        torch.manual_seed(77)
+        with refload.stage(2), torch.no_grad():
+            res = net2(**_kw(b))
+        p = f"s2_{tag}_"
+        for k in ("rgb", "alpha", "depth", "weights", "deform_pts_final", "observe_pts", "deform_pts_prev_final"):
+            if k in res and res[k] is not None:
+                out[p + k] = res[k]
+        out[p + "keys"] = np.array(sorted(res.keys()))
     save("human_forward.npz", **out)
 
 
@@ -192,9 +208,13 @@ def main():
     hsd = synth.human_state_dict(777, 2)
     print(net.load_state_dict(hsd, strict=True))
     net.eval()
-    golden_human_parts(net, cfg, hsd)
-    golden_human_forward(net, cfg)
-    golden_stage3_step(net, cfg, hsd)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "parts"):
+        golden_human_parts(net, cfg, hsd)
+    if only in (None, "forward"):
+        golden_human_forward(net, cfg)
+    if only in (None, "step"):
+        golden_stage3_step(net, cfg, hsd)
 
 
 if __name__ == "__main__":

@@ -113,6 +113,32 @@ def test_forward_s3(hsd, tag):
         close(out["z_vals"], hf[p + "z_vals"], 1e-6)
 
 
+@pytest.mark.parametrize("tag,time,is_train,it,perturb", [("evalA", 0.5, False, 3e5, 0.0), ("trainA", 0.5, True, 3e5, 1.0),
+                                                          ("earlyB", 0.3, True, 1000.0, 0.0), ("t0C", 0.0, True, 3e5, 0.0)])
+def test_forward_s2(hsd, tag, time, is_train, it, perturb):
+    """oracle.human_forward(stage=2) against the reference's STAGE-2 Network (2nd_State_Conditional_Human-Object/core/nets/
+    human_nerf/network.py:273-299, 538-556: composites inside, returns rgb / alpha / depth / weights), same items and jitter
+    as the stage-3 cases."""
+    hf = load("human_forward.npz")
+    p = f"s2_{tag}_"
+    b = synth.human_batch(8, seed=21, time=time, is_train=is_train, iter_val=it)
+    t_rand = T(hf[f"s3_{tag}_t_rand"]) if perturb > 0 else None
+    with torch.no_grad():
+        out = oh.human_forward(hsd, b, transitions_times=[0.4], t_rand=t_rand, stage=2)
+    close(out["rgb"], hf[p + "rgb"], 2e-5)
+    close(out["alpha"], hf[p + "alpha"], 2e-5)
+    close(out["weights"], hf[p + "weights"], 2e-5)
+    close(out["depth"], hf[p + "depth"], 1e-4)
+    close(out["observe_pts"], hf[p + "observe_pts"], 2e-6)
+    close(out["deform_pts_final"], hf[p + "deform_pts_final"], 5e-5)
+    ref_keys = set(hf[p + "keys"].tolist())
+    assert ref_keys <= set(out.keys()), ref_keys - set(out.keys())
+    if (p + "deform_pts_prev_final") in hf:
+        close(out["deform_pts_prev_final"], hf[p + "deform_pts_prev_final"], 3e-4)
+    else:
+        assert "deform_pts_prev_final" not in out and "deform_pts_prev_final" not in ref_keys
+
+
 @pytest.mark.parametrize("tag,B,seed", [("A", 16, 31), ("tinyd", 8, 32), ("nofg", 8, 33)])
 def test_stage3_composite(hsd, tag, B, seed):
     st = load("stage3_step.npz")
