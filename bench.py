@@ -1,23 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- train rays/s of the stage-1 state-conditional mip-NeRF-360 step on MI355X.
+"""bench.py -- train rays/s of the HOSNeRF training steps on MI355X (BASELINE.json metric: "train rays/sec at 1/2/4/8 MI355X").
 
-Workload = BASELINE.json configs[1]: "Stage-1 background mip-NeRF-360 Backpack, 1024 rays/batch,
-1xMI355X" restated on synthetic rays: 1024 rays per GPU, 64/64/32 samples,
-2x PropMLP 4x256 + NeRFMLP 8x1024 (9.50 M params), reference-style random init, fp32.
-One "step" = forward (3 levels) + Charbonnier/interlevel/distortion losses + backward + gradient
-all-reduce (N>1) + norm clipping (0.001) + Adam -- nothing skipped, inputs resident in HBM.
+PRIMARY line (the `value` / `ms_per_step` / `roofline` of the one JSON line):
+  BASELINE configs[3] -- stage-3 full HOSNeRF (background mip-NeRF-360 + human-object branch + z-merged composite + MSE /
+  flow / cycle losses + two flat Adam updates), **4096 rays per step GLOBAL, STRONG scaling**: 4096 / N rays per GPU, every
+  rank's flat gradients (38 MB background + 259 MB human) all-reduced over RCCL.  This is the series the north-star's
+  ">= 6x at 8 GPUs" refers to.  At N = 1 all 4096 rays run on one GPU.
+SECONDARY objects in the same line (`stages`):
+  stage2  BASELINE configs[2] -- the reference's stage-2 step (human-object network with its in-network composite, 0.2 MSE on
+          unpacked patches + 0.01 flow + 0.01 cycle, Adam; 2048 rays = 2 patches of 32x32), N = 1 only, next to the SAME op
+          graph as plain PyTorch-ROCm ops on the same GPU (`torch_rocm`: the denominator of the north-star's ">= 10x").
+  stage1  BASELINE configs[1] -- stage-1 background mip-NeRF-360, 1024 rays per GPU (weak scaling), one all-reduce per step.
+One "step" = forward + losses + backward + gradient all-reduce (N > 1) + (clip +) Adam; nothing skipped, inputs resident in
+HBM.  Steps are captured once in a hipGraph (forward + backward [+ optimiser at N = 1]) and replayed; per-step scalars that
+change (learning rate, Adam bias corrections) live in device memory.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
-
-Multi-GPU: one process per GPU; rays are independent, so each rank renders its own 1024 rays
-(weak scaling, like the reference's 4096 rays over 4 GPUs) and the only exchange is ONE RCCL
-all-reduce of the flat 38 MB gradient per step.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,7 +36,9 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SPLIT_MFMA_PEAK_TFLOPS = 2500.0 / 3   # 3 bf16/fp16 MFMAs (dense peak ~2.5 PFLOP/s) per algorithmic product
-S1_TRAIN_FLOP_PER_RAY = 1841e6     # 2*(128*881408 + 32*25242496)
+# SURVEY 8(d) algorithmic FLOP per ray (2 FLOP per MAC; forward + weight gradients + the data gradients that are needed)
+FLOP_PER_RAY = {"stage1": 1841e6, "stage2": 558e6 + 77.7e6, "stage3": 2261e6 + 77.7e6}
+GLOBAL_RAYS_S3 = 4096
 
 
 def parse():
@@ -39,14 +46,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
+    ap.add_argument("--primary", choices=["stage3", "stage2", "stage1"], default="stage3")
+    ap.add_argument("--rays", type=int, default=0, help="override the primary workload's GLOBAL ray count (stage 3 / 2) or per-GPU count (stage 1)")
+    ap.add_argument("--only-primary", action="store_true", help="skip the secondary stages and the baseline legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=256)
+    ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--split-graph", action="store_true",
-                    help="capture only zero_grad+forward+loss+backward; all-reduce, clip and Adam are launched eagerly "
-                         "(what multi-GPU runs do, so that no RCCL call sits inside a captured graph)")
     ap.add_argument("--gemm", choices=["planes", "split", "fp32"], default="planes",
                     help="split = fp16/bf16 hi-lo split MFMA (3 products, fp32 accumulate); fp32 = exact fp32 MFMA")
     return ap.parse_args()
@@ -59,41 +65,325 @@ def basedir():
     return d
 
 
-def cpu_baseline(num_rays: int):
-    """The oracle (torch CPU fp32 restatement of the reference op graph, autograd backward, torch Adam)
-    timed on the host cores on a bounded sample of the same workload."""
-    import oracle.background as ob
-    from hosnerf_amd import synth
-    # torch's CPU GEMMs stop scaling (and oversubscribe badly) far below the 256 hardware threads of the
-    # GPU host: use the physical-core-ish count that is fastest in practice and report exactly that
-    cores = min(os.cpu_count() or 1, int(os.environ.get("HOS_CPU_THREADS", "32")))
-    torch.set_num_threads(cores)
-    sd = {k: v.clone().requires_grad_(True) for k, v in synth.background_state_dict(777, 2).items()}
-    params = list(sd.values())
-    opt = torch.optim.Adam(params, lr=2e-3)
-    batch = synth.stage1_batch(num_rays, seed=777)
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One stage's training step on this rank: eager step, captured step, per-step host work."""
 
-    def step():
-        opt.zero_grad()
-        rend, hist = ob.mipnerf360_forward(sd, batch, 0.5, True, 0.1, 1e6, transitions_times=[0.4])
-        loss, _ = ob.stage1_loss(rend[-1]["rgb"], batch["target"], hist)
+    name = ""
+    scaling = "weak"
+
+    def fwd_bwd(self, i):
+        raise NotImplementedError
+
+    def opts(self):
+        raise NotImplementedError
+
+    def lr(self, i):
+        raise NotImplementedError
+
+    def eager_step(self, i):
+        loss = self.fwd_bwd(i)
+        for o in self.opts():
+            o.step(self.lr(i))
+        return loss
+
+
+class Stage1(Workload):
+    name, scaling = "stage1", "weak"
+    describe = ("BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, 64/64/32 samples, "
+                "PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states")
+
+    def __init__(self, dev, rank, world, rays):
+        from hosnerf_amd import synth
+        from hosnerf_amd.mipnerf360 import MipNeRF360
+        from hosnerf_amd.train import FusedAdam
+        self.rays_local, self.rays_global = rays, rays * world
+        self.model = MipNeRF360(basedir(), opaque_background=True)
+        self.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
+        self.model = self.model.to(dev)
+        self.opt = FusedAdam(self.model, lr=2e-3, max_grad_norm=0.001)
+        self.batch = {k: v.to(dev) for k, v in synth.stage1_batch(rays, seed=777 + rank).items()}
+        self.batch["times"] = 0.5      # python float: no host sync inside the step (the reference syncs on `time` every call)
+        self.max_steps = 500000
+        self.frac = torch.zeros(1, device=dev)       # train_frac lives on the device: the captured step anneals like the eager one
+
+    def opts(self):
+        return [self.opt]
+
+    def lr(self, i):
+        from hosnerf_amd.train import stage1_lr
+        return stage1_lr(i, self.max_steps)
+
+    def host_prepare(self, i):
+        self.frac.fill_(i / self.max_steps)
+
+    def fwd_bwd(self, i):
+        from hosnerf_amd.train import stage1_loss
+        self.opt.zero_grad()
+        rend, hist = self.model(self.batch, self.frac, True, True, 0.1, 1e6)
+        loss, _ = stage1_loss(rend[-1]["rgb"], self.batch["target"], hist)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 0.001)
-        opt.step()
+        return loss.detach()
 
-    step()  # warm-up
+
+def _human_item(rays, rank, stage):
+    from hosnerf_amd import synth
+    from hosnerf_amd.train import prepare_patch_targets
+    n_patches = max(1, (rays + 1023) // 1024)
+    b = synth.add_patch_supervision(synth.human_batch(rays, seed=777 + rank, time=0.5, is_train=True, iter_val=3e5), n_patches, 32, 777 + rank)
+    return b, prepare_patch_targets(b)
+
+
+class Stage2(Workload):
+    name, scaling = "stage2", "strong"
+    describe = ("BASELINE configs[2]: stage-2 human-object network (pose refiner + motion bases + volume decoder, backward LBS, "
+                "non-rigid 6x128 + canonical 8x256 MLPs, flow + cycle sets, in-network composite), 128 samples/ray, 2 states")
+
+    def __init__(self, dev, rank, world, rays_global):
+        from hosnerf_amd import synth
+        from hosnerf_amd.human_nerf import Network, default_cfg
+        from hosnerf_amd.train import FusedAdam, batch_to_device, human_lr_ranges
+        self.rays_global, self.rays_local = rays_global, rays_global // world
+        cfg = default_cfg(basedir())
+        cfg.perturb = 1.0
+        cfg.chunk = max(cfg.chunk, self.rays_local)
+        self.net = Network(cfg, stage=2)
+        self.net.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+        self.net = self.net.to(dev)
+        self.host_item, prepared = _human_item(self.rays_local, rank, 2)
+        self.batch = batch_to_device(prepared, dev)      # control scalars (time, iter_val) stay on the host
+        self.opt = FusedAdam(self.net, lr=6.667e-4, lr_ranges=human_lr_ranges(self.net, 6.667e-4, 6.667e-5))
+
+    def opts(self):
+        return [self.opt]
+
+    def lr(self, i):
+        from hosnerf_amd.train import human_lr_decay
+        return 6.667e-4 * human_lr_decay(300000 + i)
+
+    def host_prepare(self, i):
+        pass
+
+    def fwd_bwd(self, i):
+        from hosnerf_amd.train import stage2_losses
+        self.opt.zero_grad()
+        out = self.net(static_cycle=True, **self.batch)
+        loss, _ = stage2_losses(out, self.batch)
+        loss.backward()
+        return loss.detach()
+
+
+class Stage3(Workload):
+    name, scaling = "stage3", "strong"
+    describe = ("BASELINE configs[3]: stage-3 full HOSNeRF (mip-NeRF-360 background 64/64/32 samples + human-object branch 128 "
+                "samples + 160-sample z-merged composite), 4096 rays/batch GLOBAL, DDP over ray shards")
+
+    def __init__(self, dev, rank, world, rays_global):
+        from hosnerf_amd import synth
+        from hosnerf_amd.hosnerf import HOSNeRF
+        from hosnerf_amd.human_nerf import default_cfg
+        from hosnerf_amd.train import FusedAdam, batch_to_device, human_lr_ranges
+        self.rays_global, self.rays_local = rays_global, rays_global // world
+        cfg = default_cfg(basedir())
+        cfg.perturb = 1.0
+        cfg.chunk = max(cfg.chunk, self.rays_local)
+        self.hos = HOSNeRF(cfg)
+        self.hos.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+        self.hos.human.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+        self.hos = self.hos.to(dev)
+        self.host_item, prepared = _human_item(self.rays_local, rank, 3)
+        self.batch = batch_to_device(prepared, dev)
+        self.ob = FusedAdam(self.hos.model, lr=6.667e-5)
+        self.oh = FusedAdam(self.hos.human, lr=6.667e-5, lr_ranges=human_lr_ranges(self.hos.human))
+
+    def opts(self):
+        return [self.ob, self.oh]
+
+    def lr(self, i):
+        from hosnerf_amd.train import human_lr_decay
+        return 6.667e-5 * human_lr_decay(300000 + i)
+
+    def host_prepare(self, i):
+        pass
+
+    def fwd_bwd(self, i):
+        from hosnerf_amd.train import stage3_losses
+        self.ob.zero_grad()
+        self.oh.zero_grad()
+        out = self.hos.render(self.batch, randomized=True, is_train=True, static_cycle=True)
+        loss, _ = stage3_losses(out, self.batch)
+        loss.backward()
+        return loss.detach()
+
+
+# ------------------------------------------------------------------------------------------------ timing
+def run_workload(wl, args, dev, rank, world, dist, want_events):
+    """Warm up, capture, time exactly args.steps steps between barriers; returns (seconds [max over ranks], info dict)."""
+    from hosnerf_amd import ops
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        wl.host_prepare(i)
+        wl.eager_step(i)
+    barrier()
+    graph, static_loss, launch = None, None, "eager"
+    full_graph = world == 1        # RCCL stays outside the captured region: fwd+bwd graph, eager all-reduce + optimiser
+    if not args.no_graph:
+        try:
+            for o in wl.opts():
+                o.set_step_hyper(wl.lr(args.warmup))
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    wl.fwd_bwd(args.warmup)
+                    for o in wl.opts():
+                        o.step(dynamic=True)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+                static_loss = wl.fwd_bwd(args.warmup)
+                if full_graph:
+                    for o in wl.opts():
+                        o.step(dynamic=True)
+            for _ in range(2):
+                for o in wl.opts():
+                    o.set_step_hyper(wl.lr(args.warmup))
+                graph.replay()
+                if not full_graph:
+                    for o in wl.opts():
+                        o.step(dynamic=True)
+            torch.cuda.synchronize()
+            launch = "hipGraph replay" if full_graph else "hipGraph replay (fwd+bwd) + eager all-reduce/Adam"
+        except Exception as e:      # fall back to eager launches, and say so in the JSON
+            print(f"[bench] {wl.name}: graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step = args.warmup + i
+        wl.host_prepare(step)
+        if graph is not None:
+            for o in wl.opts():
+                o.set_step_hyper(wl.lr(step))
+            graph.replay()
+            if not full_graph:
+                for o in wl.opts():
+                    o.step(dynamic=True)
+            loss = static_loss
+        else:
+            loss = wl.eager_step(step)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    info = {"launch": launch, "final_loss": float(loss.detach())}
+    table = None
+    if want_events and rank == 0:
+        # per-kernel HIP-event timing cannot be recorded inside a captured graph: time the same steps eagerly right after
+        # the timed region (same kernels, same shapes; rocprofv3 --stats of this command agrees)
+        prof = ops.KernelEvents()
+        ops.set_kernel_events(prof)
+        for i in range(min(args.steps, 3)):
+            wl.fwd_bwd(args.warmup + args.steps + i)       # rank-local: no collective outside the timed region
+        torch.cuda.synchronize()
+        ops.set_kernel_events(None)
+        table = prof.summary()
+    return dt, info, table
+
+
+def source_hash(*rel):
+    h = hashlib.sha256()
+    for r in rel:
+        with open(os.path.join(ROOT, r), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def roofline_of(table, gemm):
+    """The dominant GEMM launch of the step against the MFMA peak of the arithmetic it uses.  `traffic` (HBM bytes per launch, PMC)
+    comes from the committed rocprofv3 --pmc pass of the same kernel and shape (scripts/pmc_gemmp.sh) and is reported only
+    if that pass was made on the kernel sources this library was built from; null otherwise."""
+    if not table:
+        return None
+    dom = max(table, key=lambda r: r["total_ms"])
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_gemmp_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("source_hash") == source_hash("hosnerf_amd/csrc/hos_gemmp.hip", "hosnerf_amd/csrc/hos_gemm_common.h"):
+            traffic = tj.get("kernels", {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
+    peak = FP32_MFMA_PEAK_TFLOPS if gemm == "fp32" else SPLIT_MFMA_PEAK_TFLOPS
+    return {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
+            "traffic": traffic, "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
+            "flop_per_launch": dom["flop_per_launch"]}
+
+
+# ------------------------------------------------------------------------------------------------ baseline legs
+def _time_steps(step, warm, budget_s, max_n, sync=None):
+    for _ in range(warm):
+        step()
+    if sync:
+        sync()
     t0 = time.perf_counter()
     n = 0
     while True:
         step()
         n += 1
-        if time.perf_counter() - t0 > 12.0 or n >= 8:
+        if sync:
+            sync()
+        if time.perf_counter() - t0 > budget_s or n >= max_n:
             break
-    dt = (time.perf_counter() - t0) / n
-    return {"value": num_rays / dt, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed step(s) of {num_rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads)"}
+    return (time.perf_counter() - t0) / n, n
 
 
+def cpu_baseline(stage: str, device=None, rays: int = 0):
+    """THE BASELINE LEG -- the only place this file touches oracle/: the oracle (torch fp32 restatement of the reference's op
+    graph, autograd backward, torch Adam) timed as the reference would run,
+      * device=None: on the host cores, on a bounded sample of the workload (the `cpu_baseline` object), and
+      * device=cuda: the same op graph as plain PyTorch-ROCm ops on this GPU (fp32 rocBLAS / MIOpen kernels) -- what the
+        reference does on this hardware, the denominator of the north-star's ">= 10x the reference PyTorch path".
+    Never the product path: nothing measured as `value` runs through here."""
+    import oracle.steps as osteps
+    from hosnerf_amd import synth
+    on_gpu = device is not None
+    dev = device if on_gpu else "cpu"
+    if not on_gpu:
+        # torch's CPU GEMMs stop scaling (and oversubscribe badly) far below the 256 hardware threads of the GPU host: use
+        # the count that is fastest in practice and report exactly that
+        cores = min(os.cpu_count() or 1, int(os.environ.get("HOS_CPU_THREADS", "32")))
+        torch.set_num_threads(cores)
+        rays = 256 if stage == "stage1" else 128
+    if stage == "stage1":
+        step = osteps.stage1_step(synth.background_state_dict(777, 2), synth.stage1_batch(rays, seed=777), device=dev)
+    else:
+        b = synth.add_patch_supervision(synth.human_batch(rays, seed=777, time=0.5, is_train=True, iter_val=3e5), max(1, rays // 1024), 32, 777)
+        if stage == "stage2":
+            step = osteps.stage2_step(synth.human_state_dict(777, 2), b, device=dev)
+        else:
+            step = osteps.stage3_step(synth.background_state_dict(777, 2), synth.human_state_dict(777, 2), b, device=dev)
+    if on_gpu:
+        dt, n = _time_steps(step, 1, 4.0, 5, sync=torch.cuda.synchronize)
+        del step
+        torch.cuda.empty_cache()
+        return {"value": rays / dt, "unit": "rays/s", "rays": rays, "steps": n,
+                "what": "the reference's op graph (oracle restatement) as PyTorch-ROCm ops on the same GPU: fp32 rocBLAS, autograd, torch Adam"}
+    dt, n = _time_steps(step, 1, 12.0, 8)
+    return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "workload": stage,
+            "sample": f"{n} timed step(s) of {rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads)"}
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -118,143 +408,67 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from hosnerf_amd import ops, synth
-    from hosnerf_amd.mipnerf360 import MipNeRF360
-    from hosnerf_amd.train import FusedAdam, stage1_loss, stage1_lr
-
+    from hosnerf_amd import ops
     ops.set_gemm_mode({"planes": ops.GEMM_PLANES, "split": ops.GEMM_BF16X3, "fp32": ops.GEMM_FP32}[args.gemm])
-    model = MipNeRF360(basedir(), opaque_background=True)
-    model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
-    model = model.to(dev)
-    opt = FusedAdam(model, lr=2e-3, max_grad_norm=0.001)
-    batch = {k: v.to(dev) for k, v in synth.stage1_batch(args.rays, seed=777 + rank).items()}
-    max_steps = 500000
 
-    batch["times"] = 0.5          # python float: no host sync inside the step (the reference syncs on `time` every call)
+    def make(name):
+        if name == "stage1":
+            return Stage1(dev, rank, world, args.rays if (args.rays and args.primary == "stage1") else 1024)
+        g = args.rays if (args.rays and args.primary == name) else (GLOBAL_RAYS_S3 if name == "stage3" else 2048)
+        if g % world:
+            raise SystemExit(f"{g} global rays do not divide over {world} ranks")
+        return (Stage3 if name == "stage3" else Stage2)(dev, rank, world, g)
 
-    def fwd_bwd(i, frac=None):
-        opt.zero_grad()
-        rend, hist = model(batch, (i / max_steps) if frac is None else frac, True, True, 0.1, 1e6)
-        loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
-        loss.backward()
-        return loss.detach()
+    def measure(name, events):
+        wl = make(name)
+        dt, info, table = run_workload(wl, args, dev, rank, world, dist, events)
+        rays_total = wl.rays_global * args.steps
+        res = {"value": rays_total / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": wl.scaling,
+               "rays_per_gpu": wl.rays_local, "global_rays": wl.rays_global, "workload": wl.describe,
+               "algorithmic_tflops": rays_total * FLOP_PER_RAY[name] / dt / 1e12, **info}
+        del wl
+        torch.cuda.empty_cache()
+        return res, table
 
-    def step(i, dynamic=False, frac=None):
-        loss = fwd_bwd(i, frac)
-        if dynamic:
-            opt.step(dynamic=True)
-        else:
-            opt.step(stage1_lr(i, max_steps))
-        return loss
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-
-    # ---- optional: capture ONE full training step in a hipGraph and replay it (removes ~150 host launches/step).
-    # Per-step scalars that change (lr, Adam bias corrections) live in a 12-byte device block refreshed before each
-    # replay; train_frac (only the resampling anneal scalar) is frozen at its capture value.
-    graph = None
-    split_graph = (world > 1 or args.split_graph)     # keep the RCCL all-reduce (and the 3 launches behind it) out of the graph
-    if not args.no_graph:
-        try:
-            opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    step(args.warmup, dynamic=True, frac=0.5)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
-                static_loss = fwd_bwd(args.warmup, frac=0.5) if split_graph else step(args.warmup, dynamic=True, frac=0.5)
-            for _ in range(2):
-                opt.set_step_hyper(stage1_lr(args.warmup, max_steps))
-                graph.replay()
-                if split_graph:
-                    opt.step(dynamic=True)
-            torch.cuda.synchronize()
-        except Exception as e:      # fall back to eager launches, and say so in the JSON
-            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-    barrier()
-    prof = None
-    if graph is None and rank == 0 and not args.no_kernel_events:
-        prof = ops.KernelEvents()
-        ops.set_kernel_events(prof)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if graph is not None:
-            opt.set_step_hyper(stage1_lr(args.warmup + i, max_steps))
-            graph.replay()
-            if split_graph:
-                opt.step(dynamic=True)
-            loss = static_loss
-        else:
-            loss = step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.set_kernel_events(None)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
-    final_loss = float(loss.detach())
-    if graph is not None and rank == 0 and not args.no_kernel_events:
-        # per-kernel HIP-event timing cannot be recorded inside a captured graph: time the same steps eagerly
-        # right after the timed region (same kernels, same shapes; rocprofv3 --stats of this command agrees)
-        prof = ops.KernelEvents()
-        ops.set_kernel_events(prof)
-        for i in range(min(args.steps, 5)):
-            fwd_bwd(args.warmup + args.steps + i)       # rank-local: no collective outside the timed region
-        torch.cuda.synchronize()
-        ops.set_kernel_events(None)
-
+    events = not args.no_kernel_events
+    prim, table = measure(args.primary, events)
+    stages = {}
+    if not args.only_primary:
+        for name in ("stage2", "stage1"):
+            if name == args.primary or (name == "stage2" and world > 1):
+                continue
+            stages[name], _ = measure(name, False)
     if rank == 0:
-        rays_total = args.rays * world * args.steps
         out = {
-            "metric": "train rays/sec (stage-1 state-conditional mip-NeRF-360, fwd+loss+bwd+clip+Adam)",
-            "value": rays_total / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": f"train rays/sec ({args.primary}: forward + losses + backward + gradient all-reduce + Adam)",
+            "value": prim["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)",
-            "gemm": args.gemm,
-            "launch": ("hipGraph replay (fwd+bwd) + eager all-reduce/clip/Adam" if split_graph else "hipGraph replay") if graph is not None else "eager", "data": "synthetic rays (seeded), random-init weights of the reference architecture",
-            "config": {"workload": "BASELINE configs[1]: stage-1 background mip-NeRF-360, 1024 rays/batch per GPU, "
-                                   "64/64/32 samples, PropMLP 4x256 x2 + NeRFMLP 8x1024, 2 states",
-                       "rays_per_gpu": args.rays, "global_rays": args.rays * world, "parallelism": f"dp{world} (ray shards, 1 flat-gradient all-reduce/step)"},
-            "final_loss": final_loss,
-            "algorithmic_tflops": rays_total * S1_TRAIN_FLOP_PER_RAY / dt / 1e12,
+            "gemm": args.gemm, "launch": prim["launch"],
+            "data": "synthetic rays / poses (seeded), random-init weights of the reference architecture",
+            "config": {"workload": prim["workload"], "rays_per_gpu": prim["rays_per_gpu"], "global_rays": prim["global_rays"],
+                       "parallelism": f"dp{world} (ray shards; flat-gradient all-reduce per module per step)"},
+            "final_loss": prim["final_loss"], "algorithmic_tflops": prim["algorithmic_tflops"],
         }
-        if prof is not None:
-            table = prof.summary()
-            dom = max(table, key=lambda r: r["total_ms"]) if table else None
-            if dom is not None:
-                # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process,
-                # so the figure comes from the committed rocprofv3 --pmc pass of the same kernel and shape
-                # (scripts/pmc_gemmp.sh -> profiles/r01_pmc_gemmp_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE); null if absent
-                traffic = None
-                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemmp_traffic.json")
-                if os.path.exists(tpath):
-                    with open(tpath) as f:
-                        tj = json.load(f)
-                    key = dom["kernel"].split("[")[0] + "[32768x1024x1024]"
-                    if key in tj and dom["flop_per_launch"] == 2.0 * 32768 * 1024 * 1024:
-                        traffic = tj[key]["hbm_bytes_per_launch"]
-                peak = FP32_MFMA_PEAK_TFLOPS if args.gemm == "fp32" else SPLIT_MFMA_PEAK_TFLOPS
-                out["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s",
-                                   "frac": dom["tflops"] / peak, "traffic": traffic,
-                                   "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
-                                   "flop_per_launch": dom["flop_per_launch"]}
-            out["kernels"] = table
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        roof = roofline_of(table, args.gemm)
+        if roof is not None:
+            out["roofline"] = roof
+            out["kernels"] = table[:16]
+        if world == 1 and not args.only_primary:
+            if not args.no_torch_baseline:
+                for name, rays in (("stage2", 2048), (args.primary, prim["global_rays"])):
+                    tb = cpu_baseline(name, device=dev, rays=rays)
+                    tgt = stages.get(name, prim if name == args.primary else None)
+                    if tgt is not None:
+                        tgt["torch_rocm"] = tb
+                        tgt["speedup_vs_torch_rocm"] = tgt["value"] / tb["value"]
+                    if name == args.primary:
+                        out["torch_rocm"] = tb
+                        out["speedup_vs_torch_rocm"] = prim["value"] / tb["value"]
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.primary)
+        if stages:
+            out["stages"] = stages
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

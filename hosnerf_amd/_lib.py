@@ -46,7 +46,7 @@ PROTOTYPES = {
     "hos_split_planes2": [_P, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_linearp_dgrad": [_P, _I, _P, _I, _I, _P, _I, _I, _I, _P, _I, _P],
     "hos_linearp_wgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
-    "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],
+    "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _P, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],
     "hos_encode_ipe": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P],
     "hos_encode_ipe_planes": [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P],
     "hos_encode_viewdirs": [_P, _I, _I, _P, _I, _I, _P],
@@ -72,6 +72,9 @@ PROTOTYPES = {
     "hos_raw2outputs_bwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],
     "hos_merge_composite_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "hos_merge_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "hos_compact_workspace_ints": [],
+    "hos_compact_rows": [_P, _F, _P, _P, _L, _P, _P, _P, _P, _P, _P],
+    "hos_scatter_rows": [_P, _P, _P, _L, _P, _P],
     "hos_pose_refine_saved_floats": [],
     "hos_pose_refine_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "hos_pose_refine_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
@@ -85,7 +88,7 @@ PROTOTYPES = {
     "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
 }
 _RESTYPES = {"hos_error_string": c_char_p, "hos_train_losses_workspace_floats": c_int64,
-             "hos_pose_refine_saved_floats": c_int64}
+             "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64}
 
 _lib = None
 

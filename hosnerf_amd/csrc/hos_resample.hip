@@ -49,10 +49,15 @@ __device__ __forceinline__ int count_le(const float* a, int n, float x) {
 
 __global__ __launch_bounds__(256) void resample_kernel(
     const float* __restrict__ sdist_prev, const float* __restrict__ w_prev, int n, int B, int S,
-    float dilation, float anneal, float pad, const float* __restrict__ u_base,
+    float dilation, float anneal, const float* __restrict__ train_frac_dev, float anneal_slope, float pad,
+    const float* __restrict__ u_base,
     const float* __restrict__ jitter, float jitter_scale, float s_near, float s_far,
     float* __restrict__ sdist, float* __restrict__ tdist, int32_t* __restrict__ bin_idx) {
     __shared__ RayLds lds[4];
+    if (train_frac_dev) {      // M:459-460 bias(train_frac, slope) from device memory: a captured step anneals like an eager one
+        const double x = (double)*train_frac_dev;
+        anneal = anneal_slope > 0.f ? (float)(((double)anneal_slope * x) / (((double)anneal_slope - 1.0) * x + 1.0)) : 1.f;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ray_raw = blockIdx.x * 4 + wave;
     const bool live = ray_raw < B;
@@ -190,15 +195,15 @@ __global__ __launch_bounds__(256) void resample_kernel(
 }  // namespace
 
 extern "C" int hos_resample(const float* sdist_prev, const float* w_prev, int n_prev, int B, int S,
-                            float dilation, float anneal, float resample_padding,
-                            const float* u_base, const float* jitter, float jitter_scale,
+                            float dilation, float anneal, const float* train_frac_dev, float anneal_slope,
+                            float resample_padding, const float* u_base, const float* jitter, float jitter_scale,
                             float near_, float far_, float* sdist, float* tdist, int32_t* bin_idx,
                             hos_stream_t stream) {
     if (!sdist_prev || !w_prev || !u_base || !sdist || !tdist || B <= 0) return HOS_E_ARG;
     if (n_prev < 1 || n_prev > NMAX || S < 2 || S > SMAX) return HOS_E_SHAPE;
     const float s_near = (float)(1.0 / (double)near_), s_far = (float)(1.0 / (double)far_);
     hipLaunchKernelGGL(resample_kernel, dim3(hos_cdiv(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       sdist_prev, w_prev, n_prev, B, S, dilation, anneal, resample_padding, u_base, jitter,
+                       sdist_prev, w_prev, n_prev, B, S, dilation, anneal, train_frac_dev, anneal_slope, resample_padding, u_base, jitter,
                        jitter_scale, s_near, s_far, sdist, tdist, bin_idx);
     return hos_launch_status();
 }

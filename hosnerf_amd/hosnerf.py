@@ -34,14 +34,14 @@ class HOSNeRF(nn.Module):
         self.human.store.zero_grad()
 
     def render(self, batch: Dict[str, torch.Tensor], randomized: bool = True, is_train: bool = True,
-               jitters=None, t_rand=None, prologue=None, with_cycle: bool = True) -> Dict[str, torch.Tensor]:
+               jitters=None, t_rand=None, prologue=None, with_cycle: bool = True, static_cycle: bool = False) -> Dict[str, torch.Tensor]:
         """M:1507-1596 on one ray batch (keys of SURVEY Appendix B).  Returns the human dict + `rgb` [B,3],
         `idx_fg`, `total_order`, `human_weights_sorted` and the background `ray_history`."""
         batch_bkg = {"rays_o": batch["rays_o_bkg"], "rays_d": batch["rays_d_bkg"], "viewdirs": batch["viewdirs_bkg"],
                      "radii": batch["radii"], "times": batch["time"]}
         # the reference passes train_frac = 1.0 and randomized = True everywhere in stage 3 (M:1512-1516, M:720-723)
         _, hist = self.model(batch_bkg, 1.0, randomized, is_train, self.near_bkg, self.far_bkg, jitters=jitters)
-        out = self.human(t_rand=t_rand, prologue=prologue, with_cycle=with_cycle, **batch)
+        out = self.human(t_rand=t_rand, prologue=prologue, with_cycle=with_cycle, static_cycle=static_cycle, **batch)
         last = hist[-1]
         rgb, hw, idx_fg, order, zh = ops.merge_composite(
             last["tdist"], last["rgb"], last["density"], out["human_rgbsigma"], out["newsmpl_pts"], out["pts_mask"],

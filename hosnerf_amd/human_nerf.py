@@ -8,10 +8,10 @@ signature (swallows arbitrary extra kwargs), same output dict, sa
 (`mweight_vol_decoder.*`, `non_rigid_mlp.*`, `non_rigid_forward_mlp.*`, `cnl_mlp.*`, `pose_decoder.*`,
 `human_stateembeds.*`).
 
-Per-step prologue (P2-P4: pose refiner MLP on one 75-vector, 26-joint kinematic chain, the 5-layer
-ConvTranspose3d volume decoder) runs as torch ops on the device -- once per call, a few launches
-(SURVEY 2.2 marks MIOpen/rocBLAS acceptable there).  Everything per sample point (P5-P10) is HIP:
-sample+backward-LBS warp, hann/Fourier embedders, fp32-MFMA MLPs, forward LBS.
+Per-step prologue: pose refiner MLP + Rodrigues + 26-joint kinematic chain + motion bases are two HIP launches
+(hos_pose_refine_*, hos_motion_basis_*; P2, P3), the 5-layer ConvTranspose3d volume decoder is GEMM + gather kernels
+(hos_deconv3d_*; P4).  Everything per sample point (P5-P10) is HIP: sample+backward-LBS warp, hann/Fourier embedders,
+split-MFMA MLPs, forward LBS.
 """
 from __future__ import annotations
 
@@ -250,72 +250,29 @@ class Network(FlatModule):
         flat = self.store.grad if grad else self.store.param
         return L.W.view(flat), L.b.view(flat).view(-1)
 
-    # ------------------------------------------------------------------ prologue (torch ops, once per call)
-    # Both frames of a training step (current pose and previous-frame pose) go through the prologue as ONE batch, and the
-    # kinematic chain is evaluated level by level of the SMPL tree (9 batched products instead of 2 x 25 chained ones):
-    # the prologue is launch-bound (26 joints), so its cost is its number of launches.
+    # ------------------------------------------------------------------ prologue (once per call)
+    # Both frames of a training step (current pose and previous-frame pose) go through the prologue as ONE batch of F = 2:
+    # pose refinement + Rodrigues + composition is one launch (hos_pose_refine_fwd), the kinematic chain + the two families
+    # of motion bases another (hos_motion_basis_fwd); their backward passes are one launch each and write the pose decoder's
+    # parameter gradients straight into the flat gradient buffer.  The reference spends ~120 tiny torch launches (and a
+    # torch.inverse, which synchronises) on these 26 joints.
+    def _pose_tensors(self, grad: bool = False):
+        P = self._plain
+        out = []
+        for name in ops.POSE_PARAM_ORDER:
+            for kind in ("weight", "bias"):
+                p_ = P[f"pose_decoder.{name}.{kind}"]
+                out.append(p_.grad if grad else p_.detach())
+        return out
+
     def _pose_refine(self, Rs, Ts, posevec):
         """N:589-605 + pose_decoders/mlp_delta_body_pose.py + U:66-92.  Rs [F,K,3,3], Ts [F,K,3], posevec [F,75]."""
-        P = self._plain
-        F_ = Rs.shape[0]
-        h = posevec
-        for name in ("block_mlps.0", "block_mlps.2", "block_mlps.4"):
-            h = torch.relu(F.linear(h, P[f"pose_decoder.{name}.weight"], P[f"pose_decoder.{name}.bias"]))
-
-        def head(tag):
-            y = torch.relu(F.linear(h, P[f"pose_decoder.block_mlps_{tag}.0.weight"], P[f"pose_decoder.block_mlps_{tag}.0.bias"]))
-            return F.linear(y, P[f"pose_decoder.block_mlps_{tag}.2.weight"], P[f"pose_decoder.block_mlps_{tag}.2.bias"])
-
-        rvec = head("dstR").view(-1, 3)
-        theta = torch.sqrt(1e-5 + torch.sum(rvec**2, dim=1))
-        r = rvec / theta[:, None]
-        c, s = torch.cos(theta), torch.sin(theta)
-        x, y, z = r[:, 0], r[:, 1], r[:, 2]
-        dR = torch.stack([x * x + (1 - x * x) * c, x * y * (1 - c) - z * s, x * z * (1 - c) + y * s,
-                          x * y * (1 - c) + z * s, y * y + (1 - y * y) * c, y * z * (1 - c) - x * s,
-                          x * z * (1 - c) - y * s, y * z * (1 - c) + x * s, z * z + (1 - z * z) * c], dim=1).view(F_, -1, 3, 3)
-        dT = head("dstT").view(F_, -1, 3)
-        Rs = torch.cat([Rs[:, 0:1], torch.matmul(Rs[:, 1:], dR)], 1)
-        Ts = torch.cat([Ts[:, 0:1], Ts[:, 1:] + dT], 1)
-        return Rs, Ts
-
-    def _chain_levels(self, K: int, device):
-        """Per tree level: (joint indices, position of each joint's parent inside the previous level)."""
-        key = (K, str(device))
-        cache = getattr(self, "_levels_cache", None)
-        if cache is not None and cache[0] == key:
-            return cache[1], cache[2]
-        depth = [0] * K
-        for i in range(1, K):
-            depth[i] = depth[SMPL_PARENT[i]] + 1
-        levels, prev = [], [0]
-        for d in range(1, max(depth) + 1):
-            idx = [i for i in range(K) if depth[i] == d]
-            par = [prev.index(SMPL_PARENT[i]) for i in idx]
-            levels.append((torch.tensor(idx, device=device), torch.tensor(par, device=device)))
-            prev = idx
-        order = [0] + [int(i) for idx, _ in levels for i in idx.tolist()]
-        inv = torch.tensor([order.index(i) for i in range(K)], device=device)
-        self._levels_cache = (key, levels, inv)
-        return levels, inv
+        self.store.ensure_bound()
+        return ops.pose_refine(self._token, Rs, Ts, posevec, self._pose_tensors(False), self._pose_tensors(True))
 
     def _motion_basis(self, dst_Rs, dst_Ts, cnl_gtfms):
         """U:134-174 for F frames at once: dst_Rs [F,K,3,3], dst_Ts [F,K,3] -> (R_bwd, T_bwd, R_fwd, T_fwd), each [F,K,...]."""
-        F_, K = dst_Rs.shape[0], dst_Rs.shape[1]
-        bottom = torch.zeros(F_, K, 1, 4, dtype=dst_Rs.dtype, device=dst_Rs.device)
-        bottom[..., 3] = 1.0
-        G = torch.cat([torch.cat([dst_Rs, dst_Ts[..., None]], -1), bottom], -2)          # [F,K,4,4]
-        levels, inv = self._chain_levels(K, dst_Rs.device)
-        parts = [G[:, 0:1]]
-        prev = parts[0]
-        for idx, par in levels:
-            prev = torch.matmul(prev.index_select(1, par), G.index_select(1, idx))
-            parts.append(prev)
-        dst = torch.cat(parts, 1).index_select(1, inv)
-        bwd = cnl_gtfms @ torch.inverse(dst)
-        fwd = dst @ torch.inverse(cnl_gtfms)
-        return (bwd[..., :3, :3].contiguous(), bwd[..., :3, 3].contiguous(),
-                fwd[..., :3, :3].contiguous(), fwd[..., :3, 3].contiguous())
+        return ops.motion_basis(dst_Rs, dst_Ts, cnl_gtfms)
 
     def _motion_weight_volume(self, priors):
         """deconv_vol_decoder.py:34-42 + U:21-59 -> [K+1, V, V, V]."""
@@ -333,14 +290,20 @@ class Network(FlatModule):
         return F.softmax(h + torch.log(priors[None]), dim=1)[0].contiguous()
 
     def _band_weights(self, iter_val: float, device) -> torch.Tensor:
-        """hannw_fourier.py:29-44 (evaluated with torch on the host, 6 floats)."""
+        """hannw_fourier.py:29-44 (evaluated with torch on the host, 6 floats).  The device copy is cached by value: before
+        kick-in and after full band the weights do not change, and a captured step must not issue a host->device copy."""
         c = self.cfg.non_rigid_motion_mlp
         kick = torch.tensor(float(c.kick_in_iter), dtype=torch.float32)
         t = torch.clamp(torch.tensor(float(iter_val), dtype=torch.float32) - kick, min=0.0)
         Nn = c.full_band_iter - kick
         alpha = c.multires * t / Nn
         j = torch.arange(c.multires, dtype=torch.float32)
-        return ((1.0 - torch.cos(np.pi * torch.clamp(alpha - j, min=0.0, max=1.0))) / 2.0).to(device)
+        w = (1.0 - torch.cos(np.pi * torch.clamp(alpha - j, min=0.0, max=1.0))) / 2.0
+        key = (tuple(w.tolist()), str(device))
+        cache = getattr(self, "_band_cache", None)
+        if cache is None or cache[0] != key:
+            self._band_cache = (key, w.to(device))
+        return self._band_cache[1]
 
     # ------------------------------------------------------------------ HIP MLP chains (forward)
     def _nonrigid_fwd(self, specs: List[_LayerSpec], x: torch.Tensor, cond: torch.Tensor, band_w: torch.Tensor, save: bool):
@@ -514,7 +477,11 @@ class Network(FlatModule):
         return pro
 
     def forward(self, rays, dst_Rs=None, dst_Ts=None, cnl_gtfms=None, motion_weights_priors=None, dst_posevec=None, near=None,
-                far=None, iter_val=1e7, t_rand=None, prologue=None, with_cycle: bool = True, **kwargs):
+                far=None, iter_val=1e7, t_rand=None, prologue=None, with_cycle: bool = True, static_cycle: bool = False, **kwargs):
+        """Reference signature + keyword-only extensions: `t_rand` (the stratified jitter draws), `prologue` (a cached
+        `frame_prologue`), `with_cycle=False` (evaluation loops never read the cycle outputs), `static_cycle=True`
+        (fixed-shape cycle outputs [P,3] + `cycle_count` on the device instead of the reference's data-dependent
+        [n_selected,3]: no host synchronisation, the step can be captured in a hipGraph)."""
         cfg = self.cfg
         dev = rays.device
         K = cfg.total_bones
@@ -570,7 +537,16 @@ class Network(FlatModule):
             if flow:                                                               # N:474-502
                 ret["deform_pts_prev_final"] = fwd_branch(cnl, R_fp, T_fp, cond_prev).view(b, N, 3)
             # N:505-536 (data-dependent size); the frame loops of eval.py never read the cycle outputs and switch them off
-            if with_cycle:
+            if with_cycle and static_cycle:
+                # fixed-capacity form for captured training steps: the selection is a device-side compaction, the row count
+                # stays in device memory (`cycle_count`), rows past it are zero and receive zero gradients
+                if B > chunk:
+                    raise ValueError("static_cycle needs the whole ray batch in one chunk (cfg.chunk >= number of rays)")
+                sel_cnl, observe, _, count = ops.compact_rows(mask, 0.005, cnl, pts)
+                ret["deform_pts_final"] = fwd_branch(sel_cnl, R_f, T_f, cond)
+                ret["observe_pts"] = observe
+                ret["cycle_count"] = count
+            elif with_cycle:
                 sel = torch.nonzero(mask.detach() > 0.005).reshape(-1)
                 if sel.numel() > 0:
                     ret["deform_pts_final"] = fwd_branch(cnl.index_select(0, sel), R_f, T_f, cond)

@@ -586,7 +586,14 @@ class MipNeRF360(FlatModule):
         sdist = torch.cat([torch.zeros(B, 1, device=dev), torch.ones(B, 1, device=dev)], dim=-1)
         weights = torch.ones(B, 1, device=dev)
         prod = 1
-        anneal = (self.anneal_slope * train_frac) / ((self.anneal_slope - 1) * train_frac + 1) if self.anneal_slope > 0 else 1.0
+        # M:459-460.  `train_frac` may be a 1-element device tensor: the anneal factor is then evaluated inside the resampling
+        # kernel, so a step captured once in a hipGraph keeps annealing as training advances (no host value baked in)
+        frac_dev = train_frac if isinstance(train_frac, torch.Tensor) and train_frac.is_cuda else None
+        if frac_dev is not None:
+            anneal = 1.0
+        else:
+            train_frac = float(train_frac)
+            anneal = (self.anneal_slope * train_frac) / ((self.anneal_slope - 1) * train_frac + 1) if self.anneal_slope > 0 else 1.0
         ray_history, renderings = [], []
         for lvl in range(self.num_levels):
             is_prop = lvl < self.num_levels - 1
@@ -595,7 +602,8 @@ class MipNeRF360(FlatModule):
             prod *= S
             jit = None if jitters is None else jitters[lvl]
             out = ops.resample(sdist, weights, S, dilation, anneal, bool(randomized), near, far, jitter=jit,
-                               resample_padding=self.resample_padding, want_index=want_index)
+                               resample_padding=self.resample_padding, want_index=want_index,
+                               train_frac_dev=frac_dev, anneal_slope=float(self.anneal_slope))
             sdist, tdist = out[0], out[1]
             if is_prop and not self.train_proposals:
                 with torch.no_grad():

@@ -277,8 +277,10 @@ def _u_base(S: int, randomized: bool, device) -> Tuple[torch.Tensor, float]:
 
 def resample(sdist_prev: torch.Tensor, w_prev: torch.Tensor, S: int, dilation: float, anneal: float,
              randomized: bool, near: float, far: float, jitter: Optional[torch.Tensor] = None,
-             resample_padding: float = 0.0, want_index: bool = False):
-    """Fused max_dilate -> logits -> inverse-CDF -> interval edges -> s_to_t.  Returns (sdist, tdist[, idx])."""
+             resample_padding: float = 0.0, want_index: bool = False, train_frac_dev: Optional[torch.Tensor] = None,
+             anneal_slope: float = 10.0):
+    """Fused max_dilate -> logits -> inverse-CDF -> interval edges -> s_to_t.  Returns (sdist, tdist[, idx]).
+    `train_frac_dev` (1-element device tensor): the anneal factor is evaluated on the device from it (graph replay)."""
     B, n = w_prev.shape
     dev = w_prev.device
     u, scale = _u_base(S, randomized, dev)
@@ -290,7 +292,7 @@ def resample(sdist_prev: torch.Tensor, w_prev: torch.Tensor, S: int, dilation: f
     tdist = torch.empty(B, S + 1, device=dev)
     idx = torch.empty(B, S, dtype=torch.int32, device=dev) if want_index else None
     call("hos_resample", ptr(sdist_prev.detach()), ptr(w_prev.detach()), n, B, S, float(dilation), float(anneal),
-         float(resample_padding), ptr(u), ptr(None if jitter is None else jitter.reshape(-1)), scale,
+         ptr(train_frac_dev), float(anneal_slope), float(resample_padding), ptr(u), ptr(None if jitter is None else jitter.reshape(-1)), scale,
          float(near), float(far), ptr(sdist), ptr(tdist), ptr(idx, torch.int32))
     return (sdist, tdist, idx) if want_index else (sdist, tdist)
 
@@ -336,7 +338,8 @@ class _AlphaWeights(torch.autograd.Function):
         density, tdist, dirs = ctx.saved_tensors
         B, S = density.shape
         gd = torch.empty_like(density)
-        call("hos_alpha_weights_bwd", ptr(gw.contiguous()), ptr(density), ptr(tdist), ptr(dirs), B, S, ctx.opaque, ptr(gd))
+        gw = gw.contiguous()           # bound to a local: a temporary would be freed (and its block reused) before the launch
+        call("hos_alpha_weights_bwd", ptr(gw), ptr(density), ptr(tdist), ptr(dirs), B, S, ctx.opaque, ptr(gd))
         return gd, None, None, None
 
 
@@ -361,7 +364,8 @@ class _VolRender(torch.autograd.Function):
         B, S = weights.shape
         g_rgbs = torch.empty_like(rgbs) if ctx.needs_input_grad[0] else None
         g_w = torch.empty_like(weights) if ctx.needs_input_grad[1] else None
-        call("hos_volrender_bwd", ptr(g.contiguous()), ptr(rgbs), ptr(weights), B, S, ctx.bg, ptr(g_rgbs), ptr(g_w))
+        g = g.contiguous()
+        call("hos_volrender_bwd", ptr(g), ptr(rgbs), ptr(weights), B, S, ctx.bg, ptr(g_rgbs), ptr(g_w))
         return g_rgbs, g_w, None
 
 
@@ -518,7 +522,9 @@ class _Raw2Outputs(torch.autograd.Function):
         B, S = z_vals.shape
         g_rs = torch.empty_like(rgbsigma)
         g_mask = torch.empty(B, S, device=z_vals.device) if mask is not None else None
-        call("hos_raw2outputs_bwd", ptr(g_rgb.contiguous()), ptr(None if g_w is None else g_w.contiguous()), ptr(rgbsigma), 4,
+        g_rgb = g_rgb.contiguous()     # locals keep the (possibly materialised) cotangents alive until the launch is enqueued
+        g_w = None if g_w is None else g_w.contiguous()
+        call("hos_raw2outputs_bwd", ptr(g_rgb), ptr(g_w), ptr(rgbsigma), 4,
              ptr(rgbsigma) + 12, 4, ptr(z_vals), ptr(rays_d), ptr(mask), ptr(bgcolor), ctx.last_dist, B, S,
              ptr(g_rs), 4, ptr(g_rs) + 12, 4, ptr(g_mask))
         return g_rs, None, None, g_mask, None, None
@@ -559,7 +565,9 @@ class _MergeComposite(torch.autograd.Function):
         g_bden = torch.empty_like(bkg_density)
         g_h = torch.empty_like(human)
         g_m = torch.empty_like(mask)
-        call("hos_merge_composite_bwd", ptr(g_rgb.contiguous()), ptr(None if g_hw is None else g_hw.contiguous()),
+        g_rgb = g_rgb.contiguous()
+        g_hw = None if g_hw is None else g_hw.contiguous()
+        call("hos_merge_composite_bwd", ptr(g_rgb), ptr(g_hw),
              ptr(tdist), ptr(bkg_rgb), ptr(bkg_density), ptr(human), ptr(pts), ptr(mask), ptr(ro), ptr(rd), ptr(A),
              ptr(flag, torch.int32), B, Sb, Sh, ctx.thre, ptr(g_brgb), ptr(g_bden), ptr(g_h), ptr(g_m))
         return g_brgb, g_bden, g_h, g_m, None, None, None, None, None, None, None
@@ -637,14 +645,58 @@ class _MotionBasis(torch.autograd.Function):
     def backward(ctx, gRb, gTb, gRf, gTf):
         Rs, Ts, cnl = ctx.saved_tensors
         F_, K = Rs.shape[0], Rs.shape[1]
-        c = lambda g: None if g is None else g.contiguous()
+        # locals, not temporaries: four materialised cotangents freed one after the other would share one allocator block
+        gRb, gTb, gRf, gTf = (None if g is None else g.contiguous() for g in (gRb, gTb, gRf, gTf))
         gRs, gTs = torch.empty_like(Rs), torch.empty_like(Ts)
-        call("hos_motion_basis_bwd", ptr(c(gRb)), ptr(c(gTb)), ptr(c(gRf)), ptr(c(gTf)), ptr(Rs), ptr(Ts), ptr(cnl), F_, K, ptr(gRs), ptr(gTs))
+        call("hos_motion_basis_bwd", ptr(gRb), ptr(gTb), ptr(gRf), ptr(gTf), ptr(Rs), ptr(Ts), ptr(cnl), F_, K, ptr(gRs), ptr(gTs))
         return gRs, gTs, None
 
 
 def motion_basis(Rs, Ts, cnl_gtfms):
     return _MotionBasis.apply(Rs, Ts, cnl_gtfms)
+
+
+# ------------------------------------------------------------------------------------------ cycle-set selection (P9)
+_COMPACT_WS = {}
+
+
+def _compact_workspace(device) -> torch.Tensor:
+    key = str(device)
+    if key not in _COMPACT_WS:
+        _COMPACT_WS[key] = torch.zeros(int(_lib.load().hos_compact_workspace_ints()), dtype=torch.int32, device=device)
+    return _COMPACT_WS[key]
+
+
+class _CompactRows(torch.autograd.Function):
+    """Order-preserving selection of the rows with mask > thr into fixed-capacity buffers (N:505-536 without the boolean
+    index): returns (a_sel [P,3], b_sel [P,3], sel [P] int32, count [1] int32); rows >= count are zero.  Differentiable
+    w.r.t. `a` (the canonical points): the gradient is scattered back to the selected rows."""
+
+    @staticmethod
+    def forward(ctx, mask, thr, a, b):
+        P = mask.numel()
+        dev = mask.device
+        a_sel, b_sel = torch.empty(P, 3, device=dev), torch.empty(P, 3, device=dev)
+        sel = torch.empty(P, dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev)
+        call("hos_compact_rows", ptr(mask), float(thr), ptr(a), ptr(b), P, ptr(count, torch.int32), ptr(sel, torch.int32), ptr(a_sel),
+             ptr(b_sel), ptr(_compact_workspace(dev), torch.int32))
+        ctx.save_for_backward(sel, count)
+        ctx.mark_non_differentiable(b_sel, sel, count)
+        return a_sel, b_sel, sel, count
+
+    @staticmethod
+    def backward(ctx, g_a, *_):
+        sel, count = ctx.saved_tensors
+        P = sel.numel()
+        g = torch.empty(P, 3, device=sel.device)
+        g_a = g_a.contiguous()
+        call("hos_scatter_rows", ptr(g_a), ptr(sel, torch.int32), ptr(count, torch.int32), P, ptr(g))
+        return None, None, g, None
+
+
+def compact_rows(mask, thr: float, a, b):
+    return _CompactRows.apply(mask.detach().reshape(-1).contiguous(), thr, a.reshape(-1, 3).contiguous(), b.detach().reshape(-1, 3).contiguous())
 
 
 # ------------------------------------------------------------------------------------------ training losses (C4)
@@ -691,7 +743,8 @@ class _TrainLosses(torch.autograd.Function):
         g_pts = torch.empty_like(pts_prev) if (pts_prev is not None and need[4]) else None
         g_w = torch.empty_like(weights) if (weights is not None and need[5]) else None
         g_def = torch.empty_like(deform) if (deform is not None and need[11]) else None
-        call("hos_train_losses_bwd", ptr(g_total.contiguous()), ptr(out), ptr(rgb), ptr(target), B, mse_count, ptr(pts_prev), ptr(weights),
+        g_total = g_total.contiguous()
+        call("hos_train_losses_bwd", ptr(g_total), ptr(out), ptr(rgb), ptr(target), B, mse_count, ptr(pts_prev), ptr(weights),
              ptr(ray_grid), ptr(fg, torch.int32), ptr(cam), ptr(Kin), S, ptr(observe), ptr(deform), n_cyc, ptr(n_cyc_dev, torch.int32),
              w_mse, w_flow, w_cycle, ptr(g_rgb), ptr(g_pts), ptr(g_w), ptr(g_def))
         return (g_rgb, None, None, None, g_pts, g_w, None, None, None, None, None, g_def, None, None, None, None)
@@ -757,8 +810,9 @@ class _LbsForward(torch.autograd.Function):
         g_vol = torch.zeros_like(vol_cl)
         g_R = torch.zeros_like(R_f)
         g_T = torch.zeros_like(T_f)
+        g = g.contiguous()
         call("hos_lbs_forward_bwd", ptr(cnl), ptr(R_f), ptr(T_f), ptr(vol_cl), vol_cl.shape[0], vol_cl.shape[-1], ptr(bmin),
-             ptr(bscale), P, ctx.K, ptr(g.contiguous()), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T))
+             ptr(bscale), P, ctx.K, ptr(g), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T))
         return g_cnl, g_vol, g_R, g_T, None, None, None
 
 

@@ -125,7 +125,7 @@ class LitHumanObject(_LitFlat):
         `train.prepare_patch_targets` + `train.batch_to_device`."""
         batch = dict(batch)
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M2:576
-        out = self.human(**batch)
+        out = self.human(static_cycle=True, **batch)
         loss, _ = stage2_losses(out, batch)
         self._step += 1
         return loss
@@ -165,7 +165,7 @@ class LitHOSNeRF(_LitFlat):
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
         batch = dict(batch)
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M:1506
-        out = self.net.render(batch, randomized=True, is_train=True)
+        out = self.net.render(batch, randomized=True, is_train=True, static_cycle=True)
         loss, _ = stage3_losses(out, batch)
         self._step += 1
         return loss

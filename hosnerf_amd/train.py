@@ -79,15 +79,19 @@ class FusedAdam:
         self._hyper = None      # device [lr, 1-b1^t, 1/sqrt(1-b2^t)] for graph-captured steps
 
     def set_step_hyper(self, lr: Optional[float] = None):
-        """Advance the step counter and refresh the 12-byte device hyper-parameter block (call OUTSIDE a captured
-        graph, before each replay).  `step(dynamic=True)` then reads lr / bias corrections from device memory."""
+        """Advance the step counter and refresh the device hyper-parameter block (call OUTSIDE a captured graph, before
+        each replay): one row [lr * multiplier, 1-b1^t, 1/sqrt(1-b2^t)] per learning-rate range.  `step(dynamic=True)`
+        then reads lr / bias corrections from device memory."""
         self.step_count += 1
         lr = self.lr if lr is None else lr
-        vals = [lr, 1.0 - self.betas[0] ** self.step_count, 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)]
-        host = torch.tensor(vals, dtype=torch.float32).pin_memory()
+        ranges = self.lr_ranges or [(0, 0, 1.0)]
+        bc1, bc2 = 1.0 - self.betas[0] ** self.step_count, 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)
         if self._hyper is None:
-            self._hyper = torch.empty(3, device=self.module.flat_param.device)
-        self._hyper.copy_(host, non_blocking=True)
+            self._hyper = torch.empty(len(ranges), 3, device=self.module.flat_param.device)
+            self._hyper_host = torch.empty(len(ranges), 3, dtype=torch.float32).pin_memory()
+        for r, (_, _, mult) in enumerate(ranges):
+            self._hyper_host[r, 0], self._hyper_host[r, 1], self._hyper_host[r, 2] = lr * mult, bc1, bc2
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
 
     def zero_grad(self):
         self.module.store.zero_grad()
@@ -95,10 +99,12 @@ class FusedAdam:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def step(self, lr: Optional[float] = None, dynamic: bool = False):
+    def step(self, lr: Optional[float] = None, dynamic: bool = False, reduced: bool = False):
+        """`reduced=True`: the caller already all-reduced the flat gradient (e.g. overlapped with other work); only the
+        1/world scaling is applied here."""
         self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
         g = self.module.flat_grad
-        world = allreduce_flat_grad(self.module, self.group)
+        world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
         if dynamic:
             sumsq = None
             if self.max_grad_norm > 0:
@@ -106,10 +112,9 @@ class FusedAdam:
                 ops.sumsq(g, self._sumsq)
                 sumsq = self._sumsq
             p = self.module.flat_param
-            for off, n, mult in (self.lr_ranges or [(0, p.numel(), 1.0)]):
-                assert mult == 1.0, "per-range LR multipliers need one hyper block per range"
+            for r, (off, n, _) in enumerate(self.lr_ranges or [(0, p.numel(), 1.0)]):
                 ops.adam_step_dyn(p[off:off + n], g[off:off + n], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n],
-                                  self._hyper, self.betas[0], self.betas[1], self.eps, 1.0 / world, sumsq, self.max_grad_norm)
+                                  self._hyper[r], self.betas[0], self.betas[1], self.eps, 1.0 / world, sumsq, self.max_grad_norm)
             return
         self.step_count += 1
         sumsq = None
@@ -307,7 +312,7 @@ def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: O
     in-network composite, 0.2 MSE on the unpacked patches + 0.01 flow + 0.01 cycle, backward, flat Adam with the
     per-module learning rates.  `batch` comes from `prepare_patch_targets` + `batch_to_device`."""
     opt.zero_grad()
-    out = net(t_rand=t_rand, **batch)
+    out = net(t_rand=t_rand, static_cycle=True, **batch)
     loss, parts = stage2_losses(out, batch)
     loss.backward()
     opt.step(lr)
@@ -320,7 +325,7 @@ def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dic
     losses + backward + the two flat Adam updates."""
     opt_bkgd.zero_grad()
     opt_human.zero_grad()
-    out = hos.render(batch, randomized=True, is_train=True)
+    out = hos.render(batch, randomized=True, is_train=True, static_cycle=True)
     loss, parts = stage3_losses(out, batch)
     loss.backward()
     opt_bkgd.step(lr)

@@ -196,10 +196,12 @@ int hos_outer_accum(const float* x, int ldx, const float* dy, int lddy, float* g
  *   u_base [S]        torch.linspace grid of H:354 / H:363 (host supplies it; bit-exact u)
  *   jitter [B] or NULL, jitter_scale = max_jitter of H:360 (train); NULL -> u = u_base (eval)
  *   outputs: sdist [B,S+1], tdist [B,S+1], bin_idx [B,S] int32 (optional, may be NULL):
- *            index of the CDF knot left of every sample centre (bit-exact target of SURVEY B4). */
+ *            index of the CDF knot left of every sample centre (bit-exact target of SURVEY B4).
+ *   anneal = bias(train_frac, anneal_slope) of M:459-460; if train_frac_dev != NULL it is evaluated on the device from
+ *   *train_frac_dev instead (a step captured in a hipGraph anneals like an eager one; `anneal` is then ignored). */
 int hos_resample(const float* sdist_prev, const float* w_prev, int n_prev, int B, int S,
-                 float dilation, float anneal, float resample_padding,
-                 const float* u_base, const float* jitter, float jitter_scale,
+                 float dilation, float anneal, const float* train_frac_dev, float anneal_slope,
+                 float resample_padding, const float* u_base, const float* jitter, float jitter_scale,
                  float near_, float far_, float* sdist, float* tdist, int32_t* bin_idx,
                  hos_stream_t stream);
 
@@ -386,6 +388,19 @@ int hos_motion_basis_fwd(const float* dst_Rs, const float* dst_Ts, const float* 
 int hos_motion_basis_bwd(const float* g_R_bwd, const float* g_T_bwd, const float* g_R_fwd, const float* g_T_fwd,
                          const float* dst_Rs, const float* dst_Ts, const float* cnl_gtfms, int F, int K,
                          float* g_dst_Rs, float* g_dst_Ts, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Cycle-consistency set (N:505-536): the sample points with fg_likelihood_mask > 0.005.
+ * The reference selects them by boolean indexing (data-dependent shape = a host round trip per step);
+ * this is an order-preserving stream compaction into fixed-capacity buffers, the count stays on the device.
+ *   sel[j]   = j-th index i (ascending, = torch.nonzero order) with mask[i] > thr, -1 for j >= *count
+ *   out_a[j] = src_a[sel[j]], out_b[j] = src_b[sel[j]]  ([P,3] each, rows >= *count zero); any of sel / out_a /
+ *   out_b may be NULL.  workspace: hos_compact_workspace_ints() int32, zeroed once by the caller.  P <= 4 Mi. */
+long long hos_compact_workspace_ints(void);
+int hos_compact_rows(const float* mask, float thr, const float* src_a, const float* src_b, int64_t P, int32_t* count,
+                     int32_t* sel, float* out_a, float* out_b, int32_t* workspace, hos_stream_t stream);
+/* The gather's gradient: dst [P,3] = 0, then dst[sel[j]] = src[j] for j < *count. */
+int hos_scatter_rows(const float* src, const int32_t* sel, const int32_t* count, int64_t P, float* dst, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training losses of the human-object stages, values and gradients on the

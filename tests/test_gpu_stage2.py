@@ -85,36 +85,44 @@ def _stage2_item(B, seed, n_patches=2, size=32):
 
 def test_stage2_step_vs_oracle(dev, net2):
     """One stage-2 training step at a size the oracle finishes in seconds (24 rays in two 4x4 patches, partial masks):
-    loss terms and every parameter gradient against the oracle's op graph + torch autograd."""
+    loss terms against the fp32 oracle, and EVERY parameter gradient against the oracle evaluated in float64 -- the bound is
+    the fp32 oracle's own distance from float64 (parts of this graph are ill-conditioned in fp32 by construction, see
+    tests/test_gpu_conditioning.py), not a fixed constant."""
     from hosnerf_amd.train import batch_to_device, prepare_patch_targets, stage2_losses
     B = 24
     b = _stage2_item(B, seed=41, n_patches=2, size=4)
     assert int(b["patch_masks"].sum()) == B and not bool(b["patch_masks"].all())
-    sd = {k: v.clone().requires_grad_(True) for k, v in synth.human_state_dict(777, 2).items()}
-    out_o = oh.human_forward(sd, b, transitions_times=[0.4], stage=2)
-    tot_o, parts_o = ol.stage2_losses(out_o, b, 0.5)
-    tot_o.backward()
+    grads, outs = {}, {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        sd = {k: v.to(dt).requires_grad_(True) for k, v in synth.human_state_dict(777, 2).items()}
+        bb = {k: (v.to(dt) if isinstance(v, torch.Tensor) and v.is_floating_point() else v) for k, v in b.items()}
+        out_o = oh.human_forward(sd, bb, transitions_times=[0.4], stage=2)
+        tot_o, parts_o = ol.stage2_losses(out_o, bb, 0.5)
+        tot_o.backward()
+        grads[tag] = {n: (p_.grad.double() if p_.grad is not None else None) for n, p_ in sd.items()}
+        outs[tag] = (out_o["rgb"].detach().double(), float(tot_o), {k: float(v) for k, v in parts_o.items()})
 
     gb = batch_to_device(prepare_patch_targets(b), dev)
     net2.zero_grad()
-    out = net2(**gb)
+    out = net2(static_cycle=True, **gb)
     total, parts = stage2_losses(out, gb)
     total.backward()
-    assert maxerr(out["rgb"], out_o["rgb"]) < 1e-4
-    assert abs(float(total) - float(tot_o)) < 1e-5 * max(1.0, abs(float(tot_o)))
+    rgb64, tot64, parts64 = outs["f64"]
+    assert maxerr(out["rgb"].double(), rgb64) < 1e-4
+    assert abs(float(total) - tot64) < 1e-5 * max(1.0, abs(tot64))
     for k in ("mse", "flow", "cycle"):
-        assert abs(float(parts[k]) - float(parts_o[k])) < 2e-4 * max(1e-3, abs(float(parts_o[k]))), (k, float(parts[k]), float(parts_o[k]))
+        e_ref = abs(outs["f32"][2][k] - parts64[k])
+        assert abs(float(parts[k]) - parts64[k]) < 3.0 * e_ref + 1e-5 * max(1e-3, abs(parts64[k])), (k, float(parts[k]), parts64[k])
     params = dict(net2.named_parameters())
-    seen = 0
-    for n, p_o in sd.items():
-        go = p_o.grad
-        if go is None or float(go.abs().max()) == 0:
+    seen, report = 0, {}
+    for n, t in grads["f64"].items():
+        if t is None or float(t.abs().max()) == 0:
             continue
-        a, bb = params[n].grad.detach().double().cpu().reshape(-1), go.double().reshape(-1)
-        cos = float((a @ bb) / (a.norm() * bb.norm() + 1e-30))
-        rel = float((a - bb).norm() / (bb.norm() + 1e-30))
+        e_ref = float((grads["f32"][n] - t).norm() / (t.norm() + 1e-30))
+        e_hip = float((params[n].grad.detach().double().cpu().reshape(t.shape) - t).norm() / (t.norm() + 1e-30))
+        report[n] = (e_ref, e_hip)
         seen += 1
-        assert cos > 0.999 and rel < 3e-2, (n, cos, rel)
+        assert e_hip < 3.0 * e_ref + 1e-3, (n, e_ref, e_hip)
     assert seen >= 70
     net2.zero_grad()
 

@@ -1,5 +1,6 @@
 """The oracle is test infrastructure: nothing under hosnerf_amd/ may import or reference it, and the only
-other importers allowed are tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+other importers allowed are tests/, __graft_entry__.smoke() and bench.py's baseline leg (`cpu_baseline`: the oracle timed as
+the reference would run -- on the host cores, and as the same op graph on the GPU -- never as the product)."""
 import os
 import re
 
