@@ -1,0 +1,82 @@
+"""Multi-rank paths on the 1-GPU box:
+  * RCCL executes: a 1-rank `nccl` process group all-reduces the flat gradient and FusedAdam steps through it;
+  * bench.py's N > 1 code path -- stage-3, 4096 GLOBAL rays split over the ranks (strong scaling), fwd+bwd hipGraph replay +
+    eager all-reduce of both flat gradients + dynamic Adam, max-over-ranks timing -- runs as two processes sharing cuda:0
+    (HOS_BENCH_ONE_GPU=1: gloo carries the collectives, RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RCCL_SELF_TEST = r"""
+import os, sys, json, tempfile
+sys.path.insert(0, os.environ["HOS_ROOT"])
+import torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+from hosnerf_amd import synth
+from hosnerf_amd.mipnerf360 import MipNeRF360
+from hosnerf_amd.train import FusedAdam, allreduce_flat_grad, stage1_loss
+d = tempfile.mkdtemp()
+json.dump({"f0": {"time": 0.4}}, open(os.path.join(d, "transitions_times.json"), "w"))
+m = MipNeRF360(d, opaque_background=True)
+m.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+m = m.to(dev)
+opt = FusedAdam(m, lr=1e-3, max_grad_norm=0.001)
+b = {k: v.to(dev) for k, v in synth.stage1_batch(64, seed=1).items()}
+opt.zero_grad()
+rend, hist = m(b, 0.5, True, True, 0.1, 1e6)
+loss, _ = stage1_loss(rend[-1]["rgb"], b["target"], hist)
+loss.backward()
+g0 = m.flat_grad.clone()
+assert allreduce_flat_grad(m) == 1                      # world 1: no collective issued by the helper
+dist.all_reduce(m.flat_grad)                            # RCCL all-reduce of the 38 MB flat gradient, sum over 1 rank = identity
+torch.cuda.synchronize()
+assert torch.equal(m.flat_grad, g0)
+t = torch.arange(8, device=dev, dtype=torch.float32)
+dist.all_reduce(t); dist.barrier()
+out = torch.empty(8, device=dev); dist.all_gather_into_tensor(out, t)
+assert torch.equal(out, t)
+p0 = m.flat_param.clone()
+opt.step(1e-3)
+torch.cuda.synchronize()
+assert not torch.equal(p0, m.flat_param) and bool(torch.isfinite(m.flat_param).all())
+print("RCCL_OK", dist.get_backend())
+dist.destroy_process_group()
+"""
+
+
+def _env():
+    e = dict(os.environ)
+    e["HOS_ROOT"] = ROOT
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    e["MASTER_ADDR"] = "127.0.0.1"
+    return e
+
+
+def test_rccl_single_rank_allreduce_and_step():
+    r = subprocess.run([sys.executable, "-c", _RCCL_SELF_TEST], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_two_ranks_share_one_gpu_strong_scaling():
+    e = _env()
+    e["HOS_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--only-primary",
+           "--no-kernel-events"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_rays"] == 4096 and d["config"]["rays_per_gpu"] == 2048
+    assert d["value"] > 0 and d["steps"] == 3 and "stage-3" in d["config"]["workload"]
+    assert "eager all-reduce" in d["launch"], d["launch"]          # the step was captured; the collectives stay outside the graph
