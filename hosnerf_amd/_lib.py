@@ -29,13 +29,13 @@ PROTOTYPES = {
     "hos_error_string": [_I],
     "hos_set_gemm_mode": [_I],
     "hos_get_gemm_mode": [],
-    "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P],
+    "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P, _P],
     "hos_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hos_thin_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
     "hos_linear_wgrad_tr": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P],
-    "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
+    "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P],
     "hos_camera_rays": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "hos_rays_aabb": [_P, _P, _L, _P, _P, _P, _P, _P],
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],
@@ -60,13 +60,13 @@ PROTOTYPES = {
     "hos_distortion_bwd": [_P, _P, _I, _I, _F, _P, _P],
     "hos_head_grad": [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P, _I, _P],
     "hos_human_sample_warp": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
-    "hos_lbs_forward": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P],
-    "hos_embed_hannw": [_P, _P, _I, _P, _I, _L, _P, _I, _P, _I, _P],
+    "hos_lbs_forward": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P],
+    "hos_embed_hannw": [_P, _P, _I, _P, _I, _L, _P, _I, _P, _I, _P, _P],
     "hos_embed_fourier": [_P, _I, _P, _I, _L, _P, _I, _P, _I, _P],
     "hos_human_sample_warp_bwd": [_P, _P, _P, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P],
-    "hos_lbs_forward_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P],
-    "hos_embed_bwd": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _P, _I, _P],
-    "hos_slice_mask": [_P, _I, _I, _P, _I, _I, _L, _I, _P, _I, _P],
+    "hos_lbs_forward_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P],
+    "hos_embed_bwd": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _P, _I, _P, _P],
+    "hos_slice_mask": [_P, _I, _I, _P, _I, _I, _L, _I, _P, _I, _P, _P],
     "hos_rgbsigma_grad": [_P, _P, _L, _P, _I, _P],
     "hos_raw2outputs_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "hos_raw2outputs_bwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],
@@ -77,7 +77,8 @@ PROTOTYPES = {
     "hos_scatter_rows": [_P, _P, _P, _L, _P, _P],
     "hos_pose_refine_saved_floats": [],
     "hos_pose_refine_fwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "hos_pose_refine_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "hos_pose_refine_workspace_floats": [],
+    "hos_pose_refine_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P],
     "hos_motion_basis_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "hos_motion_basis_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "hos_train_losses_workspace_floats": [],
@@ -88,7 +89,8 @@ PROTOTYPES = {
     "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
 }
 _RESTYPES = {"hos_error_string": c_char_p, "hos_train_losses_workspace_floats": c_int64,
-             "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64}
+             "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
+             "hos_pose_refine_workspace_floats": c_int64}
 
 _lib = None
 

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
     const int tm_i = (bid / a.tiles_n) % a.tiles_m;
     const int split = bid / (a.tiles_n * a.tiles_m);
     const int i0 = tm_i * BM, j0 = tn_i * BN;
+    if (MODE == MODE_FWD && a.m_dev && i0 >= *a.m_dev) return;     // fixed-capacity buffer: rows past the device-side count are dead
     const int kt_begin = split * a.kt_per_split;
     const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;
@@ -253,7 +254,7 @@ extern "C" int hos_get_gemm_mode(void) { return g_gemm_mode; }
 extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
                               const float* W, int ldw, const float* bias, float* C, int ldc,
                               int M, int N, int epilogue, float* aux, int aux_col, float p0, float p1,
-                              hos_stream_t stream) {
+                              const int32_t* rows_dev, hos_stream_t stream) {
     if (!A0 || !W || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
     if (K1 > 0 && !A1) return HOS_E_ARG;
     if ((K0 % BK) || (K1 % BK)) return HOS_E_SHAPE;
@@ -271,6 +272,7 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
     a.M = M; a.N = N; a.Mload = M; a.Nload = N;
     a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.bias = bias; a.aux = aux; a.aux_col = aux_col; a.p0 = p0; a.p1 = p1; a.epi = epilogue;
+    a.m_dev = rows_dev;
     if (epilogue == HOS_EPI_RESIDUAL) { a.mask = aux; a.ldmask = aux_col; }   // residual [M, ld=aux_col]
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N <= 32) {

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NT3, 2) void gemm3_kernel(const GemmArgs a) {
     const int tm_i = (bid / a.tiles_n) % a.tiles_m;
     const int split = bid / (a.tiles_n * a.tiles_m);
     const int i0 = tm_i * BM, j0 = tn_i * BN;
+    if (MODE == MODE_FWD && a.m_dev && i0 >= *a.m_dev) return;     // fixed-capacity buffer: rows past the device-side count are dead
     const int kt_begin = split * a.kt_per_split;
     const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;

@@ -27,6 +27,7 @@ struct GemmArgs {
     int epi;
     int ablate;              // debug only (HOS_GEMM_ABLATE): 1 = skip global loads, 2 = skip convert/store, 4 = skip MFMA
     int pf_dist;             // split kernels: software L2 prefetch distance in K tiles (0 = off; HOS_GEMM_PF)
+    const int* m_dev;        // FWD only, optional: live row count in device memory; row tiles at or past it are skipped
 };
 
 

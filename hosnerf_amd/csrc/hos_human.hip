@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restric
                                                           const float* __restrict__ T, const float* __restrict__ vol_cl,
                                                           int V, int CL, const float* __restrict__ bbox_min,
                                                           const float* __restrict__ bbox_scale, long P, int K,
-                                                          float* __restrict__ x_def) {
+                                                          float* __restrict__ x_def, const int* __restrict__ p_dev) {
     __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6];
+    if (p_dev) P = min(P, (long)*p_dev);          // fixed-capacity buffer: only the first *p_dev rows are live
     for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
     for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
     if (threadIdx.x < 3) { sB[threadIdx.x] = bbox_min[threadIdx.x]; sB[3 + threadIdx.x] = bbox_scale[threadIdx.x]; }
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256) void lbs_forward_kernel(const float* __restric
 // Optionally also writes the features alone into PE [P, ldpe] (zero padded) for the skip concat.
 __global__ __launch_bounds__(256) void embed_hannw_kernel(const float* __restrict__ x, const float* __restrict__ band_w,
                                                           int F, const float* __restrict__ cond, int C, long P,
-                                                          float* __restrict__ E, int lde, float* __restrict__ PE, int ldpe) {
+                                                          float* __restrict__ E, int lde, float* __restrict__ PE, int ldpe,
+                                                          const int* __restrict__ p_dev) {
+    if (p_dev) P = min(P, (long)*p_dev);
     const int W = max(lde, PE ? C + ldpe : 0);     // iterate a virtual row wide enough for both destinations
     const long total = P * W;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -225,22 +228,22 @@ extern "C" int hos_human_sample_warp(const float* rays_o, const float* rays_d, c
 
 extern "C" int hos_lbs_forward(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
                                int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
-                               float* x_deform, hos_stream_t stream) {
+                               float* x_deform, const int32_t* rows_dev, hos_stream_t stream) {
     if (!cnl_pts || !R_fwd || !T_fwd || !vol_cl || !bbox_min || !bbox_scale || !x_deform || P <= 0) return HOS_E_ARG;
     if (K <= 0 || K > KMAX || CL < K || (CL & 3) || V < 2) return HOS_E_SHAPE;
     HOS_CHECK_ALIGN16(vol_cl);
     hipLaunchKernelGGL(lbs_forward_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), cnl_pts, R_fwd, T_fwd, vol_cl, V, CL, bbox_min, bbox_scale,
-                       (long)P, K, x_deform);
+                       (long)P, K, x_deform, rows_dev);
     return hos_launch_status();
 }
 
 extern "C" int hos_embed_hannw(const float* x, const float* band_w, int num_freqs, const float* cond, int cond_size,
-                               int64_t P, float* E, int lde, float* PE, int ldpe, hos_stream_t stream) {
+                               int64_t P, float* E, int lde, float* PE, int ldpe, const int32_t* rows_dev, hos_stream_t stream) {
     if (!x || !band_w || !E || P <= 0 || (cond_size > 0 && !cond)) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16 || lde < cond_size + 6 * num_freqs || (PE && ldpe < 6 * num_freqs)) return HOS_E_SHAPE;
     hipLaunchKernelGGL(embed_hannw_kernel, dim3(grid_for(P * (lde > cond_size + ldpe ? lde : cond_size + ldpe))), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, band_w, num_freqs, cond, cond_size, (long)P, E, lde, PE, ldpe);
+                       x, band_w, num_freqs, cond, cond_size, (long)P, E, lde, PE, ldpe, rows_dev);
     return hos_launch_status();
 }
 
@@ -521,8 +524,10 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
     const float* __restrict__ cnl, const float* __restrict__ R, const float* __restrict__ T,
     const float* __restrict__ vol_cl, int V, int CL, const float* __restrict__ bbox_min,
     const float* __restrict__ bbox_scale, long P, int K, const float* __restrict__ g_xdef,
-    float* __restrict__ g_cnl, float* __restrict__ g_vol_cl, float* __restrict__ g_R, float* __restrict__ g_T) {
+    float* __restrict__ g_cnl, float* __restrict__ g_vol_cl, float* __restrict__ g_R, float* __restrict__ g_T,
+    const int* __restrict__ p_dev) {
     __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6], sAcc[KMAX * 12];
+    if (p_dev) P = min(P, (long)*p_dev);
     for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
     for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
     for (int i = threadIdx.x; i < K * 12; i += blockDim.x) sAcc[i] = 0.f;
@@ -716,7 +721,8 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ band_w, int F,
                                                         int identity, const float* __restrict__ dA, int lda, int colA,
                                                         const float* __restrict__ dB, int ldb, int colB, long P,
-                                                        float* __restrict__ g_x, int accumulate) {
+                                                        float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev) {
+    if (p_dev) P = min(P, (long)*p_dev);
     const long total = P * 3;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
         const long p = it / 3;
@@ -744,7 +750,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // h-part out of the canonical skip-concat gradient, and (mask NULL) for plain strided slices.
 __global__ __launch_bounds__(256) void slice_mask_kernel(const float* __restrict__ src, int lds, int col0,
                                                          const float* __restrict__ msk, int ldm, int mcol0, long P,
-                                                         int width, float* __restrict__ out, int ldo) {
+                                                         int width, float* __restrict__ out, int ldo, const int* __restrict__ p_dev) {
+    if (p_dev) P = min(P, (long)*p_dev);
     const long total = P * width;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
         const long p = it / width;
@@ -802,32 +809,32 @@ extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const
 extern "C" int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
                                    int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
                                    const float* g_x_deform, float* g_cnl, float* g_vol_cl, float* g_R, float* g_T,
-                                   hos_stream_t stream) {
+                                   const int32_t* rows_dev, hos_stream_t stream) {
     if (!cnl_pts || !R_fwd || !T_fwd || !vol_cl || !bbox_min || !bbox_scale || !g_x_deform || !g_R || !g_T || P <= 0)
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || CL < K || (CL & 3) || V < 2) return HOS_E_SHAPE;
     const long lb_chunks = (P + 255) / 256;
     hipLaunchKernelGGL(lbs_forward_bwd_kernel, dim3((unsigned)(lb_chunks < persist_grid() ? lb_chunks : persist_grid())), dim3(256), 0,
                        static_cast<hipStream_t>(stream), cnl_pts, R_fwd, T_fwd, vol_cl, V, CL, bbox_min, bbox_scale,
-                       (long)P, K, g_x_deform, g_cnl, g_vol_cl, g_R, g_T);
+                       (long)P, K, g_x_deform, g_cnl, g_vol_cl, g_R, g_T, rows_dev);
     return hos_launch_status();
 }
 
 extern "C" int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
                              int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
-                             hos_stream_t stream) {
+                             const int32_t* rows_dev, hos_stream_t stream) {
     if (!x || !dA || !g_x || P <= 0) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16) return HOS_E_SHAPE;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(P * 3)), dim3(256), 0, static_cast<hipStream_t>(stream), x, band_w,
-                       num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate);
+                       num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev);
     return hos_launch_status();
 }
 
 extern "C" int hos_slice_mask(const float* src, int lds, int col0, const float* mask_src, int ldm, int mcol0, int64_t P,
-                              int width, float* out, int ldo, hos_stream_t stream) {
+                              int width, float* out, int ldo, const int32_t* rows_dev, hos_stream_t stream) {
     if (!src || !out || P <= 0 || width <= 0) return HOS_E_ARG;
     hipLaunchKernelGGL(slice_mask_kernel, dim3(grid_for(P * width)), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds,
-                       col0, mask_src, ldm, mcol0, (long)P, width, out, ldo);
+                       col0, mask_src, ldm, mcol0, (long)P, width, out, ldo, rows_dev);
     return hos_launch_status();
 }
 

@@ -34,6 +34,7 @@ struct MlpBwdArgs {
     int relu_mask;
     float* ws;                    // optional per-workgroup slabs [dW partial (if ws_dw) | db partial] (NULL: fp32 atomics)
     int ws_dw;
+    const int* m_dev;             // optional: live row count in device memory (fixed-capacity buffers); rows past it are skipped
 };
 
 constexpr int mb_rows(bool dg) { return dg ? 64 : 32; }   // rows per block iteration (wide WGRAD: 128 accumulator registers)
@@ -106,8 +107,9 @@ __device__ __forceinline__ void dgrad_store(const MlpBwdArgs& a, const f32x16& a
 // DG = true: the fused layer backward (N, K <= 128, W resident).  DG = false: WGRAD only for wider layers (N <= 256,
 // K <= 256; W does not fit next to the tiles), same staging and transposed reads, dX comes from the split GEMM.
 template <int NT, int KT, bool DG>
-__global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(const MlpBwdArgs a) {
+__global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(MlpBwdArgs a) {
     constexpr int N_ = NT * 32, K_ = KT * 32, R = mb_rows(DG);
+    if (a.m_dev) a.M = min(a.M, *a.m_dev);
     // row pitches in bytes: +32 B so that consecutive rows start 8 banks apart
     constexpr int PZ = N_ * 2 + 32, PX = K_ * 2 + 32, PW = K_ * 2 + 32;
     constexpr int W_PLANE = DG ? N_ * PW : 0, Z_PLANE = R * PZ, X_PLANE = R * PX;
@@ -410,12 +412,12 @@ int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
 // ws: optional scratch of ws_floats >= 256 * (128 * 128 + 128) floats for the per-workgroup dW partials (NULL: atomics).
 extern "C" int hos_linear_bwd_fused(const float* dZ, int lddz, const float* X, int ldx, const float* W, int ldw,
                                     float* dX, int lddx, float* dW, int lddw, float* db, int M, int N, int K,
-                                    int relu_mask, float* ws, int64_t ws_floats, hos_stream_t stream) {
+                                    int relu_mask, float* ws, int64_t ws_floats, const int32_t* rows_dev, hos_stream_t stream) {
     if (!dZ || !X || !W || !dW || M <= 0 || N <= 0 || K <= 0 || ws_floats < 0) return HOS_E_ARG;
     if (N > 128 || K > 128) return HOS_E_SHAPE;
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (K & 3) || (dX && (lddx & 3))) return HOS_E_ALIGN;
     if (((uintptr_t)dZ | (uintptr_t)X | (uintptr_t)W | (uintptr_t)ws) & 15u) return HOS_E_ALIGN;
-    MlpBwdArgs a{dZ, lddz, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, relu_mask, ws, 1};
+    MlpBwdArgs a{dZ, lddz, X, ldx, W, ldw, dX, lddx, dW, lddw, db, M, N, K, relu_mask, ws, 1, rows_dev};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nt = hos_cdiv(N, 32), kt = hos_cdiv(K, 32);
     if (nt <= 1 && kt <= 4) return launch_mb<1, 4, true>(a, (size_t)ws_floats, s);

@@ -32,15 +32,34 @@ struct PoseG {
 };
 // index: 0 W0 [256,75]  1 b0   2 W2 [256,256]  3 b2   4 W4  5 b4   6 WR0  7 bR0   8 WR2 [75,256]  9 bR2   10 WT0  11 bT0   12 WT2  13 bT2
 
-// out[n] = act(W[n,:] . in + b[n]),  W row-major [N,Kd]; one wave per row, lanes over k (coalesced), 16 waves stride the rows
+// out[n] = act(W[n,:] . in + b[n]),  W row-major [N,Kd]; one wave per row, lanes over k (coalesced), 16 waves stride the rows.
+// The prologue is pure latency: a wave issues the loads of ALL its rows before it reduces any of them.
+template <int KD>
 __device__ __forceinline__ void matvec(const float* __restrict__ W, const float* __restrict__ b, const float* in, float* out,
-                                       int N, int Kd, bool relu, int tid) {
+                                       int N, bool relu, int tid) {
+    constexpr int NW = PT / 64, RMAX = (PW + NW - 1) / NW, PER = (KD + 63) / 64;
     const int wave = tid >> 6, lane = tid & 63;
-    for (int n = wave; n < N; n += PT / 64) {
+    float w[RMAX][PER];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int n = wave + r * NW;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int k = lane + 64 * j;
+            w[r][j] = (n < N && k < KD) ? W[(size_t)n * KD + k] : 0.f;
+        }
+    }
+    float x[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) x[j] = (lane + 64 * j < KD) ? in[lane + 64 * j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+        const int n = wave + r * NW;
         float acc = 0.f;
-        for (int k = lane; k < Kd; k += 64) acc += W[(size_t)n * Kd + k] * in[k];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc += w[r][j] * x[j];
         acc = wave_sum(acc);
-        if (lane == 0) {
+        if (lane == 0 && n < N) {
             acc += b[n];
             out[n] = relu ? fmaxf(acc, 0.f) : acc;
         }
@@ -119,17 +138,17 @@ __global__ __launch_bounds__(PT) void pose_refine_fwd_kernel(const float* poseve
     const int f = blockIdx.x, tid = threadIdx.x;
     if (tid < PE) in[tid] = posevec[f * PE + tid];
     __syncthreads();
-    matvec(pw.w[0], pw.w[1], in, h1, PW, PE, true, tid);
+    matvec<PE>(pw.w[0], pw.w[1], in, h1, PW, true, tid);
     __syncthreads();
-    matvec(pw.w[2], pw.w[3], h1, h2, PW, PW, true, tid);
+    matvec<PW>(pw.w[2], pw.w[3], h1, h2, PW, true, tid);
     __syncthreads();
-    matvec(pw.w[4], pw.w[5], h2, h3, PW, PW, true, tid);
+    matvec<PW>(pw.w[4], pw.w[5], h2, h3, PW, true, tid);
     __syncthreads();
-    matvec(pw.w[6], pw.w[7], h3, yR, PW, PW, true, tid);
-    matvec(pw.w[10], pw.w[11], h3, yT, PW, PW, true, tid);
+    matvec<PW>(pw.w[6], pw.w[7], h3, yR, PW, true, tid);
+    matvec<PW>(pw.w[10], pw.w[11], h3, yT, PW, true, tid);
     __syncthreads();
-    matvec(pw.w[8], pw.w[9], yR, rv, PE, PW, false, tid);
-    matvec(pw.w[12], pw.w[13], yT, dT, PE, PW, false, tid);
+    matvec<PW>(pw.w[8], pw.w[9], yR, rv, PE, false, tid);
+    matvec<PW>(pw.w[12], pw.w[13], yT, dT, PE, false, tid);
     __syncthreads();
     float* sv = saved + (size_t)f * SAVED;
     if (tid < PW) {
@@ -158,13 +177,16 @@ __global__ __launch_bounds__(PT) void pose_refine_fwd_kernel(const float* poseve
     }
 }
 
-// out[k] = sum_n W[n,k] g[n] (W row-major [N,Kd]); 1024 threads = 4 row groups x 256 columns, partials through LDS
+// out[k] = sum_n W[n,k] g[n] (W row-major [N,Kd], Kd <= 256); 1024 threads = 4 row groups x 256 columns, partials through LDS.
+// Each thread's loads are independent (unrolled), so they are all in flight together.
 __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const float* g, float* out, float* part, int N, int Kd, int tid,
                                          bool accumulate) {
     const int grp = tid >> 8, k = tid & 255;
     float acc = 0.f;
-    if (k < Kd)
+    if (k < Kd) {
+#pragma unroll 16
         for (int n = grp; n < N; n += 4) acc += W[(size_t)n * Kd + k] * g[n];
+    }
     part[tid] = acc;
     __syncthreads();
     if (tid < Kd) {
@@ -174,65 +196,89 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
     __syncthreads();
 }
 
-// gW[n,k] += g[n] in[k];  gb[n] += g[n]
-__device__ __forceinline__ void outer_acc(float* gW, float* gb, const float* g, const float* in, int N, int Kd, int tid) {
-    for (int e = tid; e < N * Kd; e += PT) gW[e] += g[e / Kd] * in[e % Kd];
-    if (tid < N) gb[tid] += g[tid];
+// ------------------------------------------------------------------------------------------------ P2 backward
+// Pass 1 (one workgroup per frame): the chain of per-layer output gradients.  gvec[f] = {g_rv[80], g_dT[80], g_yR', g_yT', g_h3', g_h2',
+// g_h1'} (primes: already masked by the ReLU of that layer's output), 5 x 256 + 160 floats.
+constexpr int GVEC = 5 * PW + 160;
+
+__global__ __launch_bounds__(PT) void pose_refine_bwd_vec_kernel(const float* gRs_out, const float* gTs_out, const float* Rs,
+                                                                const float* saved, PoseW pw, int K, float* gvec) {
+    __shared__ float h1[PW], h2[PW], h3[PW], yR[PW], yT[PW], g_rv[80], g_dT[80];
+    __shared__ float gA[PW], gB[PW], gC[PW], part[PT];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const float* sv = saved + (size_t)f * SAVED;
+    float* gv = gvec + (size_t)f * GVEC;
+    if (tid < PW) {
+        h1[tid] = sv[tid]; h2[tid] = sv[PW + tid]; h3[tid] = sv[2 * PW + tid]; yR[tid] = sv[3 * PW + tid]; yT[tid] = sv[4 * PW + tid];
+    }
+    if (tid < 80) { g_rv[tid] = 0.f; g_dT[tid] = 0.f; }
+    __syncthreads();
+    if (tid >= 1 && tid < K) {
+        const float* R = Rs + ((size_t)f * K + tid) * 9;
+        const float* gRo = gRs_out + ((size_t)f * K + tid) * 9;
+        float gdR[9], gr[3];
+        mtm3(R, gRo, gdR);                                   // R_out = R dR  ->  g_dR = R^T g_Rout
+        rodrigues_bwd(sv + 5 * PW + 3 * (tid - 1), gdR, gr);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            g_rv[3 * (tid - 1) + e] = gr[e];
+            g_dT[3 * (tid - 1) + e] = gTs_out[((size_t)f * K + tid) * 3 + e];
+        }
+    }
+    __syncthreads();
+    if (tid < 80) { gv[tid] = g_rv[tid]; gv[80 + tid] = g_dT[tid]; }
+    matvec_t(pw.w[8], g_rv, gA, part, PE, PW, tid, false);          // g_yR
+    matvec_t(pw.w[12], g_dT, gB, part, PE, PW, tid, false);         // g_yT
+    if (tid < PW) {
+        gA[tid] = yR[tid] > 0.f ? gA[tid] : 0.f;
+        gB[tid] = yT[tid] > 0.f ? gB[tid] : 0.f;
+        gv[160 + tid] = gA[tid];
+        gv[160 + PW + tid] = gB[tid];
+    }
+    __syncthreads();
+    matvec_t(pw.w[6], gA, gC, part, PW, PW, tid, false);
+    matvec_t(pw.w[10], gB, gC, part, PW, PW, tid, true);            // g_h3
+    if (tid < PW) { gC[tid] = h3[tid] > 0.f ? gC[tid] : 0.f; gv[160 + 2 * PW + tid] = gC[tid]; }
+    __syncthreads();
+    matvec_t(pw.w[4], gC, gA, part, PW, PW, tid, false);            // g_h2
+    if (tid < PW) { gA[tid] = h2[tid] > 0.f ? gA[tid] : 0.f; gv[160 + 3 * PW + tid] = gA[tid]; }
+    __syncthreads();
+    matvec_t(pw.w[2], gA, gB, part, PW, PW, tid, false);            // g_h1
+    if (tid < PW) gv[160 + 4 * PW + tid] = h1[tid] > 0.f ? gB[tid] : 0.f;
 }
 
-// ------------------------------------------------------------------------------------------------ P2 backward
-__global__ __launch_bounds__(PT) void pose_refine_bwd_kernel(const float* gRs_out, const float* gTs_out, const float* posevec,
-                                                            const float* Rs, const float* saved, PoseW pw, PoseG pg, int F, int K) {
-    __shared__ float in[PW], h1[PW], h2[PW], h3[PW], yR[PW], yT[PW], g_rv[80], g_dT[80];
-    __shared__ float gA[PW], gB[PW], gC[PW], part[PT];
-    const int tid = threadIdx.x;
-    for (int f = 0; f < F; ++f) {
-        const float* sv = saved + (size_t)f * SAVED;
-        __syncthreads();
-        if (tid < PW) {
-            h1[tid] = sv[tid]; h2[tid] = sv[PW + tid]; h3[tid] = sv[2 * PW + tid]; yR[tid] = sv[3 * PW + tid]; yT[tid] = sv[4 * PW + tid];
-            in[tid] = tid < PE ? posevec[f * PE + tid] : 0.f;
+// Pass 2 (grid over all weight elements): gW[n,k] += sum_f g_f[n] in_f[k], gb[n] += sum_f g_f[n] for the seven layers.
+struct OuterJob { int N, Kd, g_off, in_off, in_is_pose; };     // offsets into gvec / saved rows
+__constant__ OuterJob c_jobs[7] = {
+    {PW, PE, 160 + 4 * PW, 0, 1},          // block_mlps.0      g_h1' (x) posevec
+    {PW, PW, 160 + 3 * PW, 0, 0},          // block_mlps.2      g_h2' (x) h1
+    {PW, PW, 160 + 2 * PW, PW, 0},         // block_mlps.4      g_h3' (x) h2
+    {PW, PW, 160, 2 * PW, 0},              // block_mlps_dstR.0 g_yR' (x) h3
+    {PE, PW, 0, 3 * PW, 0},                // block_mlps_dstR.2 g_rv  (x) yR
+    {PW, PW, 160 + PW, 2 * PW, 0},         // block_mlps_dstT.0 g_yT' (x) h3
+    {PE, PW, 80, 4 * PW, 0},               // block_mlps_dstT.2 g_dT  (x) yT
+};
+
+__global__ __launch_bounds__(256) void pose_refine_bwd_outer_kernel(const float* gvec, const float* saved, const float* posevec, PoseG pg,
+                                                                   int F) {
+    const int job = blockIdx.y;
+    const OuterJob j = c_jobs[job];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float* gW = pg.g[2 * job];
+    float* gb = pg.g[2 * job + 1];
+    if (e < j.N * j.Kd) {
+        const int n = e / j.Kd, k = e % j.Kd;
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) {
+            const float x = j.in_is_pose ? posevec[f * PE + k] : saved[(size_t)f * SAVED + j.in_off + k];
+            acc += gvec[(size_t)f * GVEC + j.g_off + n] * x;
         }
-        if (tid >= 1 && tid < K) {
-            const float* R = Rs + ((size_t)f * K + tid) * 9;
-            const float* gRo = gRs_out + ((size_t)f * K + tid) * 9;
-            float gdR[9], gr[3];
-            mtm3(R, gRo, gdR);                                   // R_out = R dR  ->  g_dR = R^T g_Rout
-            rodrigues_bwd(sv + 5 * PW + 3 * (tid - 1), gdR, gr);
-#pragma unroll
-            for (int e = 0; e < 3; ++e) {
-                g_rv[3 * (tid - 1) + e] = gr[e];
-                g_dT[3 * (tid - 1) + e] = gTs_out[((size_t)f * K + tid) * 3 + e];
-            }
-        }
-        __syncthreads();
-        // heads, last layers [75,256]
-        matvec_t(pw.w[8], g_rv, gA, part, PE, PW, tid, false);          // g_yR
-        matvec_t(pw.w[12], g_dT, gB, part, PE, PW, tid, false);         // g_yT
-        outer_acc(pg.g[8], pg.g[9], g_rv, yR, PE, PW, tid);
-        outer_acc(pg.g[12], pg.g[13], g_dT, yT, PE, PW, tid);
-        if (tid < PW) {
-            gA[tid] = yR[tid] > 0.f ? gA[tid] : 0.f;
-            gB[tid] = yT[tid] > 0.f ? gB[tid] : 0.f;
-        }
-        __syncthreads();
-        // heads, first layers [256,256] on h3
-        matvec_t(pw.w[6], gA, gC, part, PW, PW, tid, false);
-        matvec_t(pw.w[10], gB, gC, part, PW, PW, tid, true);            // g_h3
-        outer_acc(pg.g[6], pg.g[7], gA, h3, PW, PW, tid);
-        outer_acc(pg.g[10], pg.g[11], gB, h3, PW, PW, tid);
-        if (tid < PW) gC[tid] = h3[tid] > 0.f ? gC[tid] : 0.f;
-        __syncthreads();
-        // trunk
-        matvec_t(pw.w[4], gC, gA, part, PW, PW, tid, false);            // g_h2
-        outer_acc(pg.g[4], pg.g[5], gC, h2, PW, PW, tid);
-        if (tid < PW) gA[tid] = h2[tid] > 0.f ? gA[tid] : 0.f;
-        __syncthreads();
-        matvec_t(pw.w[2], gA, gB, part, PW, PW, tid, false);            // g_h1
-        outer_acc(pg.g[2], pg.g[3], gA, h1, PW, PW, tid);
-        if (tid < PW) gB[tid] = h1[tid] > 0.f ? gB[tid] : 0.f;
-        __syncthreads();
-        outer_acc(pg.g[0], pg.g[1], gB, in, PW, PE, tid);
+        gW[e] += acc;
+    }
+    if (e < j.N) {
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) acc += gvec[(size_t)f * GVEC + j.g_off + e];
+        gb[e] += acc;
     }
 }
 
@@ -355,6 +401,7 @@ __global__ __launch_bounds__(64) void motion_basis_bwd_kernel(const float* gR_b,
 }  // namespace
 
 extern "C" long long hos_pose_refine_saved_floats(void) { return SAVED; }
+extern "C" long long hos_pose_refine_workspace_floats(void) { return GVEC; }      // per frame
 
 extern "C" int hos_pose_refine_fwd(const float* posevec, const float* Rs, const float* Ts, const float* const* weights14,
                                    int F, int K, int width, float* Rs_out, float* Ts_out, float* saved, hos_stream_t stream) {
@@ -372,8 +419,8 @@ extern "C" int hos_pose_refine_fwd(const float* posevec, const float* Rs, const 
 
 extern "C" int hos_pose_refine_bwd(const float* g_Rs_out, const float* g_Ts_out, const float* posevec, const float* Rs,
                                    const float* saved, const float* const* weights14, float* const* grads14, int F, int K, int width,
-                                   hos_stream_t stream) {
-    if (!g_Rs_out || !g_Ts_out || !posevec || !Rs || !saved || !weights14 || !grads14 || F <= 0) return HOS_E_ARG;
+                                   float* workspace, hos_stream_t stream) {
+    if (!g_Rs_out || !g_Ts_out || !posevec || !Rs || !saved || !weights14 || !grads14 || !workspace || F <= 0) return HOS_E_ARG;
     if (K != KJ || width != PW) return HOS_E_SHAPE;
     PoseW pw;
     PoseG pg;
@@ -382,8 +429,9 @@ extern "C" int hos_pose_refine_bwd(const float* g_Rs_out, const float* g_Ts_out,
         pw.w[i] = weights14[i];
         pg.g[i] = grads14[i];
     }
-    hipLaunchKernelGGL(pose_refine_bwd_kernel, dim3(1), dim3(PT), 0, static_cast<hipStream_t>(stream), g_Rs_out, g_Ts_out, posevec, Rs,
-                       saved, pw, pg, F, K);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(pose_refine_bwd_vec_kernel, dim3(F), dim3(PT), 0, s, g_Rs_out, g_Ts_out, Rs, saved, pw, K, workspace);
+    hipLaunchKernelGGL(pose_refine_bwd_outer_kernel, dim3(PW * PW / 256, 7), dim3(256), 0, s, workspace, saved, posevec, pg, F);
     return hos_launch_status();
 }
 

@@ -306,13 +306,14 @@ class Network(FlatModule):
         return self._band_cache[1]
 
     # ------------------------------------------------------------------ HIP MLP chains (forward)
-    def _nonrigid_fwd(self, specs: List[_LayerSpec], x: torch.Tensor, cond: torch.Tensor, band_w: torch.Tensor, save: bool):
-        """mlp_offset.py:54-70: xyz + MLP([cond | hann(x)]) with the hann features re-concatenated before Linear #4."""
+    def _nonrigid_fwd(self, specs: List[_LayerSpec], x: torch.Tensor, cond: torch.Tensor, band_w: torch.Tensor, save: bool, rows_dev=None):
+        """mlp_offset.py:54-70: xyz + MLP([cond | hann(x)]) with the hann features re-concatenated before Linear #4.
+        `rows_dev` (int32 [1] on the device): only that many leading rows are live (fixed-capacity cycle set)."""
         Pn = x.shape[0]
         dev = x.device
         E = torch.empty(Pn, NR_LDE, device=dev)
         PE = torch.empty(Pn, NR_LDPE, device=dev)
-        ops.embed_hannw(x, band_w, cond.reshape(-1), E, PE)
+        ops.embed_hannw(x, band_w, cond.reshape(-1), E, PE, rows_dev=rows_dev)
         acts = []
         h = E
         for i in range(6):
@@ -320,14 +321,14 @@ class Network(FlatModule):
             Wt, bt = self._w(L)
             out = torch.empty(Pn, 128, device=dev)
             if i == 4:
-                ops.linear_fwd(h, 128, Wt, bt, 128, out, ops.EPI_RELU, A1=PE, K1=NR_LDPE)
+                ops.linear_fwd(h, 128, Wt, bt, 128, out, ops.EPI_RELU, A1=PE, K1=NR_LDPE, rows_dev=rows_dev)
             else:
-                ops.linear_fwd(h, L.Kpad, Wt, bt, 128, out, ops.EPI_RELU)
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 128, out, ops.EPI_RELU, rows_dev=rows_dev)
             acts.append(out)
             h = out
         Wt, bt = self._w(specs[6])
         xyz = torch.empty(Pn, 3, device=dev)
-        ops.linear_fwd(h, 128, Wt, bt, 3, xyz, ops.EPI_RESIDUAL, aux=x)
+        ops.linear_fwd(h, 128, Wt, bt, 3, xyz, ops.EPI_RESIDUAL, aux=x, rows_dev=rows_dev)
         return xyz, ((E, PE, acts) if save else None)
 
     def _canonical_fwd(self, cnl: torch.Tensor, state: int, save: bool):
@@ -359,7 +360,7 @@ class Network(FlatModule):
         return raw, ((E, acts) if save else None)
 
     # ------------------------------------------------------------------ HIP MLP chains (backward)
-    def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor):
+    def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor, rows_dev=None):
         """Parameter gradients into the flat buffer; returns d loss / d x  ([P,3]).  Every layer is 128 wide, so each
         layer's (wgrad, dgrad) pair is one fused pass over (dZ, X) (ops.linear_bwd_fused); HOS_FUSED_BWD=0 selects the
         two-GEMM form."""
@@ -371,14 +372,14 @@ class Network(FlatModule):
             Wt, _ = self._w(spec)
             gW, gb = self._w(spec, grad=True)
             if fused:
-                ops.linear_bwd_fused(dz, X, Wt, gW, gb if bias else None, N, K, out, relu_mask, w_col0=w_col0)
+                ops.linear_bwd_fused(dz, X, Wt, gW, gb if bias else None, N, K, out, relu_mask, w_col0=w_col0, rows_dev=rows_dev)
             else:
                 ops.linear_wgrad(dz, X, gW, gb if bias else None, N, K, w_col0=w_col0)
                 ops.linear_dgrad(dz, Wt, dz.shape[1], K, out, mask_src=X if relu_mask else None, w_col0=w_col0)
             return out
 
         dz6 = torch.zeros(Pn, 32, device=dev)
-        ops.slice_mask(g_xyz, 0, None, 0, 3, dz6)
+        ops.slice_mask(g_xyz, 0, None, 0, 3, dz6, rows_dev=rows_dev)
         dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
         dPE = dE = None
         for i in range(5, -1, -1):
@@ -390,7 +391,7 @@ class Network(FlatModule):
             else:
                 dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
         g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
-        ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True)
+        ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True, rows_dev=rows_dev)
         return g_x
 
     def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):
@@ -509,7 +510,7 @@ class Network(FlatModule):
             if grad:
                 z, pts, x_skel, mask = ops.human_sample_warp_ad(vol, R_b, T_b, rays_o[sl], rays_d[sl], near[sl].contiguous(),
                                                                 far[sl].contiguous(), N, bmin, bscale, tr, K)
-                cnl = _NonRigidFn.apply(self._token, self, "nr", x_skel, cond, band_w)
+                cnl = _NonRigidFn.apply(self._token, self, "nr", x_skel, cond, band_w, None)
                 raw = _CanonicalFn.apply(self._token, self, cnl, state)
             else:
                 z, pts, x_skel, mask = ops.human_sample_warp(rays_o[sl], rays_d[sl], near[sl].contiguous(), far[sl].contiguous(),
@@ -527,12 +528,12 @@ class Network(FlatModule):
                 ret = {"human_rgb": raw[:, :3].reshape(b, N, 3), "human_density": raw[:, 3].reshape(b, N),
                        "human_rgbsigma": raw.view(b, N, 4), "newsmpl_pts": pts, "pts_mask": mask.view(b, N)}
 
-            def fwd_branch(c_pts, Rf_, Tf_, cond_):
+            def fwd_branch(c_pts, Rf_, Tf_, cond_, rows_dev=None):
                 if grad:
-                    d_ = ops.lbs_forward_ad(c_pts, vol_cl, Rf_, Tf_, bmin, bscale, K)
-                    return _NonRigidFn.apply(self._token, self, "nrf", d_, cond_, band_w)
-                d_ = ops.lbs_forward(c_pts, Rf_, Tf_, vol_cl, bmin, bscale, K)
-                return self._nonrigid_fwd(self._nrf, d_, cond_, band_w, save=False)[0]
+                    d_ = ops.lbs_forward_ad(c_pts, vol_cl, Rf_, Tf_, bmin, bscale, K, rows_dev=rows_dev)
+                    return _NonRigidFn.apply(self._token, self, "nrf", d_, cond_, band_w, rows_dev)
+                d_ = ops.lbs_forward(c_pts, Rf_, Tf_, vol_cl, bmin, bscale, K, rows_dev=rows_dev)
+                return self._nonrigid_fwd(self._nrf, d_, cond_, band_w, save=False, rows_dev=rows_dev)[0]
 
             if flow:                                                               # N:474-502
                 ret["deform_pts_prev_final"] = fwd_branch(cnl, R_fp, T_fp, cond_prev).view(b, N, 3)
@@ -543,7 +544,9 @@ class Network(FlatModule):
                 if B > chunk:
                     raise ValueError("static_cycle needs the whole ray batch in one chunk (cfg.chunk >= number of rays)")
                 sel_cnl, observe, _, count = ops.compact_rows(mask, 0.005, cnl, pts)
-                ret["deform_pts_final"] = fwd_branch(sel_cnl, R_f, T_f, cond)
+                # the kernels stop at `count` rows (the two-GEMM debug path of the backward, HOS_FUSED_BWD=0, has no row
+                # limit and runs over the zero-padded capacity instead)
+                ret["deform_pts_final"] = fwd_branch(sel_cnl, R_f, T_f, cond, rows_dev=count if ops.FUSED_THIN_BWD else None)
                 ret["observe_pts"] = observe
                 ret["cycle_count"] = count
             elif with_cycle:
@@ -569,18 +572,18 @@ class _NonRigidFn(torch.autograd.Function):
     """xyz = x + NonRigidMLP([cond | hann(x)]); parameter gradients go straight into the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, token, net: Network, which: str, x, cond, band_w):
+    def forward(ctx, token, net: Network, which: str, x, cond, band_w, rows_dev=None):
         specs = net._nr if which == "nr" else net._nrf
         x = x.contiguous()
-        xyz, saved = net._nonrigid_fwd(specs, x, cond, band_w, save=True)
-        ctx.net, ctx.specs, ctx.saved, ctx.x, ctx.band_w = net, specs, saved, x, band_w
+        xyz, saved = net._nonrigid_fwd(specs, x, cond, band_w, save=True, rows_dev=rows_dev)
+        ctx.net, ctx.specs, ctx.saved, ctx.x, ctx.band_w, ctx.rows_dev = net, specs, saved, x, band_w, rows_dev
         return xyz
 
     @staticmethod
     def backward(ctx, g):
-        g_x = ctx.net._nonrigid_bwd(ctx.specs, ctx.saved, ctx.x, ctx.band_w, g.contiguous())
+        g_x = ctx.net._nonrigid_bwd(ctx.specs, ctx.saved, ctx.x, ctx.band_w, g.contiguous(), rows_dev=ctx.rows_dev)
         ctx.saved = None
-        return None, None, None, g_x, None, None
+        return None, None, None, g_x, None, None, None
 
 
 class _CanonicalFn(torch.autograd.Function):

@@ -92,13 +92,13 @@ def get_gemm_mode() -> int:
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
                out: Optional[torch.Tensor], epilogue: int = EPI_NONE, A1: Optional[torch.Tensor] = None,
                K1: int = 0, aux: Optional[torch.Tensor] = None, aux_col: int = -1, p0: float = 0.0,
-               ldc: Optional[int] = None, M: Optional[int] = None, out_col0: int = 0):
+               ldc: Optional[int] = None, M: Optional[int] = None, out_col0: int = 0, rows_dev: Optional[torch.Tensor] = None):
     """out[M, out_col0:out_col0+N] = epi([A0[:, :K0] | A1[:, :K1]] @ W[:N, :K0+K1]^T + bias).  W is a [rows, ldw] buffer.
     For EPI_RESIDUAL `aux` is the residual matrix [M, >=N] (its row stride is passed as aux_col)."""
     M = A0.shape[0] if M is None else M
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
-    if (THIN_GEMM and A1 is None and 128 < N <= 256 and K0 <= 256 and K0 % 4 == 0 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
+    if (THIN_GEMM and rows_dev is None and A1 is None and 128 < N <= 256 and K0 <= 256 and K0 % 4 == 0 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
             and ldc is None and out is not None and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
         # many rows through a thin layer: persistent kernel with the weight in registers (hos_thin.hip)
         _timed(f"thin_fwd[M={M},N={N},K={K0}]", 2.0 * M * N * K0, lambda: call(
@@ -108,7 +108,7 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
     _timed(f"gemm_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linear_fwd", ptr(A0), A0.stride(0), K0, ptr(A1), 0 if A1 is None else A1.stride(0), K1,
         ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, (0 if out is None else out.stride(0)) if ldc is None else ldc,
-        M, N, epilogue, ptr(aux), aux_col, float(p0), 0.0))
+        M, N, epilogue, ptr(aux), aux_col, float(p0), 0.0, ptr(rows_dev, torch.int32)))
     return out
 
 
@@ -152,7 +152,7 @@ def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Option
 
 
 def linear_bwd_fused(dY: torch.Tensor, X: torch.Tensor, W: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor], N: int,
-                     K: int, out: Optional[torch.Tensor], relu_mask: bool, w_col0: int = 0):
+                     K: int, out: Optional[torch.Tensor], relu_mask: bool, w_col0: int = 0, rows_dev: Optional[torch.Tensor] = None):
     """One thin layer's whole backward in one pass over (dY, X) (hos_mlpbwd.hip; N, K <= 128):
     out[M,:K] = (dY[:, :N] @ W[:N, w_col0:w_col0+K]) * (X > 0 if relu_mask);  dW[:N, w_col0:..+K] += dY^T @ X;  db += colsum(dY)."""
     M = dY.shape[0]
@@ -160,7 +160,7 @@ def linear_bwd_fused(dY: torch.Tensor, X: torch.Tensor, W: torch.Tensor, dW: tor
     _timed(f"mlp_bwd_fused[M={M},N={N},K={K}]", 4.0 * M * N * K, lambda: call(
         "hos_linear_bwd_fused", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(W) + 4 * w_col0, W.stride(0),
         ptr(out), 0 if out is None else out.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, int(relu_mask),
-        ptr(ws), ws.numel()))
+        ptr(ws), ws.numel(), ptr(rows_dev, torch.int32)))
     return out
 
 
@@ -477,18 +477,19 @@ def human_sample_warp(rays_o, rays_d, near, far, N: int, R, T, vol, bbox_min, bb
     return z, pts, x_skel, mask
 
 
-def lbs_forward(cnl_pts, R_f, T_f, vol_cl, bbox_min, bbox_scale, K: int = 26):
+def lbs_forward(cnl_pts, R_f, T_f, vol_cl, bbox_min, bbox_scale, K: int = 26, rows_dev=None):
     P = cnl_pts.shape[0]
     out = torch.empty(P, 3, device=cnl_pts.device)
     V, CL = vol_cl.shape[0], vol_cl.shape[-1]
-    call("hos_lbs_forward", ptr(cnl_pts), ptr(R_f), ptr(T_f), ptr(vol_cl), V, CL, ptr(bbox_min), ptr(bbox_scale), P, K, ptr(out))
+    call("hos_lbs_forward", ptr(cnl_pts), ptr(R_f), ptr(T_f), ptr(vol_cl), V, CL, ptr(bbox_min), ptr(bbox_scale), P, K, ptr(out),
+         ptr(rows_dev, torch.int32))
     return out
 
 
-def embed_hannw(x, band_w, cond, E, PE=None):
+def embed_hannw(x, band_w, cond, E, PE=None, rows_dev=None):
     P = x.shape[0]
     call("hos_embed_hannw", ptr(x), ptr(band_w), band_w.numel(), ptr(cond), 0 if cond is None else cond.numel(), P,
-         ptr(E), E.stride(0), ptr(PE), 0 if PE is None else PE.stride(0))
+         ptr(E), E.stride(0), ptr(PE), 0 if PE is None else PE.stride(0), ptr(rows_dev, torch.int32))
 
 
 def embed_fourier(x, num_freqs, state, E, E2=None):
@@ -617,8 +618,9 @@ class _PoseRefine(torch.autograd.Function):
         F_, K, width = ctx.dims
         gR = torch.zeros_like(Rs) if gR is None else gR.contiguous()
         gT = torch.zeros(F_, K, 3, device=Rs.device) if gT is None else gT.contiguous()
+        ws = torch.empty(F_, int(_lib.load().hos_pose_refine_workspace_floats()), device=Rs.device)
         call("hos_pose_refine_bwd", ptr(gR), ptr(gT), ptr(posevec), ptr(Rs), ptr(saved), _ptr_array(ctx.weights), _ptr_array(ctx.grads),
-             F_, K, width)
+             F_, K, width, ptr(ws))
         return None, None, None, None, None, None
 
 
@@ -796,15 +798,15 @@ def human_sample_warp_ad(vol, R, T, rays_o, rays_d, near, far, N, bmin, bscale, 
 
 class _LbsForward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cnl, vol_cl, R_f, T_f, bmin, bscale, K):
-        out = lbs_forward(cnl, R_f, T_f, vol_cl, bmin, bscale, K)
-        ctx.save_for_backward(cnl, vol_cl, R_f, T_f, bmin, bscale)
+    def forward(ctx, cnl, vol_cl, R_f, T_f, bmin, bscale, K, rows_dev):
+        out = lbs_forward(cnl, R_f, T_f, vol_cl, bmin, bscale, K, rows_dev)
+        ctx.save_for_backward(cnl, vol_cl, R_f, T_f, bmin, bscale, rows_dev)
         ctx.K = K
         return out
 
     @staticmethod
     def backward(ctx, g):
-        cnl, vol_cl, R_f, T_f, bmin, bscale = ctx.saved_tensors
+        cnl, vol_cl, R_f, T_f, bmin, bscale, rows_dev = ctx.saved_tensors
         P = cnl.shape[0]
         g_cnl = torch.empty_like(cnl)
         g_vol = torch.zeros_like(vol_cl)
@@ -812,22 +814,22 @@ class _LbsForward(torch.autograd.Function):
         g_T = torch.zeros_like(T_f)
         g = g.contiguous()
         call("hos_lbs_forward_bwd", ptr(cnl), ptr(R_f), ptr(T_f), ptr(vol_cl), vol_cl.shape[0], vol_cl.shape[-1], ptr(bmin),
-             ptr(bscale), P, ctx.K, ptr(g), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T))
-        return g_cnl, g_vol, g_R, g_T, None, None, None
+             ptr(bscale), P, ctx.K, ptr(g), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(rows_dev, torch.int32))
+        return g_cnl, g_vol, g_R, g_T, None, None, None, None
 
 
-def lbs_forward_ad(cnl, vol_cl, R_f, T_f, bmin, bscale, K: int = 26):
-    return _LbsForward.apply(cnl.contiguous(), vol_cl.contiguous(), R_f.contiguous(), T_f.contiguous(), bmin, bscale, K)
+def lbs_forward_ad(cnl, vol_cl, R_f, T_f, bmin, bscale, K: int = 26, rows_dev=None):
+    return _LbsForward.apply(cnl.contiguous(), vol_cl.contiguous(), R_f.contiguous(), T_f.contiguous(), bmin, bscale, K, rows_dev)
 
 
-def embed_bwd(x, band_w, num_freqs, identity, dA, colA, dB, colB, g_x, accumulate):
+def embed_bwd(x, band_w, num_freqs, identity, dA, colA, dB, colB, g_x, accumulate, rows_dev=None):
     call("hos_embed_bwd", ptr(x), ptr(band_w), num_freqs, int(identity), ptr(dA), dA.stride(0), colA,
-         ptr(dB), 0 if dB is None else dB.stride(0), colB, x.shape[0], ptr(g_x), int(accumulate))
+         ptr(dB), 0 if dB is None else dB.stride(0), colB, x.shape[0], ptr(g_x), int(accumulate), ptr(rows_dev, torch.int32))
 
 
-def slice_mask(src, col0, mask_src, mcol0, width, out):
+def slice_mask(src, col0, mask_src, mcol0, width, out, rows_dev=None):
     call("hos_slice_mask", ptr(src), src.stride(0), col0, ptr(mask_src), 0 if mask_src is None else mask_src.stride(0), mcol0,
-         src.shape[0], width, ptr(out), out.stride(0))
+         src.shape[0], width, ptr(out), out.stride(0), ptr(rows_dev, torch.int32))
 
 
 def rgbsigma_grad(g, y, dz):

@@ -65,12 +65,16 @@ int hos_get_gemm_mode(void);
 #define HOS_EPI_SIGMOID_RELU4 5 /* N==4: cols 0..2 sigmoid, col 3 relu (N:539-540)             */
 #define HOS_EPI_RESIDUAL 6   /* C = acc + bias + aux[m*aux_col + n]  (xyz + offset, mlp_offset.py:66; aux_col = ld of aux) */
 
-/* C[M,N] = epi( [A0 | A1][M, K0+K1] @ W[N, K0+K1]^T + bias[N] ).
+/* `rows_dev` (several entry points below; may be NULL): the number of LIVE rows of a fixed-capacity buffer, read from device
+ * memory by the kernel -- rows (whole row tiles for the GEMMs) at or past it are skipped.  Used for the cycle-consistency set
+ * of the human branch, whose size is data dependent (hos_compact_rows): shapes stay static, the work follows the count.
+ *
+ * C[M,N] = epi( [A0 | A1][M, K0+K1] @ W[N, K0+K1]^T + bias[N] ).
  * A1 may be NULL (K1 = 0); K0, K1 multiples of 32; W row n starts at W + n*ldw.  */
 int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
                    const float* W, int ldw, const float* bias, float* C, int ldc,
                    int M, int N, int epilogue, float* aux, int aux_col, float p0, float p1,
-                   hos_stream_t stream);
+                   const int32_t* rows_dev, hos_stream_t stream);
 
 /* dX[M,K] = (dY[M,Npad] @ W[Npad,K]) (* (Xact[M,K] > 0) if Xact != NULL).
  * Npad (the reduction dim = padded layer width) multiple of 32; rows >= N of W must be zero.
@@ -93,7 +97,8 @@ int hos_linear_wgrad(const float* dY, int lddy, const float* X, int ldx, float* 
  * Reference: autograd of nn.Linear + ReLU in mlp_offset.py:54-70 (non-rigid MLPs, 128 wide, M = rays x 128). */
 int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, const float* W, int ldw,
                          float* dX, int lddx, float* dW, int lddw, float* db, int M, int N, int K,
-                         int relu_mask, float* ws, int64_t ws_floats, hos_stream_t stream);
+                         int relu_mask, float* ws, int64_t ws_floats, const int32_t* rows_dev,
+                         hos_stream_t stream);
 
 /* WGRAD of a layer up to 256 x 256 with the staging of hos_linear_bwd_fused (operands split once into LDS planes, transposed
  * LDS reads instead of in-register transposes): dW [N,ldw] += dY^T . X, db [N] += column sums (NULL: skip).  ws: optional
@@ -280,13 +285,13 @@ int hos_human_sample_warp(const float* rays_o, const float* rays_d, const float*
  * vol_cl is the volume in channel-LAST layout [V,V,V,CL] (CL >= K, multiple of 4). */
 int hos_lbs_forward(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
                     int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
-                    float* x_deform, hos_stream_t stream);
+                    float* x_deform, const int32_t* rows_dev, hos_stream_t stream);
 
 /* Hann-windowed positional encoding of the non-rigid MLP (embedders/hannw_fourier.py:15-71) written
  * as the MLP's first-layer input row  E[p] = [cond(cond_size) | w_j sin(2^j x), w_j cos(2^j x) | 0]
  * (mlp_offset.py:55) and optionally the features alone into PE [P, ldpe] for the skip concat (:59-60). */
 int hos_embed_hannw(const float* x, const float* band_w, int num_freqs, const float* cond, int cond_size,
-                    int64_t P, float* E, int lde, float* PE, int ldpe, hos_stream_t stream);
+                    int64_t P, float* E, int lde, float* PE, int ldpe, const int32_t* rows_dev, hos_stream_t stream);
 
 /* Canonical-MLP input row  E[p] = [x, sin(2^j x), cos(2^j x) (j<num_freqs) | state embedding | 0]
  * (embedders/fourier.py:11-57, N:248-249); E2 (optional) receives the same 3+6F+state_size columns
@@ -307,15 +312,15 @@ int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, 
 int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
                         int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
                         const float* g_x_deform, float* g_cnl, float* g_vol_cl, float* g_R, float* g_T,
-                        hos_stream_t stream);
+                        const int32_t* rows_dev, hos_stream_t stream);
 /* Backward of both positional embedders w.r.t. x: feature gradients are read from dA[:, colA:] (+ dB[:, colB:]
  * if not NULL); band_w NULL = plain Fourier (weights 1); identity != 0 = features start with x itself. */
 int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
                   int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
-                  hos_stream_t stream);
+                  const int32_t* rows_dev, hos_stream_t stream);
 /* out[p,c] = src[p*lds+col0+c] * (mask_src[p*ldm+mcol0+c] > 0), c < width (mask_src may be NULL). */
 int hos_slice_mask(const float* src, int lds, int col0, const float* mask_src, int ldm, int mcol0, int64_t P,
-                   int width, float* out, int ldo, hos_stream_t stream);
+                   int width, float* out, int ldo, const int32_t* rows_dev, hos_stream_t stream);
 /* dz[p, 0..3] = g * (sigmoid' | relu') evaluated from the activated outputs (N:539-540); dz is [P, ldz] zero-padded by the caller. */
 int hos_rgbsigma_grad(const float* g_rgbsigma, const float* rgbsigma, int64_t P, float* dz, int ldz,
                       hos_stream_t stream);
@@ -370,13 +375,15 @@ int hos_merge_composite_bwd(const float* g_rgb, const float* g_human_weights_sor
  *   block_mlps.0, block_mlps.2, block_mlps.4, block_mlps_dstR.0, block_mlps_dstR.2, block_mlps_dstT.0,
  *   block_mlps_dstT.2  (weights row-major [out,in], contiguous).
  * saved: [F, hos_pose_refine_saved_floats()] activations kept for the backward pass.
- * The backward ACCUMULATES (+=) the parameter gradients into grads14 (single workgroup, no atomics). */
+ * The backward ACCUMULATES (+=) the parameter gradients into grads14 (every element owned by one thread, no atomics);
+ * workspace: F * hos_pose_refine_workspace_floats() floats (the per-layer output gradients between its two launches). */
 long long hos_pose_refine_saved_floats(void);
+long long hos_pose_refine_workspace_floats(void);
 int hos_pose_refine_fwd(const float* posevec, const float* Rs, const float* Ts, const float* const* weights14,
                         int F, int K, int width, float* Rs_out, float* Ts_out, float* saved, hos_stream_t stream);
 int hos_pose_refine_bwd(const float* g_Rs_out, const float* g_Ts_out, const float* posevec, const float* Rs,
                         const float* saved, const float* const* weights14, float* const* grads14, int F, int K, int width,
-                        hos_stream_t stream);
+                        float* workspace, hos_stream_t stream);
 
 /* MotionBasisComputer.forward (U:134-174): G_dst = kinematic chain of [R_i|T_i] over the SMPL tree (U:100-103);
  * backward bases [R_bwd|T_bwd] = G_cnl G_dst^-1 (observation -> canonical, used by the backward LBS warp N:304-355),

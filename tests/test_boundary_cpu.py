@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_without_gpu():
     from hosnerf_amd import _lib
     lib = _lib.load()
-    assert lib.hos_linear_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0) == -1       # HOS_E_ARG
+    assert lib.hos_linear_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0, 0) == -1       # HOS_E_ARG
     assert lib.hos_resample(0, 0, 64, 8, 64, 0.0, 1.0, 0, 10.0, 0.0, 0, 0, 0.0, 0.1, 1e6, 0, 0, 0, 0) == -1
 
 

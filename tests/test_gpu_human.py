@@ -391,7 +391,7 @@ def test_thin_and_fused_entry_points_small_m(dev, M):
     # fused 128-wide backward, no workspace (atomics path)
     n = k = 128
     dW2 = torch.zeros(n, k, device=dev); db2 = torch.zeros(n, device=dev); dX2 = torch.empty(M, k, device=dev)
-    call("hos_linear_bwd_fused", ptr(dYd), N, ptr(Xd), K, ptr(Wd), K, ptr(dX2), k, ptr(dW2), k, ptr(db2), M, n, k, 1, None, 0)
+    call("hos_linear_bwd_fused", ptr(dYd), N, ptr(Xd), K, ptr(Wd), K, ptr(dX2), k, ptr(dW2), k, ptr(db2), M, n, k, 1, None, 0, None)
     want = (dY[:, :n].double() @ W[:n, :k].double()) * (X[:, :k] > 0)
     assert float((dX2.double().cpu() - want).abs().max()) < 2e-5 * float(want.abs().max())
     want = dY[:, :n].double().t() @ X[:, :k].double()
