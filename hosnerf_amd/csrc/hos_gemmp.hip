@@ -174,7 +174,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #ifdef HOS_EXP_SKIP_A_DMA
         if (!isB) return;
 #endif
-        unsigned off;
+        size_t off;            // 64-bit: 4 Mi rows x 576 columns x 2 planes already exceeds 2^32 elements (65 536-ray proposal levels)
         const uint16_t* P;
         if constexpr (!TR) {
             const bool seg1 = kt >= kt0;                                 // A may switch to its second K segment
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             int gr = g_row0 + kc_row + 8 * q;
             gr = gr < g_limit ? gr : g_limit - 1;                       // clamp: out-of-range rows are never stored
             const int chunk = kc_pos ^ (kc_swz | ((q & 1) << 2));       // 0-3: hi k 0..31, 4-7: lo
-            off = (unsigned)gr * (unsigned)(2 * ld) + (unsigned)(kb * 64 + chunk * 8);
+            off = (size_t)gr * (size_t)(2 * ld) + (size_t)(kb * 64 + chunk * 8);
         } else {
             P = P0;
             const int pos = q * 1024 + lane * 16;                       // byte position inside this wave's quarter
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             const int unit = (rb >> 6) ^ (m & 3);                       // source 64-byte unit (swizzle on the source)
             int gc = g_row0 + (unit >> 1) * 32 + ((rb >> 4) & 3) * 8;   // logical column of this 16-byte piece
             gc = gc < ((g_limit + 7) & ~7) ? gc : 0;                    // clamp: columns past the operand are never stored
-            off = (unsigned)(kt * PBK + m) * (unsigned)(2 * ld0) + (unsigned)((gc >> 5) * 64 + (unit & 1) * 32 + (gc & 31));
+            off = (size_t)(kt * PBK + m) * (size_t)(2 * ld0) + (size_t)((gc >> 5) * 64 + (unit & 1) * 32 + (gc & 31));
         }
         dma16(P + off, lds_wave + stage * STAGE + q * 1024);             // LDS address is wave-uniform
     };

@@ -104,6 +104,9 @@ class FusedAdam:
         1/world scaling is applied here."""
         self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
         g = self.module.flat_grad
+        if self.exp_avg.device != g.device:       # the module was moved after the optimiser was built (`lit.to(device)`)
+            self.exp_avg, self.exp_avg_sq, self._sumsq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device), self._sumsq.to(g.device)
+            self._hyper = None
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
         if dynamic:
             sumsq = None

@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Launcher with the reference's command line (`run.py` of each stage directory: 1st_State-Conditional_Scene/run.py:141-156,
+3rd_Complete_HOSNeRF/run.py:75-292): `--ginc` / `--ginb` (gin files and bindings), `--scene_name`, `--seed`, `--logbase`,
+`--resume_training`, `--ckpt_path`, `--cfg`; `run.model_name` selects the stage (`state_mipnerf360 | state_humanobject |
+hosnerf`), `run.max_steps`, `run.grad_max_norm`, `run.bkgd_path` / `run.human_path` (stage-3 warm start, run.py:206-212),
+`run.run_train`.  The reference's .gin files parse unchanged (hosnerf_amd/gin_lite.py).
+
+What is NOT here: Lightning's Trainer (a plain loop drives `training_step` / `optimizer_step` / checkpoints the way the Trainer
+does; DDP = one process per GPU under torch.distributed.run, ray shards + one flat-gradient all-reduce per module), the
+datasets and image IO (out of scope -- training items are synthetic unless `--items` points at a torch-saved
+list of dataset items with the reference's keys), LPIPS / SSIM.
+
+    python run.py --ginc configs/hosnerf_backpack.gin --scene_name Backpack --logbase logs --ginb "run.max_steps=200"
+    python run.py --ginc ... --cpu        # BASELINE configs[0] "CPU plumbing": everything except the kernels, no GPU needed
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--ginc", action="append", help="gin config file")
+    p.add_argument("--ginb", action="append", help="gin bindings")
+    p.add_argument("--resume_training", type=str2bool, nargs="?", const=True, default=False)
+    p.add_argument("--ckpt_path", type=str, default=None, help="path to checkpoints")
+    p.add_argument("--scene_name", type=str, default=None, help="scene name to render")
+    p.add_argument("--seed", type=int, default=220901, help="seed to use")
+    p.add_argument("--logbase", type=str, default=None, help="folder to save results")
+    p.add_argument("--cfg", default=None, type=str, help="yaml of the human-object network (configs/human_nerf/...), optional")
+    # additions of this build
+    p.add_argument("--cpu", action="store_true", help="plumbing only (BASELINE configs[0]): no kernel is launched, no GPU needed")
+    p.add_argument("--items", type=str, default=None, help="torch-saved list of dataset items (reference keys); default: synthetic")
+    p.add_argument("--rays", type=int, default=0, help="rays per step and GPU for synthetic items (default: the stage's reference batch)")
+    return p.parse_args(argv)
+
+
+def make_cfg(args, basedir):
+    """S3/run.py:33-62: defaults + configs/default.yaml + --cfg merged; here the hot-path fields of those yaml files are the
+    defaults of `default_cfg`, and an optional --cfg yaml overrides them."""
+    from hosnerf_amd.human_nerf import Cfg, default_cfg
+    cfg = default_cfg(basedir)
+    if args.cfg:
+        import yaml
+
+        def merge(dst, src):
+            for k, v in src.items():
+                if isinstance(v, dict):
+                    node = dst.get(k)
+                    if not isinstance(node, dict):
+                        node = Cfg()
+                        dst[k] = node
+                    merge(node, v)
+                else:
+                    dst[k] = v
+        with open(args.cfg) as f:
+            merge(cfg, yaml.safe_load(f) or {})
+    return cfg
+
+
+def synthetic_item(model_name: str, rays: int, seed: int, step: int):
+    from hosnerf_amd import synth
+    from hosnerf_amd.train import prepare_patch_targets
+    if model_name == "state_mipnerf360":
+        return synth.stage1_batch(rays, seed=seed + step)
+    b = synth.human_batch(rays, seed=seed + step, time=((step * 37) % 100) / 99.0, is_train=True, iter_val=float(step))
+    return prepare_patch_targets(synth.add_patch_supervision(b, max(1, rays // 1024), 32, seed + step))
+
+
+def crop_rays_64(seed: int = 777):
+    """BASELINE configs[0] / SURVEY 8(d).1: the 64x64 crop = 4096 rays of a pin-hole camera (f = 64 * 1.2) at z = +1 looking
+    at the origin, radii from the neighbouring-ray distance * 2 / sqrt(12) (S1/src/data/ray_utils.py:94-108)."""
+    H = W = 64
+    f = 64 * 1.2
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    d = torch.stack([(i + 0.5 - W / 2) / f, -(j + 0.5 - H / 2) / f, -torch.ones_like(i)], -1).reshape(-1, 3)
+    o = torch.tensor([0.0, 0.0, 1.0]).expand_as(d).contiguous()
+    dn = d.view(H, W, 3)
+    dx = torch.sqrt(((dn[:-1] - dn[1:]) ** 2).sum(-1))
+    dx = torch.cat([dx, dx[-2:-1]], 0).reshape(-1, 1)
+    vd = d / d.norm(dim=-1, keepdim=True)
+    g = torch.Generator().manual_seed(seed)
+    return {"rays_o": o, "rays_d": d, "viewdirs": vd, "radii": dx * 2 / (12 ** 0.5), "times": torch.full((H * W,), 0.5),
+            "target": torch.rand(H * W, 3, generator=g)}
+
+
+def run(args, gin):
+    from hosnerf_amd import select_option
+    from hosnerf_amd.train import batch_to_device
+    kw = gin.kwargs("run")
+    model_name = kw.get("model_name")
+    if model_name is None:
+        raise SystemExit("run.model_name is not bound (pass a --ginc file or --ginb 'run.model_name=\"hosnerf\"')")
+    dataset_name = kw.get("dataset_name", "synthetic")
+    scene = args.scene_name or "scene"
+    exp_name = f"{model_name}_{dataset_name}_{scene}_{str(args.seed).zfill(3)}"          # S3/run.py:108-110
+    if kw.get("postfix"):
+        exp_name += "_" + kw["postfix"]
+    logdir = os.path.join(args.logbase or "logs", exp_name)
+    os.makedirs(logdir, exist_ok=True)
+    basedir = kw.get("datadir") if (kw.get("datadir") and os.path.isdir(str(kw.get("datadir")))) else logdir
+    if not os.path.exists(os.path.join(basedir, "transitions_times.json")):
+        with open(os.path.join(logdir, "transitions_times.json"), "w") as f:       # one transition -> two states, like Backpack
+            json.dump({"f0": {"time": 0.4}}, f)
+        basedir = logdir
+    torch.manual_seed(args.seed)                                                         # seed_everything (run.py:155)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    model_kw = {}
+    if model_name == "state_mipnerf360":
+        model_kw.update(max_steps=int(kw.get("max_steps", 500000)), grad_max_norm=float(kw.get("grad_max_norm", 0.0)))
+        for k in ("lr_init", "lr_final", "lr_delay_steps", "lr_delay_mult"):
+            if gin.get_param(f"LitMipNeRF360.{k}") is not None:
+                model_kw[k] = gin.get_param(f"LitMipNeRF360.{k}")
+        for side, name in (("near", "LitDataNeRF360V2.near"), ("far", "LitDataNeRF360V2.far")):
+            if gin.get_param(name) is not None:
+                model_kw[side] = float(gin.get_param(name))
+    else:
+        model_kw["cfg"] = make_cfg(args, basedir)
+    lit = select_option.select_model(model_name, basedir, **model_kw)
+    n_params = sum(p.numel() for p in lit.parameters())
+    if model_name == "hosnerf":                                                          # warm start, S3/run.py:206-212
+        for key in ("human_path", "bkgd_path"):
+            path = kw.get(key)
+            if path and os.path.exists(str(path)):
+                missing, unexpected = select_option.load_checkpoint(lit, path, strict=False)
+                print(f"[run] {key}: loaded {path} ({len(missing)} missing, {len(unexpected)} unexpected keys)")
+    opt = lit.configure_optimizers()
+    ckpt = args.ckpt_path or os.path.join(logdir, "last.ckpt")
+    step0 = 0
+    if args.resume_training and os.path.exists(ckpt):
+        select_option.load_checkpoint(lit, ckpt, strict=True)
+        step0 = select_option.load_optimizer_states(ckpt, opt)
+        print(f"[run] resumed from {ckpt} at step {step0}")
+    max_steps = int(kw.get("max_steps", 0))
+    default_rays = {"state_mipnerf360": int(gin.get_param("LitData.batch_size", 4096)) // max(world, 1), "state_humanobject": 2048, "hosnerf": 2048}
+    rays = args.rays or default_rays[model_name]
+    print(f"[run] {exp_name}: {model_name}, {n_params / 1e6:.2f} M parameters, {rays} rays/step/GPU, world {world}, max_steps {max_steps}, logdir {logdir}")
+
+    if args.cpu:
+        # BASELINE configs[0] "CPU PyTorch single process (plumbing, no GPU)": flags, gin, module construction under the
+        # reference's names, optimiser + schedule, a 64x64-crop ray batch, checkpoint round trip.  The renderer itself has no
+        # CPU implementation (by design: hosnerf_amd never falls back); its CPU restatement is the test oracle (tests/).
+        crop = crop_rays_64(args.seed)
+        lit._step = step0
+        lit.apply_lr(opt, step0)
+        select_option.save_checkpoint(lit, ckpt, global_step=step0, optimizer=opt)
+        missing, unexpected = select_option.load_checkpoint(lit, ckpt, strict=True)
+        plan = {"mode": "cpu-plumbing", "exp_name": exp_name, "model_name": model_name, "parameters": n_params, "state_dict_keys": len(lit.state_dict()),
+                "crop_rays": int(crop["rays_o"].shape[0]), "samples_per_ray": "64/64/32 background, 128 human", "lr": [g["lr"] for g in opt.param_groups],
+                "checkpoint": ckpt, "checkpoint_roundtrip": {"missing": len(missing), "unexpected": len(unexpected)}, "max_steps": max_steps,
+                "gin": {k: v for k, v in sorted(gin.items())}}
+        print(json.dumps(plan))
+        return plan
+
+    if not torch.cuda.is_available():
+        raise SystemExit("run.py needs an MI355X for training / rendering (there is no CPU renderer); use --cpu for the plumbing check")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lit = lit.to(dev)
+    items = torch.load(args.items, weights_only=False) if args.items else None
+    run_train = bool(kw.get("run_train", True))
+    log_every = int(kw.get("log_every_n_steps", 100))
+    t0 = time.perf_counter()
+    lit._step = step0
+    if run_train:
+        for step in range(step0, max_steps):
+            item = items[step % len(items)] if items else synthetic_item(model_name, rays, args.seed + 1000 * rank, step)
+            batch = batch_to_device(item, dev) if model_name != "state_mipnerf360" else {k: v.to(dev) for k, v in item.items()}
+            opt.zero_grad()
+            loss = lit.training_step(batch, step)
+            loss.backward()
+            lit.optimizer_step(0, step, opt)
+            if (step + 1) % log_every == 0 and rank == 0:
+                dt = time.perf_counter() - t0
+                print(f"[run] step {step + 1}/{max_steps} loss {float(loss):.5f} lr {opt.param_groups[0]['lr']:.3e} "
+                      f"{(step + 1 - step0) * rays * world / dt:.0f} rays/s")
+        if rank == 0 and bool(kw.get("save_last", True)):
+            select_option.save_checkpoint(lit, ckpt, global_step=max_steps, optimizer=opt)
+            print(f"[run] wrote {ckpt}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return {"exp_name": exp_name, "checkpoint": ckpt}
+
+
+def main(argv=None):
+    from hosnerf_amd import gin_lite
+    args = parse_args(argv)
+    gin = gin_lite.parse_config_files_and_bindings(args.ginc, args.ginb)
+    return run(args, gin)
+
+
+if __name__ == "__main__":
+    main()
