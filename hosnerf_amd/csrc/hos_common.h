@@ -18,6 +18,7 @@ static inline int hos_launch_status() {
 }
 
 static inline int hos_cdiv(int a, int b) { return (a + b - 1) / b; }
+unsigned int* hos_range_flag_ptr();      // hos_gemm.hip: the device word registered with hos_set_range_flag (or NULL)
 
 // ---- wave-level primitives (64 lanes) ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -241,8 +241,12 @@ int launch(const GemmArgs& a, int splits, hipStream_t stream) {
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int g_gemm_mode = HOS_GEMM_BF16X3;
+unsigned int* g_range_flag = nullptr;      // caller-owned device word (hos_set_range_flag); NULL: no range reporting
 
 }  // namespace
+
+unsigned int* hos_range_flag_ptr() { return g_range_flag; }
+extern "C" int hos_set_range_flag(unsigned int* flag) { g_range_flag = flag; return HOS_OK; }
 
 extern "C" int hos_set_gemm_mode(int mode) {
     if (mode != HOS_GEMM_FP32 && mode != HOS_GEMM_BF16X3) return HOS_E_ARG;
@@ -273,6 +277,7 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
     a.nk = (K0 + K1) / BK; a.kt_per_split = a.nk; a.red_limit = 0x7fffffff;
     a.bias = bias; a.aux = aux; a.aux_col = aux_col; a.p0 = p0; a.p1 = p1; a.epi = epilogue;
     a.m_dev = rows_dev;
+    a.range_flag = (g_gemm_mode == HOS_GEMM_BF16X3) ? g_range_flag : nullptr;      // exact-fp32 mode has no fp16 operands
     if (epilogue == HOS_EPI_RESIDUAL) { a.mask = aux; a.ldmask = aux_col; }   // residual [M, ld=aux_col]
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (N <= 32) {

@@ -28,7 +28,13 @@ struct GemmArgs {
     int ablate;              // debug only (HOS_GEMM_ABLATE): 1 = skip global loads, 2 = skip convert/store, 4 = skip MFMA
     int pf_dist;             // split kernels: software L2 prefetch distance in K tiles (0 = off; HOS_GEMM_PF)
     const int* m_dev;        // FWD only, optional: live row count in device memory; row tiles at or past it are skipped
+    unsigned int* range_flag;   // FWD, optional: set to 1 when a hidden activation leaves the exactly-representable fp16 hi/lo range
 };
+
+// Forward activations travel as fp16 (hi, lo) pairs: exact to 2^-22 for |x| <= 65504, hi saturates there and lo carries the
+// residual up to |x| = 131008 (2^-11 relative), beyond that the pair saturates.  Producers flag anything above this limit
+// (hos_set_range_flag) so the host can re-run the layer stack in exact fp32 MFMA mode.
+#define HOS_RANGE_LIMIT 6.0e4f
 
 
 // One element of the fused forward epilogue.  Returns false when the value went to `aux` instead of C.
@@ -71,6 +77,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
         const bool c_vec = ((reinterpret_cast<uintptr_t>(a.C) & 15u) == 0) && ((a.ldc & 3) == 0);
         const bool m_vec = a.mask != nullptr && ((reinterpret_cast<uintptr_t>(a.mask) & 15u) == 0) && ((a.ldmask & 3) == 0);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool big = false;
         if (MODE == MODE_FWD && a.bias != nullptr) {
             if (colb + 0 < a.N) bias4.x = a.bias[colb + 0];
             if (colb + 1 < a.N) bias4.y = a.bias[colb + 1];
@@ -97,6 +104,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                 const bool simple = (a.epi == HOS_EPI_NONE || a.epi == HOS_EPI_RELU);
                 if (simple && full && c_vec) {
                     if (a.epi == HOS_EPI_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    big |= fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT;
                     *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + colb) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
@@ -105,6 +113,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                         if (col >= a.N) break;
                         float x = v[k];
                         if (fwd_epilogue_value(a, x, row, col)) a.C[(size_t)row * a.ldc + col] = x;
+                        if (simple) big |= fabsf(x) > HOS_RANGE_LIMIT;
                     }
                 }
             } else {   // MODE_DGRAD
@@ -133,6 +142,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                 }
             }
         }
+        if (MODE == MODE_FWD && a.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
     }
 }
 

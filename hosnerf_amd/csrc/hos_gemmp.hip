@@ -499,6 +499,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         char* const stg = smemp + wave * 8192;
         const bool dual = (EPI == PEPI_PLANES_FWD) && a.Yb != nullptr;
         const bool first = a.Y != nullptr;
+        bool big = false;          // a hidden activation beyond the exact fp16 hi/lo range (HOS_RANGE_LIMIT)
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                             if (col >= a.N) v = 0.f;                                   // zero the padding columns
                             const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                             uint32_t p;
-                            if (EPI == PEPI_PLANES_FWD && fmt == 0) p = split_pack<_Float16>(v);
+                            if (EPI == PEPI_PLANES_FWD && fmt == 0) { p = split_pack<_Float16>(v); big |= fabsf(v) > HOS_RANGE_LIMIT; }
                             else p = split_pack<__bf16>(v);
                             *reinterpret_cast<uint32_t*>(stg + (rl * 64 + yy * 32 + l31) * 4) = p;
                         }
@@ -556,6 +557,8 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging reads done before it is rewritten
                 }
             }
+        if (EPI == PEPI_PLANES_FWD && a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0)
+            atomicOr(a.f32.range_flag, 1u);
     }
 #ifdef HOS_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -746,6 +749,7 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
     a.bias = bias; a.relu = relu;
     a.Y = (uint16_t*)Y; a.ldy = ldy; a.Yb = (uint16_t*)Yb; a.ldyb = ldyb;
     a.f32.C = C; a.f32.ldc = ldc; a.f32.M = M; a.f32.N = N; a.f32.bias = bias; a.f32.aux = aux; a.f32.aux_col = aux_col;
+    a.f32.range_flag = hos_range_flag_ptr();
     a.f32.p0 = p0; a.f32.epi = epilogue;
     if (epilogue == HOS_EPI_RESIDUAL) { a.f32.mask = aux; a.f32.ldmask = aux_col; }
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -43,6 +43,7 @@ struct ThinArgs {
     int M, N, K;                      // C is [M, N]; reduction length K
     int epi;                          // FWD: HOS_EPI_NONE / HOS_EPI_RELU
     const float* mask; int ldmask;    // DGRAD: ReLU mask source [M, >= N] (NULL: none)
+    unsigned int* range_flag;         // FWD: see HOS_RANGE_LIMIT
 };
 
 constexpr int TH_NT = 512;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     };
 
     GemmArgs ef{};                                       // FWD epilogue (bias, ReLU, 16-byte stores)
-    ef.C = a.C; ef.ldc = a.ldc; ef.M = a.M; ef.N = a.N; ef.bias = a.bias; ef.epi = a.epi;
+    ef.C = a.C; ef.ldc = a.ldc; ef.M = a.M; ef.N = a.N; ef.bias = a.bias; ef.epi = a.epi; ef.range_flag = a.range_flag;
 
     const int ntiles = (a.M + R - 1) / R;
     const int G = gridDim.x;
@@ -263,7 +264,7 @@ extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int 
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
     if (N > 256 || K > 256 || (epilogue != HOS_EPI_NONE && epilogue != HOS_EPI_RELU)) return HOS_E_SHAPE;
     if ((ldx & 3) || (ldw & 3) || (K & 3) || (((uintptr_t)X | (uintptr_t)W) & 15u)) return HOS_E_ALIGN;
-    ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0};
+    ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0, hos_range_flag_ptr()};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return K <= 128 ? launch_thin<8, false>(a, s) : launch_thin<16, false>(a, s);
 }

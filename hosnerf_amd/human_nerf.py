@@ -93,6 +93,8 @@ CNL_CAT = 384     # skip-concat row [fourier+state (127) | h (256) | 0]
 
 
 class Network(FlatModule):
+    gemm_mode = None      # None: the process default (ops.set_gemm_mode); ops.GEMM_* pins the arithmetic of this module's GEMMs
+
     def __init__(self, cfg, stage: int = 3):
         super().__init__()
         self.cfg = cfg
@@ -482,7 +484,14 @@ class Network(FlatModule):
         """Reference signature + keyword-only extensions: `t_rand` (the stratified jitter draws), `prologue` (a cached
         `frame_prologue`), `with_cycle=False` (evaluation loops never read the cycle outputs), `static_cycle=True`
         (fixed-shape cycle outputs [P,3] + `cycle_count` on the device instead of the reference's data-dependent
-        [n_selected,3]: no host synchronisation, the step can be captured in a hipGraph)."""
+        [n_selected,3]: no host synchronisation, the step can be captured in a hipGraph).
+        `self.gemm_mode` (None = process default) selects the arithmetic of this module's GEMMs (see ops.guarded_forward)."""
+        return ops.guarded_forward(self, rays.device, lambda: self._forward(
+            rays, dst_Rs, dst_Ts, cnl_gtfms, motion_weights_priors, dst_posevec, near, far, iter_val, t_rand, prologue, with_cycle,
+            static_cycle, **kwargs))
+
+    def _forward(self, rays, dst_Rs=None, dst_Ts=None, cnl_gtfms=None, motion_weights_priors=None, dst_posevec=None, near=None,
+                 far=None, iter_val=1e7, t_rand=None, prologue=None, with_cycle: bool = True, static_cycle: bool = False, **kwargs):
         cfg = self.cfg
         dev = rays.device
         K = cfg.total_bones

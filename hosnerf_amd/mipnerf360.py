@@ -572,7 +572,15 @@ class MipNeRF360(FlatModule):
         self.store.rebind()
         self.mlps = nn.ModuleList(mlps)
 
+    gemm_mode = None      # None: the process default (ops.set_gemm_mode); ops.GEMM_* pins the arithmetic of this module's GEMMs
+
     def forward(self, batch, train_frac, randomized, is_train, near, far, jitters=None, want_index: bool = False):
+        """`self.gemm_mode` (None = the process default, ops.set_gemm_mode) selects the arithmetic of THIS module's GEMMs;
+        without autograd the fp16 range guard may set it to exact fp32 (ops.guarded_forward)."""
+        return ops.guarded_forward(self, batch["rays_o"].device,
+                                   lambda: self._forward(batch, train_frac, randomized, is_train, near, far, jitters, want_index))
+
+    def _forward(self, batch, train_frac, randomized, is_train, near, far, jitters=None, want_index: bool = False):
         rays_o = batch["rays_o"].contiguous()
         rays_d = batch["rays_d"].contiguous()
         viewdirs = batch["viewdirs"].contiguous()

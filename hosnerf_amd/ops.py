@@ -183,6 +183,54 @@ WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "1") == "1"       # planes WGRAD: spli
 WGRAD_WS_MIN = int(os.environ.get("HOS_WGRAD_WS_MIN", "0"))  # ... for gradients of at least this many elements
 
 
+# ------------------------------------------------------------------------------------------ fp16 range guard
+_RANGE_FLAG = {}
+RANGE_GUARD = os.environ.get("HOS_RANGE_GUARD", "1") != "0"
+
+
+def arm_range_flag(device) -> torch.Tensor:
+    """Register a device word with the library (hos_set_range_flag): forward epilogues set it to 1 when a hidden activation
+    exceeds the range the fp16 (hi, lo) operand format represents exactly (|x| <= 6e4 flagged, 65 504 exact, 131 008 hard limit)."""
+    key = str(device)
+    if key not in _RANGE_FLAG:
+        _RANGE_FLAG[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    _lib.check(_lib.load().hos_set_range_flag(ptr(_RANGE_FLAG[key], torch.int32)), "hos_set_range_flag")
+    return _RANGE_FLAG[key]
+
+
+def range_events(device, reset: bool = True) -> int:
+    """1 if any forward GEMM since the last reset produced an activation outside the exact fp16 hi/lo range (host sync)."""
+    flag = _RANGE_FLAG.get(str(device))
+    if flag is None:
+        return 0
+    v = int(flag.item())
+    if v and reset:
+        flag.zero_()
+    return v
+
+
+def guarded_forward(module, device, run):
+    """Run `run()` (a no-grad forward of `module`); if the fp16 range flag fires, switch the module to exact-fp32 MFMA for good
+    (`module.gemm_mode = GEMM_FP32`) and run it again.  Costs one 4-byte device read per call; only used without autograd
+    (evaluation / inference), training loops poll `range_events` every few hundred steps instead (train.check_range)."""
+    mode = getattr(module, "gemm_mode", None)
+    if mode is not None:
+        with gemm_mode(mode):
+            return run()
+    if not RANGE_GUARD or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        return run()
+    arm_range_flag(device)
+    out = run()
+    if range_events(device):
+        import warnings
+        warnings.warn(f"{type(module).__name__}: hidden activations beyond the exact fp16 hi/lo range (|x| > 6e4); "
+                      "switching this module to exact fp32 MFMA")
+        module.gemm_mode = GEMM_FP32
+        with gemm_mode(GEMM_FP32):
+            out = run()
+    return out
+
+
 class gemm_mode:
     """Context manager: run the enclosed GEMM launches in another arithmetic mode (the mode is read when a kernel is
     launched, so this also works while a graph is being captured)."""

@@ -305,6 +305,18 @@ def stage2_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
     return total, _loss_parts(parts)
 
 
+def check_range(modules, device) -> bool:
+    """Training-loop side of the fp16 range guard (ops.guarded_forward is the no-grad side): poll the device flag -- one
+    4-byte read, so every few hundred steps, not every step -- and switch the given modules to exact fp32 MFMA if a hidden
+    activation left the exactly-representable fp16 hi/lo range since the last poll.  Returns True if it switched."""
+    ops.arm_range_flag(device)
+    if not ops.range_events(device):
+        return False
+    for m in modules:
+        m.gemm_mode = ops.GEMM_FP32
+    return True
+
+
 def human_lr_decay(step: int, lrate_decay: int = 500) -> float:
     """`optimizer_step` of the human stages (M2:606-634, M:1631-1656): every group's lr = base * 0.1 ** (step / (lrate_decay * 1000))."""
     return 0.1 ** (step / (lrate_decay * 1000.0))

@@ -56,6 +56,13 @@ const char* hos_error_string(int code);
 int hos_set_gemm_mode(int mode);
 int hos_get_gemm_mode(void);
 
+/* Range guard of the split modes.  Forward activations travel as fp16 (hi, lo) pairs: exact to 2^-22 for |x| <= 65504; hi
+ * saturates there and lo carries the residual up to 131008 (2^-11 relative); beyond that the pair saturates.  With a device word
+ * registered here (caller-owned, NULL switches the reporting off) every forward epilogue that produces a hidden activation
+ * (HOS_EPI_NONE / HOS_EPI_RELU, and the planes outputs) ORs 1 into it when |x| > 6e4, so the host can re-run the layer stack
+ * in HOS_GEMM_MODE_FP32 (hosnerf_amd.ops.guarded_forward does).  Gradients use bf16 pairs (8-bit exponent) and need no guard. */
+int hos_set_range_flag(unsigned int* flag);
+
 /* epilogues for hos_linear_fwd */
 #define HOS_EPI_NONE 0       /* C = acc + bias                                                */
 #define HOS_EPI_RELU 1       /* C = relu(acc + bias)                                          */

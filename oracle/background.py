@@ -275,7 +275,7 @@ class MLPWeights:
 def encode_samples(means, covs, basis, max_deg_point: int = 12):
     """M:213-222: contract -> lift -> IPE  ([B,S,504])."""
     m, c = contract(means, covs)
-    lm, lv = lift_and_diagonalize(m, c, basis.to(m.device))
+    lm, lv = lift_and_diagonalize(m, c, basis.to(device=m.device, dtype=m.dtype))
     return integrated_pos_enc(lm, lv, 0, max_deg_point)
 
 

@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_configs.py -x -q -k launcher 2>&1 | tail -4
+python -m pytest tests/test_gpu_stress.py -x -q 2>&1 | tail -12
