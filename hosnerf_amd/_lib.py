@@ -73,6 +73,10 @@ PROTOTYPES = {
     "hos_raw2outputs_bwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],
     "hos_merge_composite_fwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P],
     "hos_merge_composite_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P],
+    "hos_mlp_chain_weight_bytes": [],
+    "hos_mlp_chain_aux_floats": [],
+    "hos_mlp_chain_pack": [_P, _P, _P, _P, _P, _P],
+    "hos_mlp_chain128_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _P],
     "hos_compact_workspace_ints": [],
     "hos_compact_rows": [_P, _F, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "hos_scatter_rows": [_P, _P, _P, _L, _P, _P],
@@ -91,7 +95,8 @@ PROTOTYPES = {
 }
 _RESTYPES = {"hos_error_string": c_char_p, "hos_train_losses_workspace_floats": c_int64,
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
-             "hos_pose_refine_workspace_floats": c_int64}
+             "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
+             "hos_mlp_chain_aux_floats": c_int64}
 
 _lib = None
 

@@ -1,0 +1,335 @@
+// Forward of a whole thin MLP in ONE launch with the activations on chip across its layers (SURVEY 8(b).6 `fused_mlp_nonrigid`,
+// VERDICT r1 item 2): the non-rigid motion MLPs of the human branch -- `NonRigidMotionMLP` / `NonRigidForwardMLP`,
+// non_rigid_motion_mlps/mlp_offset.py:16-70: [cond 75 | hann 36] -> 5 x (128, ReLU) with the hann features re-concatenated before
+// Linear #4 -> 3, xyz = x + offset -- over P = rays x 128 sample points.
+//
+// Layer-by-layer launches move every activation through HBM twice (written by layer l, read by layer l+1: 8 B per row and
+// column and layer).  Here a wave keeps its 32 rows in REGISTERS from the embedding to the offset:
+//   * the product is formed transposed, H^T = W . X^T (v_mfma_f32_32x32x16_f16, weights as the A operand, 32 sample rows as
+//     the B operand), so the accumulator layout of layer l -- lane (row, half) holds 16 outputs of every 32-wide block for ITS
+//     row -- already IS a B-operand layout of layer l+1 once the reduction index is permuted inside every group of 16
+//     (k -> 8*(c/4) + 4*half + c%4); the weights are packed in that order once per step (hos_mlp_chain_pack), the contraction
+//     does not care.  No LDS round trip, no cross-lane traffic between layers.
+//   * fp16 (hi, lo) split of both operands, three MFMAs per product, fp32 accumulate: the arithmetic of the split GEMMs.
+//   * every layer's output is written ONCE (fp32, for the backward pass: 4 B per row and column and layer), nothing is read
+//     back; the last layer (3 outputs) is an fp32 FMA reduction on the lanes that already hold its input.
+//   * the weights stream from L2 through a two-deep LDS ring, one 32-column output block (16-24 KB of fragments) at a time, by
+//     LDS-DMA (global_load_lds), shared by the four waves of a workgroup; two workgroups per CU so that one's epilogue VALU
+//     work runs under the other's MFMAs.
+// Per row: 101 120 MAC x 3 products; HBM bytes per row = 768 read (E, PE) + 6 x 512 + 12 written.
+#include <stdlib.h>
+
+#include "hos_common.h"
+#include "hos_gemm_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+constexpr int CT = 256;             // threads per workgroup = 4 waves, one per SIMD
+constexpr int CROWS = 128;          // rows per workgroup tile (32 per wave)
+constexpr int NL = 6;               // hidden layers
+constexpr int CW = 128;             // layer width
+constexpr int KSMAX = 12;           // k-steps of 16: 8 (K = 128), 12 for the skip layer (128 + 64)
+constexpr int CBUF = KSMAX * 2 * 1024;      // one out-block of fragments: k-steps x (hi, lo) x 1 KB
+constexpr int SKIP_LAYER = 4;
+
+__host__ __device__ constexpr int ks_of(int l) { return l == SKIP_LAYER ? 12 : 8; }
+__host__ __device__ constexpr int layer_off(int l) {      // bytes, chain planes of layer l
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += 4 * ks_of(i) * 2048;
+    return o;
+}
+constexpr int WC_BYTES = layer_off(NL);
+
+struct ChainArgs {
+    const float* E; int lde;        // [P, >=128]  first-layer rows [cond | hann | 0]
+    const float* PE; int ldpe;      // [P, >=64]   hann features (skip concat)
+    const float* x;                 // [P, 3] residual
+    const uint16_t* Wc;             // chain planes of the hidden layers (hos_mlp_chain_pack)
+    const float* aux;               // [6*128 biases | 3*128 last-layer weight | 3 last-layer bias | pad]
+    float* acts[NL]; int ldact;     // [P, >=128] each: post-ReLU outputs, kept for the backward pass
+    float* xyz;                     // [P, 3]
+    long P; const int* p_dev;
+    unsigned int* range_flag;
+};
+constexpr int AUX_FLOATS = NL * CW + 3 * CW + 4;
+constexpr int AUX_BYTES = (AUX_FLOATS * 4 + 15) & ~15;
+constexpr int SMEM_BYTES = 2 * CBUF + AUX_BYTES;
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const h8& bh, const h8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void split_to(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    lo = (_Float16)(x - (float)hi);
+}
+
+// eight fp32 values at p[0..3] and p[8..11] (the k-slots of this half-lane inside a group of 16) -> (hi, lo) fragments
+__device__ __forceinline__ void load_split8(const float* p, h8& hi, h8& lo) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 8);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { _Float16 h, l; split_to(v[c], h, l); hi[c] = h; lo[c] = l; }
+}
+
+__global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const wbuf = smem;                                              // 2 x CBUF weight fragments
+    float* const s_aux = reinterpret_cast<float*>(smem + 2 * CBUF);       // biases, last layer
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    long P = a.P;
+    if (a.p_dev) P = min(P, (long)*a.p_dev);
+    for (int i = t; i < AUX_FLOATS; i += CT) s_aux[i] = a.aux[i];
+    const long ntiles = (P + CROWS - 1) / CROWS;
+    if ((long)blockIdx.x >= ntiles) return;
+
+    // Weight chunk g (0..23) = (layer g / 4, out-block g % 4): this wave moves its quarter of every 4 KB round.  The layer
+    // loop below is a REAL loop (not unrolled): with everything unrolled the compiler hoists ~110 loop-invariant 64-bit
+    // per-lane addresses out of the tile loop and spills them; as a function of the loop counter they are recomputed instead.
+    const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
+    // one 1 KB request of this wave for round q of a chunk (a chunk = ks / 2 rounds of 4 KB)
+    auto issue_round = [&](int l, int ob, int parity, int q) {
+        const int ks = l == SKIP_LAYER ? 12 : 8;
+        const int lo = l <= SKIP_LAYER ? l * 4 * 8 * 2048 : (SKIP_LAYER * 4 * 8 + 4 * 12) * 2048 + (l - SKIP_LAYER - 1) * 4 * 8 * 2048;
+#ifndef HOS_CHAIN_NO_DMA        // timing experiments only (results invalid)
+        dma16(reinterpret_cast<const char*>(a.Wc) + lo + ob * ks * 2048 + voff + q * 4096, wbuf + parity * CBUF + wave * 1024 + q * 4096);
+#endif
+    };
+    auto issue_chunk = [&](int l, int ob, int parity) {
+        const int rounds = (l == SKIP_LAYER ? 12 : 8) / 2;
+        for (int q = 0; q < rounds; ++q) issue_round(l, ob, parity, q);
+    };
+    issue_chunk(0, 0, 0);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#define CH_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+
+    bool big = false;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row = tile * CROWS + wave * 32 + r;
+        const long lrow = row < P ? row : P - 1;                       // clamped for loads; never stored
+        h8 bh[KSMAX], bl[KSMAX];
+        {
+            const float* e = a.E + (size_t)lrow * a.lde + 4 * hh;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) load_split8(e + 16 * s, bh[s], bl[s]);
+#pragma unroll
+            for (int s = 8; s < KSMAX; ++s)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { bh[s][c] = (_Float16)0.f; bl[s][c] = (_Float16)0.f; }
+        }
+        float part[3] = {0.f, 0.f, 0.f};
+        int parity = 0;
+#pragma unroll 1
+        for (int l = 0; l < NL; ++l) {
+            const int ks = l == SKIP_LAYER ? 12 : 8;
+            if (l == SKIP_LAYER) {
+                const float* pe = a.PE + (size_t)lrow * a.ldpe + 4 * hh;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) load_split8(pe + 16 * s, bh[8 + s], bl[8 + s]);
+            }
+            f32x16 acc[4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
+                // This wave's share of the chunk has landed.  vmcnt retires in issue order and the chunk's requests were issued
+                // BEFORE the 16 activation stores of the previous layer's epilogue, so at a layer's first chunk only those may
+                // still be in flight: the stores drain under the MFMAs instead of being waited for.
+                if (ob == 0 && l > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                          // ... and everybody's; the other buffer is free
+                // the next chunk (wrapping to chunk 0 for the next tile) goes into the other buffer, one request every second
+                // k-step: back-to-back requests stall the issuing wave, and an in-order wave that waits issues no MFMA
+                int nl = l, nob = ob + 1;
+                if (nob == 4) { nob = 0; nl = l + 1 == NL ? 0 : l + 1; }
+                const int nrounds = (nl == SKIP_LAYER ? 12 : 8) / 2;
+                const int npar = parity ^ 1;
+                const int parity_buf = parity;
+                parity ^= 1;
+                // Fragments one k-step ahead of the MFMAs.  hipcc stops counting LDS operations once an LDS-DMA is in flight and
+                // puts lgkmcnt(0) in front of every MFMA group -- i.e. it would also wait for the reads just issued for the NEXT
+                // k-step -- so the reads are asm statements it does not count, followed by an explicit counted wait (LDS returns
+                // in order); the fragments pass through the wait as "+v" operands so that no MFMA can move above it.
+                const unsigned la = lds_base + (unsigned)(parity_buf * CBUF + lane * 16);
+                // two register sets alternate by k-step parity: a register that an asm read is still filling must not be
+                // copied (the compiler believes the asm statement has completed)
+                h8 fh[2], fl[2];
+                CH_RD128(fh[0], la, 0);
+                CH_RD128(fl[0], la, 1024);
+#pragma unroll
+                for (int s = 0; s < KSMAX; ++s) {
+                    if (s < 8 || ks == 12) {
+                        const bool more = s + 1 < 8 || (ks == 12 && s + 1 < 12);
+                        if (more) {
+                            CH_RD128(fh[(s + 1) & 1], la, (2 * s + 2) * 1024);
+                            CH_RD128(fl[(s + 1) & 1], la, (2 * s + 3) * 1024);
+                            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
+                        }
+#ifndef HOS_CHAIN_NO_MFMA
+                        acc[ob] = mfma3(fh[s & 1], fl[s & 1], bh[s], bl[s], acc[ob]);
+#else
+                        acc[ob][s & 15] += (float)fh[s & 1][0] + (float)fl[s & 1][1];
+#endif
+                        if ((s & 1) == 0 && (s >> 1) < nrounds) issue_round(nl, nob, npar, s >> 1);
+                    }
+                }
+                if (ks == 8 && nrounds == 6) { issue_round(nl, nob, npar, 4); issue_round(nl, nob, npar, 5); }
+
+            }
+            // ---- epilogue of layer l: bias, ReLU, one store for the backward pass, next layer's B fragments in place
+            // lane-dependent part (4 * half) folded into the bases: every access below is base + immediate
+            const float* bias = s_aux + l * CW + 4 * hh;
+            float* out = a.acts[l] + (size_t)lrow * a.ldact + 4 * hh;
+            const bool last = l == NL - 1;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+#pragma unroll
+                for (int tq = 0; tq < 2; ++tq) {         // accumulator registers 8 tq .. 8 tq + 7 = the 8 k-slots of next k-step 2 ob + tq
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int q = 2 * tq + u;
+                        const int n0 = 32 * ob + 8 * q;
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
+                        v[4 * u + 0] = fmaxf(acc[ob][4 * q + 0] + b4.x, 0.f);
+                        v[4 * u + 1] = fmaxf(acc[ob][4 * q + 1] + b4.y, 0.f);
+                        v[4 * u + 2] = fmaxf(acc[ob][4 * q + 2] + b4.z, 0.f);
+                        v[4 * u + 3] = fmaxf(acc[ob][4 * q + 3] + b4.w, 0.f);
+#ifndef HOS_CHAIN_NO_STORE
+                        // (a lane owns ONE row here, so a store instruction touches 32 lines; staging the block through LDS for
+                        // whole-line stores was measured no faster: the stores are bound by the HBM write rate -- 3 KB per row --
+                        // and all CUs reach their epilogues at the same time)
+                        if (row < P) *reinterpret_cast<float4*>(out + n0) = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
+#endif
+                        if (last) {
+                            const float* w6 = s_aux + NL * CW + 4 * hh;
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(w6 + m * CW + n0);
+                                part[m] += v[4 * u] * w4.x + v[4 * u + 1] * w4.y + v[4 * u + 2] * w4.z + v[4 * u + 3] * w4.w;
+                            }
+                        }
+                    }
+                    float mx = v[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) mx = fmaxf(mx, v[c]);
+                    big |= mx > HOS_RANGE_LIMIT;
+                    h8 hi, lo;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { _Float16 h_, l_; split_to(v[c], h_, l_); hi[c] = h_; lo[c] = l_; }
+                    bh[2 * ob + tq] = hi;
+                    bl[2 * ob + tq] = lo;
+                }
+            }
+        }
+        // ---- last layer (mlp_offset.py:66-70): offset = W6 h + b6, xyz = x + offset
+#pragma unroll
+        for (int m = 0; m < 3; ++m) part[m] += __shfl_xor(part[m], 32, 64);
+        if (hh == 0 && row < P) {
+            const float* b6 = s_aux + NL * CW + 3 * CW;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) a.xyz[row * 3 + m] = part[m] + b6[m] + a.x[row * 3 + m];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // the wrapped-around prefetch of chunk 0
+    if (a.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
+// fp32 weights (nn.Linear layout [128, ldw]) -> chain planes: [out-block 4][k-step][hi, lo][lane 64][8 halfs], the lane's eight
+// values = W[32 ob + lane % 32][16 s + 8 (c / 4) + 4 (lane / 32) + c % 4], c = 0..7
+struct PackArgs {
+    const float* W[NL]; int ldw[NL];
+    const float* b[NL];
+    const float* W6; int ldw6; const float* b6;
+    uint16_t* Wc; float* aux;
+};
+
+__global__ __launch_bounds__(256) void chain_pack_kernel(PackArgs p) {
+    const int l = blockIdx.y;
+    if (l == NL) {                                   // biases and the last layer
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < AUX_FLOATS; i += gridDim.x * 256) {
+            float v = 0.f;
+            if (i < NL * CW) v = p.b[i / CW][i % CW];
+            else if (i < NL * CW + 3 * CW) { const int j = i - NL * CW; v = p.W6[(j / CW) * p.ldw6 + j % CW]; }
+            else if (i < NL * CW + 3 * CW + 3) v = p.b6[i - NL * CW - 3 * CW];
+            p.aux[i] = v;
+        }
+        return;
+    }
+    const int ks = ks_of(l);
+    const int total = 4 * ks * 64 * 8;               // (ob, s, lane, c): one thread writes hi and lo
+    uint16_t* dst = p.Wc + layer_off(l) / 2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int c = e & 7, lane = (e >> 3) & 63, s = (e >> 9) % ks, ob = (e >> 9) / ks;
+        const int n = 32 * ob + (lane & 31), k = 16 * s + 8 * (c >> 2) + 4 * (lane >> 5) + (c & 3);
+        const float w = p.W[l][(size_t)n * p.ldw[l] + k];
+        _Float16 hi, lo;
+        split_to(w, hi, lo);
+        const size_t o = (((size_t)(ob * ks + s) * 2) * 64 + lane) * 8 + c;
+        dst[o] = __builtin_bit_cast(uint16_t, hi);
+        dst[o + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
+    }
+}
+
+}  // namespace
+
+extern "C" long long hos_mlp_chain_weight_bytes(void) { return WC_BYTES; }
+extern "C" long long hos_mlp_chain_aux_floats(void) { return AUX_FLOATS; }
+
+extern "C" int hos_mlp_chain_pack(const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
+                                  float* aux, hos_stream_t stream) {
+    if (!weights7 || !ldw7 || !biases7 || !chain_planes || !aux) return HOS_E_ARG;
+    PackArgs p{};
+    for (int l = 0; l < NL; ++l) {
+        if (!weights7[l] || !biases7[l] || ldw7[l] < 16 * ks_of(l)) return HOS_E_ARG;
+        p.W[l] = weights7[l]; p.ldw[l] = ldw7[l]; p.b[l] = biases7[l];
+    }
+    if (!weights7[NL] || !biases7[NL] || ldw7[NL] < CW) return HOS_E_ARG;
+    p.W6 = weights7[NL]; p.ldw6 = ldw7[NL]; p.b6 = biases7[NL];
+    p.Wc = static_cast<uint16_t*>(chain_planes); p.aux = aux;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3(24, NL + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hos_launch_status();
+}
+
+extern "C" int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, int ldpe, const float* x, const void* chain_planes,
+                                    const float* aux, float* const* acts6, int ldact, float* xyz, int64_t P,
+                                    const int32_t* rows_dev, hos_stream_t stream) {
+    if (!E || !PE || !x || !chain_planes || !aux || !acts6 || !xyz || P <= 0) return HOS_E_ARG;
+    if (lde < 128 || ldpe < 64 || ldact < 128) return HOS_E_SHAPE;
+    if ((lde & 3) || (ldpe & 3) || (ldact & 3) || (((uintptr_t)E | (uintptr_t)PE | (uintptr_t)chain_planes) & 15u)) return HOS_E_ALIGN;
+    ChainArgs a{};
+    a.E = E; a.lde = lde; a.PE = PE; a.ldpe = ldpe; a.x = x; a.Wc = static_cast<const uint16_t*>(chain_planes); a.aux = aux;
+    for (int l = 0; l < NL; ++l) {
+        if (!acts6[l] || ((uintptr_t)acts6[l] & 15u)) return HOS_E_ARG;
+        a.acts[l] = acts6[l];
+    }
+    a.ldact = ldact; a.xyz = xyz; a.P = P; a.p_dev = rows_dev; a.range_flag = hos_range_flag_ptr();
+    constexpr size_t smem = SMEM_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long ntiles = (P + CROWS - 1) / CROWS;
+    static int max_grid = 0;
+    if (max_grid == 0) { const char* e = getenv("HOS_CHAIN_GRID"); max_grid = e ? atoi(e) : 512; if (max_grid <= 0) max_grid = 512; }
+    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    hipLaunchKernelGGL(chain128_kernel, dim3(grid), dim3(CT), smem, static_cast<hipStream_t>(stream), a);
+    return hos_launch_status();
+}

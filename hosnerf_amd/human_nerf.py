@@ -199,6 +199,7 @@ class Network(FlatModule):
         self.human_stateembeds = nn.ParameterList([st.bind(self._embeds, (k, slice(None)), (64,)) for k in range(n_states)])
         self.reset_parameters()
         self._token = torch.zeros(1, requires_grad=True)
+        self._chain_bufs = {}
 
     # ------------------------------------------------------------------ init (U:181-308 initseq rules)
     @torch.no_grad()
@@ -316,6 +317,18 @@ class Network(FlatModule):
         E = torch.empty(Pn, NR_LDE, device=dev)
         PE = torch.empty(Pn, NR_LDPE, device=dev)
         ops.embed_hannw(x, band_w, cond.reshape(-1), E, PE, rows_dev=rows_dev)
+        if ops.MLP_CHAIN and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32:
+            # the whole MLP in one launch, activations on chip across the layers (hos_chain.hip)
+            key = id(specs)
+            bufs = self._chain_bufs.get(key)
+            if bufs is None or bufs[0].device != dev:
+                bufs = self._chain_bufs[key] = ops.mlp_chain_buffers(dev)
+            ws = [self._w(L) for L in specs]
+            ops.mlp_chain_pack([w for w, _ in ws], [b_ for _, b_ in ws], bufs[0], bufs[1])
+            acts = [torch.empty(Pn, 128, device=dev) for _ in range(6)]
+            xyz = torch.empty(Pn, 3, device=dev)
+            ops.mlp_chain128_fwd(E, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=rows_dev)
+            return xyz, ((E, PE, acts) if save else None)
         acts = []
         h = E
         for i in range(6):

@@ -183,6 +183,33 @@ WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "1") == "1"       # planes WGRAD: spli
 WGRAD_WS_MIN = int(os.environ.get("HOS_WGRAD_WS_MIN", "0"))  # ... for gradients of at least this many elements
 
 
+# ------------------------------------------------------------------------------------------ fused MLP chain (hos_chain.hip)
+MLP_CHAIN = os.environ.get("HOS_MLP_CHAIN", "1") != "0"
+MLP_CHAIN_MIN_ROWS = int(os.environ.get("HOS_MLP_CHAIN_MIN_ROWS", "4096"))
+
+
+def mlp_chain_buffers(device):
+    """(chain planes [bytes/2] int16, aux [floats]) for one 6 x 128 MLP -- filled by mlp_chain_pack."""
+    lib = _lib.load()
+    return (torch.empty(int(lib.hos_mlp_chain_weight_bytes()) // 2, dtype=torch.int16, device=device),
+            torch.empty(int(lib.hos_mlp_chain_aux_floats()), device=device))
+
+
+def mlp_chain_pack(weights, biases, planes, aux):
+    """weights: 7 fp32 matrices (views [rows, ld] of the flat parameter buffer, nn.Linear layout), biases: 7 vectors."""
+    import ctypes
+    ldw = (ctypes.c_int * 7)(*[int(w.stride(0)) for w in weights])
+    call("hos_mlp_chain_pack", _ptr_array(list(weights)), ldw, _ptr_array(list(biases)), ptr(planes, torch.int16), ptr(aux))
+
+
+def mlp_chain128_fwd(E, PE, x, planes, aux, acts, xyz, rows_dev=None):
+    """xyz = x + MLP(E | PE) with the six hidden activations written once into `acts` (mlp_offset.py:54-70 in one launch)."""
+    P = x.shape[0]
+    _timed(f"mlp_chain128[M={P}]", 2.0 * P * 101120, lambda: call(
+        "hos_mlp_chain128_fwd", ptr(E), E.stride(0), ptr(PE), PE.stride(0), ptr(x), ptr(planes, torch.int16), ptr(aux), _ptr_array(list(acts)),
+        acts[0].stride(0), ptr(xyz), P, ptr(rows_dev, torch.int32)))
+
+
 # ------------------------------------------------------------------------------------------ fp16 range guard
 _RANGE_FLAG = {}
 RANGE_GUARD = os.environ.get("HOS_RANGE_GUARD", "1") != "0"

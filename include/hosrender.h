@@ -404,6 +404,26 @@ int hos_motion_basis_bwd(const float* g_R_bwd, const float* g_T_bwd, const float
                          float* g_dst_Rs, float* g_dst_Ts, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Forward of a whole non-rigid motion MLP in one launch, activations on chip across the layers (hos_chain.hip):
+ * `NonRigidMotionMLP` / `NonRigidForwardMLP`, non_rigid_motion_mlps/mlp_offset.py:16-70 -- [cond 75 | hann 36] -> 5 x (128,
+ * ReLU) with the hann features re-concatenated before Linear #4 -> 3, xyz = x + offset.  fp16 (hi, lo) x3 products like the split
+ * GEMMs; every hidden activation is written once (fp32 [P, ldact], the backward pass reads them), none is read back.
+ *   hos_mlp_chain_pack    weights7 / ldw7 / biases7: HOST arrays over the 7 linear layers (weights fp32 [128 (3), ld], nn.Linear
+ *                         layout, zero-padded reduction: ld >= 128, the skip layer [h 128 | hann 36 | 0] with ld >= 192) ->
+ *                         chain_planes (hos_mlp_chain_weight_bytes() bytes: per 32-wide output block and 16-wide reduction
+ *                         step the MFMA A fragments, reduction index permuted to the accumulator layout) and aux
+ *                         (hos_mlp_chain_aux_floats() floats: biases + the last layer).  Once per optimiser step.
+ *   hos_mlp_chain128_fwd  E [P, lde >= 128] first-layer rows, PE [P, ldpe >= 64] hann features, x [P,3]; acts6: HOST array of the
+ *                         6 output buffers; xyz [P,3].  rows_dev as for hos_linear_fwd. */
+long long hos_mlp_chain_weight_bytes(void);
+long long hos_mlp_chain_aux_floats(void);
+int hos_mlp_chain_pack(const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
+                       float* aux, hos_stream_t stream);
+int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, int ldpe, const float* x, const void* chain_planes,
+                         const float* aux, float* const* acts6, int ldact, float* xyz, int64_t P,
+                         const int32_t* rows_dev, hos_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Cycle-consistency set (N:505-536): the sample points with fg_likelihood_mask > 0.005.
  * The reference selects them by boolean indexing (data-dependent shape = a host round trip per step);
  * this is an order-preserving stream compaction into fixed-capacity buffers, the count stays on the device.

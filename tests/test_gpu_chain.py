@@ -1,0 +1,116 @@
+"""hos_mlp_chain128_fwd (the non-rigid MLP forward in one launch, activations on chip) against the layer-by-layer path and
+against float64: every hidden activation and the output, ragged row counts, the device-side row limit, and the reference's
+fixture for the whole MLP (`nonrigid_xyz`)."""
+import json
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from hosnerf_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def net():
+    from hosnerf_amd.human_nerf import Network, default_cfg
+    d = tempfile.mkdtemp(prefix="hos_basedir_")
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({"f0": {"time": 0.4}}, f)
+    n = Network(default_cfg(d))
+    n.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+    return n.to(DEV)
+
+
+def _inputs(P, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
+    cond = (torch.randn(75, generator=g) * 0.3).to(DEV)
+    band = torch.tensor([1.0, 1.0, 0.8, 0.3, 0.0, 0.0]).to(DEV)
+    return x, cond, band
+
+
+def _both(net, specs, x, cond, band, rows_dev=None):
+    prev_c, prev_m = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS
+    try:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = True, 1
+        xyz_c, (E, PE, acts_c) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
+        ops.MLP_CHAIN = False
+        xyz_l, (_, _, acts_l) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
+    finally:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = prev_c, prev_m
+    return xyz_c, acts_c, xyz_l, acts_l, E, PE
+
+
+def _ref64(net, specs, E, PE, x):
+    h = E.double()
+    acts = []
+    for i in range(6):
+        W, b = net._w(specs[i])
+        W, b = W.double(), b.double()
+        inp = torch.cat([h, PE.double()], 1) if i == 4 else h
+        h = torch.relu(inp @ W[:128, :inp.shape[1]].T + b[:128])
+        acts.append(h)
+    W, b = net._w(specs[6])
+    return x.double() + h @ W.double()[:3, :128].T + b.double()[:3], acts
+
+
+@pytest.mark.parametrize("P", [1, 31, 128, 129, 1000, 4096 + 77, 65536])
+def test_chain_matches_layers_and_fp64(net, P):
+    for which, specs in (("nr", net._nr), ("nrf", net._nrf)):
+        x, cond, band = _inputs(P, seed=P)
+        with torch.no_grad():
+            xyz_c, acts_c, xyz_l, acts_l, E, PE = _both(net, specs, x, cond, band)
+            ref, racts = _ref64(net, specs, E, PE, x)
+        for l in range(6):
+            scale = max(1.0, float(racts[l].abs().max()))
+            assert float((acts_c[l].double() - racts[l]).abs().max()) < 2e-6 * scale, (which, l)
+            assert float((acts_c[l] - acts_l[l]).abs().max()) < 2e-6 * scale, (which, l)
+        assert float((xyz_c.double() - ref).abs().max()) < 1e-6
+        assert float((xyz_c - xyz_l).abs().max()) < 1e-6
+
+
+def test_chain_respects_the_device_row_count(net):
+    P, n = 5000, 1234
+    x, cond, band = _inputs(P, seed=3)
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    with torch.no_grad():
+        full = _both(net, net._nr, x, cond, band)
+        prev = ops.MLP_CHAIN_MIN_ROWS
+        ops.MLP_CHAIN_MIN_ROWS = 1
+        try:
+            xyz = torch.full((P, 3), 7.0, device=DEV)
+            E = torch.empty(P, 128, device=DEV); PE = torch.empty(P, 64, device=DEV)
+            ops.embed_hannw(x, band, cond, E, PE)
+            bufs = ops.mlp_chain_buffers(DEV)
+            ws = [net._w(L) for L in net._nr]
+            ops.mlp_chain_pack([w for w, _ in ws], [b for _, b in ws], bufs[0], bufs[1])
+            acts = [torch.full((P, 128), 7.0, device=DEV) for _ in range(6)]
+            ops.mlp_chain128_fwd(E, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=cnt)
+        finally:
+            ops.MLP_CHAIN_MIN_ROWS = prev
+    assert torch.equal(xyz[:n], full[0][:n]) and bool((xyz[n:] == 7.0).all())
+    assert torch.equal(acts[5][:n], full[1][5][:n]) and bool((acts[5][n:] == 7.0).all())
+
+
+def test_chain_vs_reference_fixture(net):
+    """The reference's NonRigidMotionMLP on its own hann embedding (tests/golden/human_parts.npz: nonrigid_xyz)."""
+    hp = np.load(os.path.join(HERE, "golden", "human_parts.npz"))
+    b = synth.human_batch(8, seed=3)
+    cn = torch.from_numpy(hp["flbs_pts"]).to(DEV)
+    band = net._band_weights(3e5, DEV)
+    prev_c, prev_m = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS
+    ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = True, 1
+    try:
+        with torch.no_grad():
+            xyz, _ = net._nonrigid_fwd(net._nr, cn, b["dst_posevec"].to(DEV), band, save=False)
+            xyzf, _ = net._nonrigid_fwd(net._nrf, cn, b["dst_posevec"].to(DEV), band, save=False)
+    finally:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = prev_c, prev_m
+    assert float((xyz.cpu() - torch.from_numpy(hp["nonrigid_xyz"])).abs().max()) < 2e-6
+    assert float((xyzf.cpu() - torch.from_numpy(hp["nonrigid_fwd_xyz"])).abs().max()) < 2e-6
