@@ -4,7 +4,8 @@
 PRIMARY line (the `value` / `ms_per_step` / `roofline` of the one JSON line):
   BASELINE configs[3] -- stage-3 full HOSNeRF (background mip-NeRF-360 + human-object branch + z-merged composite + MSE /
   flow / cycle losses + two flat Adam updates), **4096 rays per step GLOBAL, STRONG scaling**: 4096 / N rays per GPU, every
-  rank's flat gradients (38 MB background + 259 MB human) all-reduced over RCCL.  This is the series the north-star's
+  rank's gradients all-reduced over RCCL: 38 MB background + 4 MB human + the 3.5 MB volume gradient -- the 253 MB gradient of
+  the human network's volume decoder (replicated forward, no ray enters it) is reduced at the decoder's OUTPUT instead.  This is the series the north-star's
   ">= 6x at 8 GPUs" refers to.  At N = 1 all 4096 rays run on one GPU.
 SECONDARY objects in the same line (`stages`):
   stage2  BASELINE configs[2] -- the reference's stage-2 step (human-object network with its in-network composite, 0.2 MSE on
@@ -71,6 +72,10 @@ class Workload:
 
     name = ""
     scaling = "weak"
+    static_vol_grad = None
+
+    def freeze_static(self):
+        """After the first half of a step has been captured: remember the tensors the eager collectives act on."""
 
     def fwd_bwd(self, i):
         raise NotImplementedError
@@ -81,10 +86,24 @@ class Workload:
     def lr(self, i):
         raise NotImplementedError
 
+    def reduce(self):
+        """Eager collectives between the two captured halves of a step (N > 1): flat-gradient all-reduces."""
+        from hosnerf_amd.train import allreduce_flat_grad
+        for o in self.opts():
+            allreduce_flat_grad(o.module, o.group)
+
+    def finish(self, i, dynamic):
+        """Second half: optimiser steps on the (already reduced) gradients."""
+        for o in self.opts():
+            if dynamic:
+                o.step(dynamic=True, reduced=True)
+            else:
+                o.step(self.lr(i), reduced=True)
+
     def eager_step(self, i):
         loss = self.fwd_bwd(i)
-        for o in self.opts():
-            o.step(self.lr(i))
+        self.reduce()
+        self.finish(i, False)
         return loss
 
 
@@ -134,6 +153,17 @@ def _human_item(rays, rank, stage):
     return b, prepare_patch_targets(b)
 
 
+def _reduce_human(net, opt, static_g=None):
+    """The human network's exchange: the volume gradient (3.5 MB) + every parameter outside the volume decoder (4.3 MB).
+    `static_g`: the volume-gradient tensor of a captured step (its address is fixed by the graph's memory pool)."""
+    import torch.distributed as dist
+    from hosnerf_amd.train import allreduce_flat_grad
+    g = static_g if static_g is not None else net.pending_volume_grad()
+    if g is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(opt.group) > 1:
+        dist.all_reduce(g, group=opt.group)
+    allreduce_flat_grad(net, opt.group, net.reduce_ranges())
+
+
 class Stage2(Workload):
     name, scaling = "stage2", "strong"
     describe = ("BASELINE configs[2]: stage-2 human-object network (pose refiner + motion bases + volume decoder, backward LBS, "
@@ -167,10 +197,21 @@ class Stage2(Workload):
     def fwd_bwd(self, i):
         from hosnerf_amd.train import stage2_losses
         self.opt.zero_grad()
+        self.net.split_decoder_backward = True          # the 253 MB decoder gradient is reduced at the decoder's 3.5 MB output
         out = self.net(static_cycle=True, **self.batch)
         loss, _ = stage2_losses(out, self.batch)
         loss.backward()
         return loss.detach()
+
+    def reduce(self):
+        _reduce_human(self.net, self.opt, self.static_vol_grad)
+
+    def freeze_static(self):
+        self.static_vol_grad = self.net.pending_volume_grad()
+
+    def finish(self, i, dynamic):
+        self.net.finish_decoder_backward()
+        Workload.finish(self, i, dynamic)
 
 
 class Stage3(Workload):
@@ -210,10 +251,23 @@ class Stage3(Workload):
         from hosnerf_amd.train import stage3_losses
         self.ob.zero_grad()
         self.oh.zero_grad()
+        self.hos.human.split_decoder_backward = True
         out = self.hos.render(self.batch, randomized=True, is_train=True, static_cycle=True)
         loss, _ = stage3_losses(out, self.batch)
         loss.backward()
         return loss.detach()
+
+    def reduce(self):
+        from hosnerf_amd.train import allreduce_flat_grad
+        allreduce_flat_grad(self.hos.model, self.ob.group)
+        _reduce_human(self.hos.human, self.oh, self.static_vol_grad)
+
+    def freeze_static(self):
+        self.static_vol_grad = self.hos.human.pending_volume_grad()
+
+    def finish(self, i, dynamic):
+        self.hos.human.finish_decoder_backward()
+        Workload.finish(self, i, dynamic)
 
 
 # ------------------------------------------------------------------------------------------------ timing
@@ -230,8 +284,8 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
         wl.host_prepare(i)
         wl.eager_step(i)
     barrier()
-    graph, static_loss, launch = None, None, "eager"
-    full_graph = world == 1        # RCCL stays outside the captured region: fwd+bwd graph, eager all-reduce + optimiser
+    graph, graph2, static_loss, launch = None, None, None, "eager"
+    full_graph = world == 1        # RCCL stays outside the captured region: two graphs with the eager collectives in between
     if not args.no_graph:
         try:
             for o in wl.opts():
@@ -241,26 +295,32 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
             with torch.cuda.stream(side):
                 for _ in range(2):
                     wl.fwd_bwd(args.warmup)
-                    for o in wl.opts():
-                        o.step(dynamic=True)
+                    wl.reduce()
+                    wl.finish(args.warmup, True)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local" if world > 1 else "global"):
+            mode = "thread_local" if world > 1 else "global"
+            with torch.cuda.graph(graph, capture_error_mode=mode):
                 static_loss = wl.fwd_bwd(args.warmup)
                 if full_graph:
-                    for o in wl.opts():
-                        o.step(dynamic=True)
+                    wl.finish(args.warmup, True)
+            if not full_graph:
+                wl.freeze_static()
+                wl.reduce()
+                graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
+                    wl.finish(args.warmup, True)
             for _ in range(2):
                 for o in wl.opts():
                     o.set_step_hyper(wl.lr(args.warmup))
                 graph.replay()
                 if not full_graph:
-                    for o in wl.opts():
-                        o.step(dynamic=True)
+                    wl.reduce()
+                    graph2.replay()
             torch.cuda.synchronize()
-            launch = "hipGraph replay" if full_graph else "hipGraph replay (fwd+bwd) + eager all-reduce/Adam"
+            launch = "hipGraph replay" if full_graph else "hipGraph replay (fwd+bwd) + eager all-reduce + hipGraph replay (decoder bwd + Adam)"
         except Exception as e:      # fall back to eager launches, and say so in the JSON
             print(f"[bench] {wl.name}: graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
@@ -275,8 +335,8 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                 o.set_step_hyper(wl.lr(step))
             graph.replay()
             if not full_graph:
-                for o in wl.opts():
-                    o.step(dynamic=True)
+                wl.reduce()
+                graph2.replay()
             loss = static_loss
         else:
             loss = wl.eager_step(step)

@@ -46,16 +46,23 @@ def stage1_lr(step: int, max_steps: int, lr_init: float = 2.0e-3, lr_final: floa
     return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
-def allreduce_flat_grad(module: FlatModule, group=None) -> int:
+def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
     """Sum the flat gradient over the data-parallel group (RCCL on MI355X, gloo in the CPU tests) and return
     the world size; the 1/world averaging is folded into the Adam kernel's grad_scale.
     ONE collective per step over the whole gradient: xGMI is point-to-point, so a single large message keeps
-    every link busy (DDP's default 25 MB buckets would split the 38 MB stage-1 gradient in two)."""
+    every link busy (DDP's default 25 MB buckets would split the 38 MB stage-1 gradient in two).
+    `ranges` [(offset, numel), ...] restricts the exchange to those spans (the human network's volume decoder is reduced at
+    its 3.5 MB output instead of its 253 MB of parameters, Network.decoder_backward)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
     if world > 1:
-        dist.all_reduce(module.flat_grad, group=group)
+        if ranges is None:
+            dist.all_reduce(module.flat_grad, group=group)
+        else:
+            for off, n in ranges:
+                if n > 0:
+                    dist.all_reduce(module.flat_grad[off:off + n], group=group)
     return world
 
 
@@ -322,15 +329,28 @@ def human_lr_decay(step: int, lrate_decay: int = 500) -> float:
     return 0.1 ** (step / (lrate_decay * 1000.0))
 
 
+def backward_human(net, loss: torch.Tensor, opt: "FusedAdam", group=None):
+    """loss.backward() for a step that contains the human network, data-parallel aware: the volume decoder's backward runs
+    after the all-reduce of its 3.5 MB output gradient (Network.decoder_backward), the rest of the flat gradient is
+    exchanged here, and `opt.step(..., reduced=True)` must follow.  Equivalent to loss.backward() + a whole-buffer all-reduce."""
+    if not net.split_decoder_backward:
+        raise RuntimeError("backward_human: set net.split_decoder_backward = True before the forward pass")
+    loss.backward()
+    net.decoder_backward(group)
+    allreduce_flat_grad(net, group, net.reduce_ranges())
+    net.split_decoder_backward = False
+
+
 def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, t_rand=None):
     """One stage-2 optimisation step (M2:571-605 training_step + :606-634 optimizer_step): the human-object network with its
     in-network composite, 0.2 MSE on the unpacked patches + 0.01 flow + 0.01 cycle, backward, flat Adam with the
     per-module learning rates.  `batch` comes from `prepare_patch_targets` + `batch_to_device`."""
     opt.zero_grad()
+    net.split_decoder_backward = True
     out = net(t_rand=t_rand, static_cycle=True, **batch)
     loss, parts = stage2_losses(out, batch)
-    loss.backward()
-    opt.step(lr)
+    backward_human(net, loss, opt, opt.group)
+    opt.step(lr, reduced=True)
     return loss.detach(), parts
 
 
@@ -340,9 +360,10 @@ def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dic
     losses + backward + the two flat Adam updates."""
     opt_bkgd.zero_grad()
     opt_human.zero_grad()
+    hos.human.split_decoder_backward = True
     out = hos.render(batch, randomized=True, is_train=True, static_cycle=True)
     loss, parts = stage3_losses(out, batch)
-    loss.backward()
+    backward_human(hos.human, loss, opt_human, opt_human.group)
     opt_bkgd.step(lr)
-    opt_human.step(lr)
+    opt_human.step(lr, reduced=True)
     return loss.detach(), parts

@@ -1,3 +1,1 @@
-for c in 0 1 0 1; do HOS_MLP_CHAIN=$c python bench.py --primary stage2 --only-primary --steps 20 --warmup 3 --no-kernel-events 2>/dev/null | python -c "
-import json,sys,os
-d=json.loads(sys.stdin.readline()); print('chain', os.environ.get('C'), d['value'], d['ms_per_step'])"; done
+python -m pytest tests/test_gpu_speedup.py -x -q 2>&1 | grep -E "^E  |passed|failed" | cut -c1-600 | head -12
