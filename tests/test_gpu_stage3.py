@@ -98,6 +98,9 @@ def test_stage3_step_vs_golden(dev, hos, tag, B, seed):
     # background sample that sits within that noise of a human sample may legitimately swap places:
     want = st[p + "total_order"]
     if want.size:
+        from tests._record import record
+        record(f"stage3.total_order_mismatch_end_to_end[{tag}]", {"mismatching_entries": int(np.sum(order[fg] != want)), "of": int(want.size),
+               "rgb_linf": maxerr(out["rgb"], st[p + "rgb"])})
         assert np.mean(order[fg] != want) < 0.01
     # ... the bit-exact index check therefore feeds the kernel the SAME inputs the reference composite saw
     # (oracle tensors, themselves pinned to the reference in tests/test_oracle_golden_human.py)
@@ -115,6 +118,9 @@ def test_stage3_step_vs_golden(dev, hos, tag, B, seed):
             human["newsmpl_pts"].to(dev), human["pts_mask"].to(dev), gb["rays_o_bkg"], gb["rays_d_bkg"], gb["newsmpl_to_scale_world"])
     fg2 = idx_fg.cpu().numpy().astype(bool)
     assert np.array_equal(fg2, st[p + "idx_fg"])
+    from tests._record import record
+    record(f"stage3.total_order_mismatch_identical_inputs[{tag}]", {"mismatching_entries": int(np.sum(order2.cpu().numpy().astype(np.int64)[fg2] != want)),
+           "of": int(want.size)})
     assert np.array_equal(order2.cpu().numpy().astype(np.int64)[fg2], want), "merge order (total_order) must be bit-exact"
     assert maxerr(rgb, st[p + "rgb"]) < 2e-5
     assert maxerr(hw[torch.from_numpy(fg2).to(dev)], st[p + "human_weights_onlyfg"]) < 2e-5
