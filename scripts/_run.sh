@@ -1,1 +1,1 @@
-python -m pytest tests -m gpu -q 2>&1 | tail -8
+bash scripts/pmc_gemmp_r02.sh 2>&1 | tail -70
