@@ -396,6 +396,17 @@ class Network(FlatModule):
         CAT[:, CNL_CAT - 1].zero_()
         embed = self._embeds.view(self.store.param)[state]
         ops.embed_fourier(cnl, 10, embed, E, CAT)
+        if ops.MLP_CHAIN and ops.MLP_CHAIN256 and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32:
+            # the whole canonical MLP in one launch, activations on chip across the eight layers (hos_chain.hip)
+            bufs = self._chain_bufs.get("cnl")
+            if bufs is None or bufs[0].device != dev:
+                bufs = self._chain_bufs["cnl"] = ops.mlp_chain256_buffers(dev)
+            ws = [self._w(L) for L in self._cnl]
+            ops.mlp_chain256_pack([w for w, _ in ws], [b_ for _, b_ in ws], bufs[0], bufs[1])
+            acts = [CAT if i == 4 else torch.empty(Pn, 256, device=dev) for i in range(8)]
+            raw = torch.empty(Pn, 4, device=dev)
+            ops.mlp_chain256_fwd(E, bufs[0], bufs[1], acts, [127 if i == 4 else 0 for i in range(8)], raw)
+            return raw, ((E, acts) if save else None)
         acts = []
         h = E
         for i in range(8):

@@ -1,1 +1,1 @@
-bash scripts/pmc_gemmp_r02.sh 2>&1 | tail -70
+python -m pytest tests/test_gpu_chain.py -x -q 2>&1 | tail -3
