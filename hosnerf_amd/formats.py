@@ -167,3 +167,139 @@ def load_scene(basedir: str, image_hw: Tuple[int, int], masks: Optional[np.ndarr
     if masks is not None:
         out["bkgrays_sizes"] = np.sum(np.asarray(masks, dtype=np.float32) < 1, axis=(1, 2))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ skeleton files (stages 2 / 3)
+# mesh_infos.pkl        {frame: {poses [72], tpose_joints [24,3], joints [24,3], Rh, Th, ...}} per-frame SMPL fits
+# canonical_joints.pkl  {joints [24,3]} canonical T-pose
+# The two object joints are extrapolated from the hands (3rd_Complete_HOSNeRF/core/data/human_nerf/train.py:132-191); the
+# per-frame network inputs are derived with core/utils/body_util.py:211-369.
+SMPL_PARENT = {1: 0, 2: 0, 3: 0, 4: 1, 5: 2, 6: 3, 7: 4, 8: 5, 9: 6, 10: 7, 11: 8, 12: 9, 13: 9, 14: 9, 15: 12,
+               16: 13, 17: 14, 18: 16, 19: 17, 20: 18, 21: 19, 22: 20, 23: 21, 24: 23, 25: 22}
+_TORSO = (0, 3, 6, 9, 13, 14)
+_HEAD, _OBJ_R, _OBJ_L = 15, 24, 25
+
+
+def add_object_joints(joints24: np.ndarray) -> np.ndarray:
+    """[24,3] -> [26,3]: right object joint = J23 + (J23 - J19), left = J22 + (J22 - J18) (train.py:136-140, 167-174)."""
+    j = np.asarray(joints24, dtype=np.float32)
+    return np.concatenate([j, (j[23] + (j[23] - j[19]))[None], (j[22] + (j[22] - j[18]))[None]], 0)
+
+
+def skeleton_bbox(joints: np.ndarray, offset: float = 0.6) -> Dict[str, np.ndarray]:
+    return {"min_xyz": np.min(joints, axis=0) - offset, "max_xyz": np.max(joints, axis=0) + offset}
+
+
+def load_canonical_joints(path: str, bbox_offset: float = 0.6):
+    with open(path, "rb") as f:
+        joints = add_object_joints(pickle.load(f)["joints"].astype("float32"))
+    return joints, skeleton_bbox(joints, bbox_offset)
+
+
+def load_mesh_infos(path: str, bbox_offset: float = 0.6) -> Dict:
+    """train.py:160-181: 26-joint T-pose, 78-vector pose (object joints carry zero rotation), per-frame bbox of the posed joints."""
+    with open(path, "rb") as f:
+        infos = pickle.load(f)
+    for name in infos:
+        m = infos[name]
+        m["tpose_joints"] = add_object_joints(m["tpose_joints"])
+        m["poses"] = np.concatenate([m["poses"].astype("float32"), np.zeros(6, dtype="float32")], 0)
+        m["bbox"] = skeleton_bbox(m["joints"], bbox_offset)
+    return infos
+
+
+def _rodrigues(rvec: np.ndarray) -> np.ndarray:
+    """body_util.py:211-230 (the axis is normalised by norm + 1e-5)."""
+    v = np.asarray(rvec, dtype=np.float64).reshape(3, 1)
+    theta = np.linalg.norm(v)
+    r = v / (theta + 1e-5)
+    x, y, z = r.ravel()
+    skew = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
+    return np.cos(theta) * np.eye(3) + np.sin(theta) * skew + (1 - np.cos(theta)) * r.dot(r.T)
+
+
+def body_pose_to_body_RTs(jangles: np.ndarray, tpose_joints: np.ndarray):
+    """body_util.py:233-259: per-joint local rotation (Rodrigues) and translation (offset to the parent in the T-pose)."""
+    ja = np.asarray(jangles).reshape(-1, 3)
+    K = ja.shape[0]
+    assert tpose_joints.shape[0] == K
+    Rs = np.zeros((K, 3, 3), dtype="float32")
+    Ts = np.zeros((K, 3), dtype="float32")
+    for i in range(K):
+        Rs[i] = _rodrigues(ja[i])
+        Ts[i] = tpose_joints[i] if i == 0 else tpose_joints[i] - tpose_joints[SMPL_PARENT[i]]
+    return Rs, Ts
+
+
+def get_canonical_global_tfms(canonical_joints: np.ndarray) -> np.ndarray:
+    """body_util.py:262-282: chain of pure translations along the tree."""
+    K = canonical_joints.shape[0]
+    g = np.zeros((K, 4, 4), dtype="float32")
+    for i in range(K):
+        L = np.eye(4, dtype="float32")
+        L[:3, 3] = canonical_joints[i] if i == 0 else canonical_joints[i] - canonical_joints[SMPL_PARENT[i]]
+        g[i] = L if i == 0 else g[SMPL_PARENT[i]].dot(L)
+    return g
+
+
+def _rotation_between(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """body_util.py:96-125 for one pair (float32 result)."""
+    a = a / np.clip(np.linalg.norm(a), 1e-5, None)
+    b = b / np.clip(np.linalg.norm(b), 1e-5, None)
+    n = np.cross(a, b)
+    c = a.dot(b)
+    skew = np.array([[0, -n[2], n[1]], [n[2], 0, -n[0]], [-n[1], n[0], 0]], dtype=np.float32)
+    return (np.eye(3) + skew + skew.dot(skew) * (1.0 / (1.0 + c))).astype(np.float32)
+
+
+def _gaussian_volume(grid_size, bmin, bmax, center, S, R):
+    """body_util.py:149-190: exp(-d^T (R S S R^T) d) on the [z][y][x] grid of the box."""
+    sigma = R.dot(S).dot(S).dot(R.T)
+    zg, yg, xg = np.meshgrid(np.linspace(bmin[2], bmax[2], grid_size), np.linspace(bmin[1], bmax[1], grid_size),
+                             np.linspace(bmin[0], bmax[0], grid_size), indexing="ij")
+    d = np.stack([xg - center[0], yg - center[1], zg - center[2]], axis=-1)
+    return np.exp(-1 * np.einsum("abci, abci->abc", np.einsum("abci, ij->abcj", d, sigma), d))
+
+
+def approx_gaussian_bone_volumes(tpose_joints: np.ndarray, bbox_min_xyz, bbox_max_xyz, grid_size: int = 32) -> np.ndarray:
+    """body_util.py:285-369: one Gaussian per bone (sum over the bones that start at a joint; isotropic blobs at the leaves, wider
+    for the head and the two object joints), plus the background channel; [K+1, V, V, V] normalised over the channels."""
+    tj = tpose_joints.astype(np.float32)
+    K = tj.shape[0]
+    up = np.array([0.0, 1.0, 0.0], dtype=np.float32)
+
+    def scale_mtx(stds):
+        return np.diag(1.0 / np.asarray(stds, dtype=np.float32)).astype(np.float32)
+
+    vols = []
+    for j in range(K):
+        vol = np.zeros((grid_size,) * 3, dtype="float32")
+        parent_of_any = False
+        for bone, par in SMPL_PARENT.items():
+            if par != j:
+                continue
+            S = scale_mtx(np.array([0.03, 0.06, 0.03]) * 2.0)
+            if j in _TORSO:
+                S[0][0] *= 1 / 1.5
+                S[2][2] *= 1 / 1.5
+            a, b = tj[SMPL_PARENT[bone]], tj[bone]
+            vol = vol + _gaussian_volume(grid_size, bbox_min_xyz, bbox_max_xyz, (a + b) / 2.0, S, _rotation_between(up, b - a))
+            parent_of_any = True
+        if not parent_of_any:
+            stds = np.array([0.06] * 3) if j in (_HEAD, _OBJ_R, _OBJ_L) else np.array([0.02] * 3)
+            vol = _gaussian_volume(grid_size, bbox_min_xyz, bbox_max_xyz, tj[j], scale_mtx(stds * 2.0), np.eye(3, dtype="float32"))
+        vols.append(vol)
+    g = np.stack(vols, 0)
+    g = np.concatenate([g, 1.0 - np.sum(g, axis=0, keepdims=True).clip(min=0.0, max=1.0)], 0)
+    return g / np.sum(g, axis=0, keepdims=True).clip(min=0.001)
+
+
+def skeleton_item(mesh_info: Dict, canonical_joints: np.ndarray, canonical_bbox: Dict, volume_size: int = 32) -> Dict[str, np.ndarray]:
+    """The pose part of a training item (train.py:640-727): dst_Rs / dst_Ts / cnl_gtfms / motion_weights_priors / dst_posevec and
+    the canonical box, from one frame of mesh_infos.pkl and canonical_joints.pkl."""
+    Rs, Ts = body_pose_to_body_RTs(mesh_info["poses"], mesh_info["tpose_joints"])
+    bmin, bmax = canonical_bbox["min_xyz"].astype("float32"), canonical_bbox["max_xyz"].astype("float32")
+    return {"dst_Rs": Rs, "dst_Ts": Ts, "cnl_gtfms": get_canonical_global_tfms(canonical_joints),
+            "motion_weights_priors": approx_gaussian_bone_volumes(canonical_joints, bmin, bmax, volume_size).astype("float32"),
+            "dst_posevec": mesh_info["poses"][3:] + 1e-2, "cnl_bbox_min_xyz": bmin, "cnl_bbox_max_xyz": bmax,
+            "cnl_bbox_scale_xyz": 2.0 / (bmax - bmin)}

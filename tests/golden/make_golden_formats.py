@@ -70,8 +70,29 @@ def main():
            "i_test": i_split[2], "i_all": i_split[3], "render_poses": render_poses, "bkgrays_sizes": bkg, "times": times, "render_times": render_times,
            "csw_smpl_to_scale_world": np.stack([csw[k]["smpl_to_scale_world"] for k in names]),
            "csw_scaleworld_to_camera": np.stack([csw[k]["scaleworld_to_camera"] for k in names])}
+    out.update(skeleton_golden())
     np.savez_compressed(os.path.join(HERE, "formats.npz"), **out)
     print("formats.npz", os.path.getsize(os.path.join(HERE, "formats.npz")) / 1024, "KB", extr.shape, render_poses.shape)
+
+
+def skeleton_golden():
+    """The reference's own body_util functions (3rd_Complete_HOSNeRF/core/utils/body_util.py) on a synthetic SMPL fit."""
+    rs = np.random.RandomState(11)
+    from hosnerf_amd import synth
+    tj24 = synth.tpose_joints()[:24].astype(np.float32)
+    poses72 = (rs.standard_normal(72) * 0.25).astype(np.float32)
+    joints24 = tj24 + rs.normal(0, 0.05, tj24.shape).astype(np.float32)
+    with refload.stage(3):
+        import importlib
+        B = importlib.import_module("core.utils.body_util")
+        tj26 = np.concatenate([tj24, (tj24[23] + (tj24[23] - tj24[19]))[None], (tj24[22] + (tj24[22] - tj24[18]))[None]], 0)
+        p78 = np.concatenate([poses72, np.zeros(6, np.float32)])
+        Rs, Ts = B.body_pose_to_body_RTs(p78, tj26)
+        g = B.get_canonical_global_tfms(tj26)
+        bmin, bmax = tj26.min(0) - 0.6, tj26.max(0) + 0.6
+        vol = B.approx_gaussian_bone_volumes(tj26, bmin, bmax, grid_size=32).astype(np.float32)
+    return {"sk_tpose24": tj24, "sk_poses72": poses72, "sk_joints24": joints24, "sk_Rs": Rs, "sk_Ts": Ts, "sk_gtfms": g,
+            "sk_vol_sub": vol[:, ::4, ::4, ::4], "sk_vol_sum": vol.astype(np.float64).sum(), "sk_vol_max": vol.max(axis=(1, 2, 3))}
 
 
 if __name__ == "__main__":

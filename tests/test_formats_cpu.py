@@ -57,3 +57,27 @@ def test_cameras_scaleworld_file_matches_the_reference_loader():
     A = csw[names[0]]["smpl_to_scale_world"][:3, :3].astype(np.float64)
     sc = np.cbrt(np.linalg.det(A))
     assert sc > 0 and np.abs((A / sc) @ (A / sc).T - np.eye(3)).max() < 1e-5
+
+
+def test_skeleton_files_match_the_reference_body_util():
+    """mesh_infos.pkl / canonical_joints.pkl -> network inputs, against the reference's own body_util functions."""
+    d = tempfile.mkdtemp(prefix="hos_scene_")
+    with open(os.path.join(d, "mesh_infos.pkl"), "wb") as f:
+        pickle.dump({"frame_000000": {"poses": G["sk_poses72"], "tpose_joints": G["sk_tpose24"], "joints": G["sk_joints24"],
+                                      "Rh": np.zeros(3, np.float32), "Th": np.zeros(3, np.float32)}}, f)
+    with open(os.path.join(d, "canonical_joints.pkl"), "wb") as f:
+        pickle.dump({"joints": G["sk_tpose24"]}, f)
+    infos = formats.load_mesh_infos(os.path.join(d, "mesh_infos.pkl"))
+    cj, cbox = formats.load_canonical_joints(os.path.join(d, "canonical_joints.pkl"))
+    m = infos["frame_000000"]
+    assert m["tpose_joints"].shape == (26, 3) and m["poses"].shape == (78,) and cj.shape == (26, 3)
+    assert np.allclose(m["bbox"]["min_xyz"], G["sk_joints24"].min(0) - 0.6) and np.allclose(cbox["max_xyz"], cj.max(0) + 0.6)
+    item = formats.skeleton_item(m, cj, cbox)
+    assert np.abs(item["dst_Rs"] - G["sk_Rs"]).max() < 1e-6 and np.abs(item["dst_Ts"] - G["sk_Ts"]).max() < 1e-7
+    assert np.abs(item["cnl_gtfms"] - G["sk_gtfms"]).max() < 1e-6
+    vol = item["motion_weights_priors"]
+    assert vol.shape == (27, 32, 32, 32) and vol.dtype == np.float32
+    assert np.abs(vol[:, ::4, ::4, ::4] - G["sk_vol_sub"]).max() < 1e-6
+    assert abs(vol.astype(np.float64).sum() - float(G["sk_vol_sum"])) < 1e-2 and np.abs(vol.max(axis=(1, 2, 3)) - G["sk_vol_max"]).max() < 1e-6
+    assert item["dst_posevec"].shape == (75,) and np.allclose(item["dst_posevec"], m["poses"][3:] + 1e-2)
+    assert np.allclose(item["cnl_bbox_scale_xyz"], 2.0 / (cbox["max_xyz"] - cbox["min_xyz"]))
