@@ -43,6 +43,11 @@
 #ifndef HOS_NO_SETPRIO
 #define HOS_NO_SETPRIO 0
 #endif
+// 1 / 2: the B waves issue their DMA requests in group 1 / 2 of the NEXT iteration instead of group 4 (0: both in group 4).
+// Measured at [131072,1024,1024]: fwd 730 -> 705 us, dgrad 825 -> 805 us, wgrad unchanged.
+#ifndef HOS_DMA_STAGGER
+#define HOS_DMA_STAGGER 1
+#endif
 
 namespace {
 
@@ -78,6 +83,8 @@ struct PArgs {
     const uint16_t* mask; int ldmask;             // DGRAD: fp16 planes of the layer input; gradient passes where hi > 0
     uint16_t* Y; int ldy;                         // row-major planes [M][ldy]: fp16 for FWD, bf16 for DGRAD
     uint16_t* Yb; int ldyb;                       // FWD only: the same values as bf16 planes (WGRAD operand)
+    uint32_t* bits; int bits_nb;                  // ReLU bit mask (FWD writes, DGRAD reads), 64-column blocks per row block
+    int stagger;                                  // experiment: first-round workgroups start ((bid>>3)&7) * stagger * ~4 us late
 };
 
 template <typename E> __device__ __forceinline__ uint16_t to_bits(E v) { return __builtin_bit_cast(uint16_t, v); }
@@ -139,6 +146,10 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int kt_begin = split * a.kt_per_split;
     const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;
+    if (a.stagger > 0 && blockIdx.x < 256) {
+        const int g = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- DMA plan of this wave -----------------------------------------------------------------------------------
     const bool isB = wave >= 4;                  // waves 0-3 stage the A tile, waves 4-7 the B tile
@@ -402,9 +413,22 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
         const int dstage = so ? 1 : 0;
         HOS_STAMP(0);
+        // experiment HOS_DMA_STAGGER = g: the B waves (weights: L2 hits, short latency) request tile kt+1 in group g of
+        // this iteration instead of in the last group of the previous one, so the two waves of a SIMD (one A wave, one
+        // B wave) never stall on DMA issue together
+        auto stag_dma = [&](int i) {
+            constexpr int D0 = NM / 3, ND = NM - D0;
+            if (!HOS_ABLATE_DMA && isB && more1 && kt > kt_begin && i >= D0) {
+#pragma unroll
+                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 1, dstage ^ 1);
+            }
+        };
         auto fill1 = [&](int i) {                // under (A0,B0): B1 = (s0, yh1)
             if (i == 1) HOS_READ_B1(b1h, b1l, so, 0, 1, 0);
             if (i == 3) HOS_READ_B1(b1h, b1l, so, 0, 1, 1);
+#if HOS_DMA_STAGGER == 1
+            stag_dma(i);
+#endif
         };
         HOS_GROUP(a0h, a0l, b0h, b0l, 0, fill1);
         HOS_STAMP(1);
@@ -413,6 +437,9 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             if (i == 1) HOS_READ_A1(a1h, a1l, so, 1, 1);
             if (i == 2) HOS_READ_B1(b0h, b0l, so, 1, 0, 0);
             if (i == 3) HOS_READ_B1(b0h, b0l, so, 1, 0, 1);
+#if HOS_DMA_STAGGER == 2
+            stag_dma(i);
+#endif
         };
         HOS_GROUP(a0h, a0l, b1h, b1l, 1, fill2);
         HOS_STAMP(2);
@@ -436,7 +463,11 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 if (i == 3) HOS_READ_B1(b0h, b0l, sn, 0, 0, 1);
             }
             constexpr int D0 = NM / 3, ND = NM - D0;          // DMA slots: the last two thirds of the group
+#if HOS_DMA_STAGGER
+            if (!HOS_ABLATE_DMA && more2 && !isB && i >= D0) {
+#else
             if (!HOS_ABLATE_DMA && more2 && i >= D0) {
+#endif
 #pragma unroll
                 for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 2, dstage);
             }
@@ -493,9 +524,31 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         // Plane outputs.  Every wave owns 8 KB of the (now idle) stage memory.  Per (x, pair of y) = 32 rows x 64
         // columns: each lane packs (hi, lo) of its values into one dword and writes it at [row][col] (ds_write_b32,
         // 32 consecutive dwords per half wave: conflict free); after the wave's own writes have landed every lane
-        // reads 16 bytes = four consecutive columns of one row and stores 8 bytes to the hi half and 8 to the lo half
-        // of the column block -- 16 lanes per row, so a hi/lo store pair writes four rows x two whole 128-byte lines.
+        // reads 32 bytes = eight consecutive columns of one row, keeps their hi or their lo halves and stores 16 bytes.
+        // ReLU mask of the backward pass: FWD can emit one BIT per output element in ACCUMULATOR layout (a.bits: per
+        // 32-row x 64-column block 64 dwords, dword = lane, bit 16 yy + r = element (row (r&3) + 8 (r>>2) + 4 (lane>>5),
+        // column 32 yy + (lane&31)) of the block), and DGRAD, whose accumulators have the same layout, reads its own dword
+        // back: 8 KB per tile instead of the 256 KB of the fp16 planes of the layer input (whose fetch at ~11 B/clk/CU
+        // cost ~16 us at the end of every tile: 110 us of an 817 us launch at M = 131072).
+        uint32_t bw[TM][TN / 2];                                  // DGRAD: this lane's dword of each block's bit mask
+        if constexpr (EPI == PEPI_PLANES_DGRAD) {
+            if (a.bits != nullptr) {
+#pragma unroll
+                for (int x = 0; x < TM; ++x)
+#pragma unroll
+                    for (int yp = 0; yp < TN / 2; ++yp) {
+                        const int rb = (i0 + wm * (TM * 32) + x * 32) >> 5, cbk = (j0 + wn * (TN * 32) + yp * 64) >> 6;
+                        bw[x][yp] = (rb * 32 < a.M && cbk < a.bits_nb) ? a.bits[((size_t)rb * a.bits_nb + cbk) * 64 + lane] : 0u;
+                    }
+            }
+        }
         asm volatile("s_barrier" ::: "memory");                   // all waves are done with the stage memory
+#ifdef HOS_EXP_NO_EPI
+        { float sacc = 0.f;
+          for (int x = 0; x < TM; ++x) for (int y = 0; y < TN; ++y) for (int r = 0; r < 16; ++r) sacc += acc[x][y][r];
+          if (sacc == 1.2345f) a.Y[0] = 1;
+          return; }
+#endif
         char* const stg = smemp + wave * 8192;
         const bool dual = (EPI == PEPI_PLANES_FWD) && a.Yb != nullptr;
         const bool first = a.Y != nullptr;
@@ -506,6 +559,8 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             for (int yp = 0; yp < TN / 2; ++yp) {
                 const int row0 = i0 + wm * (TM * 32) + x * 32;
                 const int col0 = j0 + wn * (TN * 32) + yp * 64;
+                uint32_t mybits = 0u;                                 // FWD: v > 0 of this lane's 32 values of the block (bit 16 yy + r)
+                const uint32_t keepbits = (EPI == PEPI_PLANES_DGRAD && a.bits != nullptr) ? bw[x][yp] : 0xffffffffu;
 #pragma unroll
                 for (int fmt = 0; fmt < 2; ++fmt) {
                     if (fmt == 0 && !first) continue;
@@ -520,6 +575,8 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                             float v = acc[x][2 * yp + yy][r] + bcol;
                             if (EPI == PEPI_PLANES_FWD && a.relu) v = fmaxf(v, 0.f);
                             if (col >= a.N) v = 0.f;                                   // zero the padding columns
+                            if (EPI == PEPI_PLANES_FWD && fmt == 0) mybits |= (v > 0.f ? 1u : 0u) << (yy * 16 + r);
+                            if (EPI == PEPI_PLANES_DGRAD && !((keepbits >> (yy * 16 + r)) & 1u)) v = 0.f;
                             const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
                             uint32_t p;
                             if (EPI == PEPI_PLANES_FWD && fmt == 0) { p = split_pack<_Float16>(v); big |= fabsf(v) > HOS_RANGE_LIMIT; }
@@ -530,32 +587,45 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     uint16_t* const Po = fmt == 0 ? a.Y : a.Yb;
                     const int ldo = fmt == 0 ? a.ldy : a.ldyb;
+                    // 16-byte stores, whole lines per instruction: 8 lanes per (row, 32-column block) -- lanes 0-3 the hi
+                    // half of the line (8 columns each), lanes 4-7 the lo half; a wave instruction writes 8 complete
+                    // 128-byte lines.
 #pragma unroll
                     for (int pass = 0; pass < 8; ++pass) {
                         const int idx = pass * 64 + lane;
-                        const int rl = idx >> 4, cg = (idx & 15) * 4;
-                        uint4 w = *reinterpret_cast<const uint4*>(stg + idx * 16);
-                        const int row = row0 + rl, col = col0 + cg;
+                        const int rl = idx >> 4, cb = (idx >> 3) & 1, half = (idx >> 2) & 1, c8 = (idx & 3) * 8;
+                        const uint4 w0 = *reinterpret_cast<const uint4*>(stg + (rl * 64 + cb * 32 + c8) * 4);
+                        const uint4 w1 = *reinterpret_cast<const uint4*>(stg + (rl * 64 + cb * 32 + c8 + 4) * 4);
+                        const int row = row0 + rl, col = col0 + cb * 32;
+                        const uint32_t sel = half ? 0x07060302u : 0x05040100u;
+                        uint4 o4 = make_uint4(__builtin_amdgcn_perm(w0.y, w0.x, sel), __builtin_amdgcn_perm(w0.w, w0.z, sel),
+                                              __builtin_amdgcn_perm(w1.y, w1.x, sel), __builtin_amdgcn_perm(w1.w, w1.z, sel));
                         if constexpr (EPI == PEPI_PLANES_DGRAD) {
-                            if (a.mask != nullptr && row < a.M && col < a.ldmask) {
-                                const uint2 mk = *reinterpret_cast<const uint2*>(a.mask + (size_t)row * (2 * a.ldmask) + (col >> 5) * 64 + (col & 31));
-                                const uint32_t m4[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
-                                uint32_t* wv = reinterpret_cast<uint32_t*>(&w);
+                            if (a.bits == nullptr && a.mask != nullptr && row < a.M && col < a.ldmask) {
+                                const uint4 mk = *reinterpret_cast<const uint4*>(a.mask + (size_t)row * (2 * a.ldmask) + (col >> 5) * 64 + c8);
+                                const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                                uint32_t* ov = reinterpret_cast<uint32_t*>(&o4);
 #pragma unroll
-                                for (int k = 0; k < 4; ++k)
-                                    if ((m4[k] & 0x8000u) || (m4[k] & 0x7fffu) == 0) wv[k] = 0u;      // fp16 hi part: x > 0 ?
+                                for (int k = 0; k < 4; ++k) {          // fp16 hi part of the layer input: x > 0 ?
+                                    const uint32_t lo16 = mw[k] & 0xffffu, hi16 = mw[k] >> 16;
+                                    uint32_t keep = 0u;
+                                    if (!(lo16 & 0x8000u) && lo16 != 0u) keep |= 0x0000ffffu;
+                                    if (!(hi16 & 0x8000u) && hi16 != 0u) keep |= 0xffff0000u;
+                                    ov[k] &= keep;
+                                }
                             }
                         }
-                        if (row < a.M && col < ldo) {
-                            const uint2 hi2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x05040100u), __builtin_amdgcn_perm(w.w, w.z, 0x05040100u));
-                            const uint2 lo2 = make_uint2(__builtin_amdgcn_perm(w.y, w.x, 0x07060302u), __builtin_amdgcn_perm(w.w, w.z, 0x07060302u));
-                            const size_t o = (size_t)row * (2 * ldo) + (col >> 5) * 64 + (col & 31);
-                            *reinterpret_cast<uint2*>(Po + o) = hi2;
-                            *reinterpret_cast<uint2*>(Po + o + 32) = lo2;
-                        }
+#ifndef HOS_EXP_NO_EPI_STORE
+                        if (row < a.M && col < ldo)
+                            *reinterpret_cast<uint4*>(Po + (size_t)row * (2 * ldo) + (col >> 5) * 64 + half * 32 + c8) = o4;
+#else
+                        if (row < a.M && col < ldo && o4.x == 0x12345u) *reinterpret_cast<uint4*>(Po) = o4;
+#endif
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging reads done before it is rewritten
                 }
+                if (EPI == PEPI_PLANES_FWD && a.bits != nullptr && first && row0 < a.M && (col0 >> 6) < a.bits_nb)
+                    a.bits[((size_t)(row0 >> 5) * a.bits_nb + (col0 >> 6)) * 64 + lane] = mybits;
             }
         if (EPI == PEPI_PLANES_FWD && a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0)
             atomicOr(a.f32.range_flag, 1u);
@@ -579,6 +649,8 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     }
     a.tiles_m = hos_cdiv(a.M, PBM);
     a.tiles_n = hos_cdiv(a.N, BN);
+    static const int env_stagger = getenv("HOS_GEMMP_STAGGER") ? atoi(getenv("HOS_GEMMP_STAGGER")) : 0;
+    a.stagger = env_stagger;
     if (EPI == PEPI_WGRAD) {
         a.kt_per_split = hos_cdiv(a.nk, splits);          // splits chosen by wgrad_splits()
         splits = hos_cdiv(a.nk, a.kt_per_split);
@@ -730,7 +802,7 @@ extern "C" int hos_split_planes2(const float* src, int lds, int R, int C, void* 
 }
 
 extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
-                               const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb,
+                               const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
                                float* C, int ldc, int epilogue, float* aux, int aux_col, float p0,
                                hos_stream_t stream) {
     if (!A || !W || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
@@ -741,6 +813,7 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
     const bool planes_out = (Y != nullptr) || (Yb != nullptr);
     if (planes_out && ((Y && (ldy & 31)) || (Yb && (ldyb & 31)))) return HOS_E_ALIGN;
     if (!planes_out && !C && epilogue != HOS_EPI_DENSITY) return HOS_E_ARG;
+    if (relu_bits && (!Y || !relu || ((uintptr_t)relu_bits & 3u))) return HOS_E_ARG;
     PArgs a{};
     a.A = (const uint16_t*)A; a.lda = lda; a.kt0 = K0 / PBK;
     a.A1 = (const uint16_t*)A1; a.lda1 = lda1;
@@ -748,6 +821,7 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
     a.M = M; a.N = N; a.nk = (K0 + K1) / PBK;
     a.bias = bias; a.relu = relu;
     a.Y = (uint16_t*)Y; a.ldy = ldy; a.Yb = (uint16_t*)Yb; a.ldyb = ldyb;
+    a.bits = (uint32_t*)relu_bits; a.bits_nb = hos_cdiv(ldy, 64);
     a.f32.C = C; a.f32.ldc = ldc; a.f32.M = M; a.f32.N = N; a.f32.bias = bias; a.f32.aux = aux; a.f32.aux_col = aux_col;
     a.f32.range_flag = hos_range_flag_ptr();
     a.f32.p0 = p0; a.f32.epi = epilogue;
@@ -759,16 +833,18 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
 }
 
 extern "C" int hos_linearp_dgrad(const void* dZ, int lddz, const void* WT, int ldwt, int Npad, const void* mask, int ldmask,
-                                 int M, int K, void* dX, int lddx, hos_stream_t stream) {
+                                 const void* mask_bits, int M, int K, void* dX, int lddx, hos_stream_t stream) {
     if (!dZ || !WT || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
     if (Npad % PBK) return HOS_E_SHAPE;
-    if ((lddz & 31) || (ldwt & 31) || (lddx & 31) || (mask && (ldmask & 31))) return HOS_E_ALIGN;
+    if ((lddz & 31) || (ldwt & 31) || (lddx & 31) || ((mask || mask_bits) && (ldmask & 31))) return HOS_E_ALIGN;
+    if (mask_bits && (ldmask <= 0 || ((uintptr_t)mask_bits & 3u))) return HOS_E_ARG;
     if (!al16p(dZ) || !al16p(WT)) return HOS_E_ALIGN;
     PArgs a{};
     a.A = (const uint16_t*)dZ; a.lda = lddz; a.kt0 = Npad / PBK;
     a.B = (const uint16_t*)WT; a.ldb = ldwt;
     a.M = M; a.N = K; a.nk = Npad / PBK;
     a.mask = (const uint16_t*)mask; a.ldmask = ldmask;
+    a.bits = (uint32_t*)mask_bits; a.bits_nb = hos_cdiv(ldmask, 64);
     a.Y = (uint16_t*)dX; a.ldy = lddx;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return K > 128 ? launchp<256, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s) : launchp<128, PEPI_PLANES_DGRAD, __bf16, false>(a, 1, s);

@@ -369,7 +369,7 @@ class MipNeRF360MLP(FlatModule):
         ping = [None, None]
         for i, L in enumerate(self._layers):
             if save:
-                out = ops.Planes.empty(P, W, torch.float16, dev)
+                out = ops.Planes.empty(P, W, torch.float16, dev, relu_bits=True)      # + 1 bit per element: the ReLU mask of the backward pass
                 outb = ops.Planes.empty(P, W, torch.bfloat16, dev)
             else:
                 if ping[i & 1] is None:

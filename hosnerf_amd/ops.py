@@ -949,18 +949,21 @@ def adam_step_dyn(p, g, m, v, hyper, beta1, beta2, eps, grad_scale=1.0, sumsq_bu
 class Planes:
     """A matrix [rows, ld] stored as interleaved 16-bit planes: one [rows, ld/32, 2, 32] tensor -- per row and
     32-column block the 32 hi values then the 32 lo values (value = hi + lo).  dtype torch.float16 for forward
-    operands, torch.bfloat16 for gradient-side operands.  `ld` is the logical (padded) column count, % 32 == 0."""
+    operands, torch.bfloat16 for gradient-side operands.  `ld` is the logical (padded) column count, % 32 == 0.
+    `bits` (optional): the ReLU bit mask of the matrix, written by linearp_fwd and read by linearp_dgrad -- int32
+    [ceil(rows/32), ceil(ld/64), 64] (include/hosrender.h, hos_linearp_fwd)."""
 
-    __slots__ = ("t", "rows", "cols")
+    __slots__ = ("t", "rows", "cols", "bits")
 
-    def __init__(self, t: torch.Tensor, rows: int, cols: int):
+    def __init__(self, t: torch.Tensor, rows: int, cols: int, bits: Optional[torch.Tensor] = None):
         assert t.dim() == 4 and t.shape[2] == 2 and t.shape[3] == 32
-        self.t, self.rows, self.cols = t, rows, cols
+        self.t, self.rows, self.cols, self.bits = t, rows, cols, bits
 
     @staticmethod
-    def empty(rows: int, ld: int, dtype, device, cols: Optional[int] = None):
+    def empty(rows: int, ld: int, dtype, device, cols: Optional[int] = None, relu_bits: bool = False):
         assert ld % 32 == 0, "planes need a leading dimension that is a multiple of 32"
-        return Planes(torch.empty(rows, ld // 32, 2, 32, dtype=dtype, device=device), rows, ld if cols is None else cols)
+        bits = torch.empty((rows + 31) // 32, (ld + 63) // 64, 64, dtype=torch.int32, device=device) if relu_bits else None
+        return Planes(torch.empty(rows, ld // 32, 2, 32, dtype=dtype, device=device), rows, ld if cols is None else cols, bits)
 
     @staticmethod
     def from_flat(flat16: torch.Tensor, offset: int, rows: int, ld: int, cols: Optional[int] = None):
@@ -1031,15 +1034,18 @@ def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool 
     _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linearp_fwd", _pp(A), A.ld, K0, _pp(A1), 0 if A1 is None else A1.ld, K1, _pp(W), W.ld, ptr(bias), M, N, int(relu),
         _pp(Y), 0 if Y is None else Y.ld, _pp(Yb), 0 if Yb is None else Yb.ld,
+        ptr(Y.bits, torch.int32) if (relu and Y is not None and Y.bits is not None) else 0,
         ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
 
 
 def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optional[Planes] = None,
                   dX: Optional[Planes] = None):
-    """dX (bf16 planes [M][ld]) = (dZ @ WT^T) masked by mask.hi > 0; WT = transposed weight planes [K][Npad]."""
+    """dX (bf16 planes [M][ld]) = (dZ @ WT^T) masked by the ReLU bits of `mask` (mask.bits, written by the linearp_fwd that
+    produced it) or by mask.hi > 0; WT = transposed weight planes [K][Npad]."""
+    bits = None if mask is None else mask.bits
     _timed(f"gemmp_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
-        "hos_linearp_dgrad", _pp(dZ), dZ.ld, _pp(WT), WT.ld, Npad, _pp(mask), 0 if mask is None else mask.ld, M, K,
-        _pp(dX), dX.ld))
+        "hos_linearp_dgrad", _pp(dZ), dZ.ld, _pp(WT), WT.ld, Npad, _pp(None if bits is not None else mask),
+        0 if mask is None else mask.ld, ptr(bits, torch.int32), M, K, _pp(dX), dX.ld))
 
 
 _wgrad_ws = {}          # device index -> fp32 scratch for the split-K slabs of hos_linearp_wgrad

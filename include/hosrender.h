@@ -144,16 +144,20 @@ int hos_split_planes2(const float* src, int lds, int R, int C, void* p16, int ld
 
 /* Forward: acc[M,N] = [A | A1][M,K0+K1] @ W[N,K0+K1]^T (fp16 planes) + bias.
  *  - plane outputs (Y != NULL and/or Yb != NULL): relu?(acc) as fp16 planes [M][ldy] (input of the next layer)
- *    and/or as bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed;
+ *    and/or as bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed; with relu and Y, relu_bits
+ *    (may be NULL) receives one bit per element, acc + bias > 0: uint32 [ceil(M/32)][ceil(ldy/64)][64], per 32-row x
+ *    64-column block in the accumulator layout of the kernel (dword l + 32 h, bit 16 y + r = row (r&3) + 8 (r>>2) + 4 h,
+ *    column 32 y + l) -- the ReLU mask hos_linearp_dgrad reads back, opaque to everything else;
  *  - otherwise the fp32 epilogues of hos_linear_fwd (C/ldc/epilogue/aux/aux_col/p0). */
 int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
-                    const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb,
+                    const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
                     float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream);
 
 /* Data gradient: dX[M,K] = dZ[M,Npad] @ WT[K,Npad]^T (bf16 planes; WT = transposed weight planes), masked by the
- * fp16 planes of the layer input (hi > 0) if mask != NULL; written as bf16 planes [M][lddx]. */
+ * ReLU bit mask hos_linearp_fwd wrote next to the layer input (mask_bits != NULL, ldmask = that input's ld; see
+ * relu_bits there) or by the fp16 planes of the layer input themselves (hi > 0, mask != NULL); bf16 planes [M][lddx]. */
 int hos_linearp_dgrad(const void* dZ, int lddz, const void* WT, int ldwt, int Npad, const void* mask, int ldmask,
-                      int M, int K, void* dX, int lddx, hos_stream_t stream);
+                      const void* mask_bits, int M, int K, void* dX, int lddx, hos_stream_t stream);
 
 /* Weight gradient: dW[N,K] += dZ[M,N]^T @ X[M, x_col0 : x_col0+K] (both ROW-MAJOR bf16 planes; the
  * reduction-contiguous MFMA fragments are gathered from LDS with ds_read_b64_tr_b16), db[N] += column sums of dZ.

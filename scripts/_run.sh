@@ -1,1 +1,2 @@
-python -m pytest tests/test_gpu_chain.py -x -q 2>&1 | tail -3
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+python bench.py --only-primary 2>&1 | grep '^{'

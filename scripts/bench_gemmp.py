@@ -13,26 +13,33 @@ X16, Xb = ops.split_planes2(X)
 W16, _ = ops.split_planes(W, dtype=torch.float16)
 _, WTb = ops.split_planes(W, dtype=torch.bfloat16, transposed=True, row_major=False)      # [K][N]
 _, dZ = ops.split_planes2(dYf, want16=False)
-Y = ops.Planes.empty(M, N, torch.float16, dev); Yb = ops.Planes.empty(M, N, torch.bfloat16, dev)
+Y = ops.Planes.empty(M, N, torch.float16, dev, relu_bits=True); Yn = ops.Planes.empty(M, N, torch.float16, dev); Yb = ops.Planes.empty(M, N, torch.bfloat16, dev)
 dX = ops.Planes.empty(M, K, torch.bfloat16, dev)
 C = torch.empty(M, N, device=dev)
 dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
 fl = 2.0 * M * N * K
 
 def run(name, fn):
-    for _ in range(3): fn()
+    for _ in range(10): fn()
     torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     us = a.elapsed_time(e) * 1e3 / iters
-    print(f"planes {name:12s} M={M} N={N} K={K}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s")
+    print(f"planes {name:18s} M={M} N={N} K={K}: {us:8.1f} us  {fl/us/1e6:7.1f} TFLOP/s")
 
+run("(warm-up line)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, Yb))
 run("fwd(2fmt)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb))
-run("fwd(f16)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, None))
+run("fwd(2fmt,nobits)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, Yb))
+run("fwd(f16)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, None))
 run("fwd(f32out)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU))
-run("dgrad", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX))
+Xm = ops.Planes.empty(M, K, torch.float16, dev, relu_bits=True)       # X as a layer output WITH bits: X = relu(X @ I)
+Xm.t.copy_(X16.t)
+eye16, _ = ops.split_planes(torch.eye(K, device=dev), dtype=torch.float16)
+ops.linearp_fwd(X16, K, eye16, None, M, K, True, Xm, None)
+run("dgrad(planes mask)", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX))
+run("dgrad(bits)", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xm, dX=dX))
 run("wgrad", lambda: ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K))
 run("split2", lambda: ops.split_planes2(X))
 # accuracy
@@ -42,6 +49,9 @@ print("fwd err fp16 planes", (Y.float()[:512].double() - ref).abs().max().item()
 ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU)
 print("fwd err fp32 out", (C[:512].double() - ref).abs().max().item())
 ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX)
+dX1 = dX.float().clone()
+ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xm, dX=dX)
+print("dgrad bits vs planes mask: max diff", (dX.float() - dX1).abs().max().item(), "bits check", (Xm.float() - torch.relu(X)).abs().max().item())
 refd = (dYf[:512].double() @ W.double()) * (X[:512] > 0)
 print("dgrad err", (dX.float()[:512].double() - refd).abs().max().item(), "scale", refd.abs().max().item())
 dW.zero_(); db.zero_()
