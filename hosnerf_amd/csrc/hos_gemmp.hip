@@ -98,6 +98,20 @@ __device__ __forceinline__ uint32_t split_pack(float x) {
     const E l = (E)(x - (float)h);
     return (uint32_t)to_bits<E>(h) | ((uint32_t)to_bits<E>(l) << 16);
 }
+// the same dword for a value the epilogue holds in a register: the final pack is ONE packed conversion (lower half = the
+// hi part again, upper half = the residual), gfx950's v_cvt_pk_{f16,bf16}_f32 (round to nearest even like the scalar forms)
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t split_pack_pk(float x, _Float16) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const float c = clampE<_Float16>(x);
+    const pf32x2 v = {c, x - (float)(_Float16)c};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+}
+__device__ __forceinline__ uint32_t split_pack_pk(float x, __bf16) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const pf32x2 v = {x, x - (float)(__bf16)x};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
+}
 template <typename E>
 __device__ __forceinline__ void split1(float x, uint16_t& hi, uint16_t& lo) {
     const uint32_t p = split_pack<E>(x);
@@ -361,7 +375,10 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     };
 
 #ifdef HOS_TRACE   // block timeline: entry / loop start / loop end / exit of workgroups 0 and 300 (second round)
-#define HOS_BSTAMP(slot) do { if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && a.f32.aux) reinterpret_cast<long long*>(a.f32.aux)[256 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 4 + (slot)] = clock64(); } while (0)
+// (slots 0 and 3 also record the constant 100 MHz counter: shader cycles / wall time = the effective clock of the launch)
+#define HOS_BSTAMP(slot) do { if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && a.f32.aux) { \
+        reinterpret_cast<long long*>(a.f32.aux)[256 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 4 + (slot)] = clock64(); \
+        if ((slot) == 0 || (slot) == 3) reinterpret_cast<long long*>(a.f32.aux)[320 + ((blockIdx.x ? 1 : 0) * 8 + wave) * 2 + ((slot) ? 1 : 0)] = wall_clock64(); } } while (0)
 #else
 #define HOS_BSTAMP(slot) do {} while (0)
 #endif
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         // 32 consecutive dwords per half wave: conflict free); after the wave's own writes have landed every lane
         // reads 32 bytes = eight consecutive columns of one row, keeps their hi or their lo halves and stores 16 bytes.
         // ReLU mask of the backward pass: FWD can emit one BIT per output element in ACCUMULATOR layout (a.bits: per
-        // 32-row x 64-column block 64 dwords, dword = lane, bit 16 yy + r = element (row (r&3) + 8 (r>>2) + 4 (lane>>5),
+        // 32-row x 64-column block 64 dwords, dword = lane, bit 31 - (16 yy + r) = element (row (r&3) + 8 (r>>2) + 4 (lane>>5),
         // column 32 yy + (lane&31)) of the block), and DGRAD, whose accumulators have the same layout, reads its own dword
         // back: 8 KB per tile instead of the 256 KB of the fp16 planes of the layer input (whose fetch at ~11 B/clk/CU
         // cost ~16 us at the end of every tile: 110 us of an 817 us launch at M = 131072).
@@ -552,38 +569,51 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         char* const stg = smemp + wave * 8192;
         const bool dual = (EPI == PEPI_PLANES_FWD) && a.Yb != nullptr;
         const bool first = a.Y != nullptr;
-        bool big = false;          // a hidden activation beyond the exact fp16 hi/lo range (HOS_RANGE_LIMIT)
+        float vmax = 0.f;          // largest hidden activation: beyond the exact fp16 hi/lo range (HOS_RANGE_LIMIT)?
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
             for (int yp = 0; yp < TN / 2; ++yp) {
                 const int row0 = i0 + wm * (TM * 32) + x * 32;
                 const int col0 = j0 + wn * (TN * 32) + yp * 64;
-                uint32_t mybits = 0u;                                 // FWD: v > 0 of this lane's 32 values of the block (bit 16 yy + r)
+                // activation (FWD) / ReLU mask (DGRAD) once, in place in the accumulators; both formats are split from that
+                uint32_t mybits = 0u;            // FWD: v > 0 of this lane's 32 values of the block, value (yy, r) at bit 31 - (16 yy + r)
                 const uint32_t keepbits = (EPI == PEPI_PLANES_DGRAD && a.bits != nullptr) ? bw[x][yp] : 0xffffffffu;
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy) {
+                    const int col = col0 + yy * 32 + l31;
+                    float bcol = 0.f;
+                    if (EPI == PEPI_PLANES_FWD && a.bias != nullptr && col < a.N) bcol = a.bias[col];
+                    const bool inb = col < a.N;                                        // zero the padding columns
+                    // ReLU and the zeroing of padding columns as ONE clamp: [0, inf) / (-inf, inf) / [0, 0]
+                    const float vlo = inb ? (a.relu ? 0.f : -__builtin_inff()) : 0.f, vhi = inb ? __builtin_inff() : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = acc[x][2 * yp + yy][r];
+                        if constexpr (EPI == PEPI_PLANES_FWD) {
+                            v = __builtin_amdgcn_fmed3f(v + bcol, vlo, vhi);
+                            mybits = __builtin_amdgcn_alignbit(mybits, __builtin_bit_cast(uint32_t, 0.f - v), 31);    // sign of -v: v > 0
+                            vmax = fmaxf(vmax, fabsf(v));
+                        } else {
+                            if (!inb) v = 0.f;
+                            v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (uint32_t)__builtin_amdgcn_sbfe(keepbits, 31 - (yy * 16 + r), 1));
+                        }
+                        acc[x][2 * yp + yy][r] = v;
+                    }
+                }
 #pragma unroll
                 for (int fmt = 0; fmt < 2; ++fmt) {
                     if (fmt == 0 && !first) continue;
                     if (fmt == 1 && !dual) continue;
 #pragma unroll
-                    for (int yy = 0; yy < 2; ++yy) {
-                        const int col = col0 + yy * 32 + l31;
-                        float bcol = 0.f;
-                        if (EPI == PEPI_PLANES_FWD && a.bias != nullptr && col < a.N) bcol = a.bias[col];
+                    for (int yy = 0; yy < 2; ++yy)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float v = acc[x][2 * yp + yy][r] + bcol;
-                            if (EPI == PEPI_PLANES_FWD && a.relu) v = fmaxf(v, 0.f);
-                            if (col >= a.N) v = 0.f;                                   // zero the padding columns
-                            if (EPI == PEPI_PLANES_FWD && fmt == 0) mybits |= (v > 0.f ? 1u : 0u) << (yy * 16 + r);
-                            if (EPI == PEPI_PLANES_DGRAD && !((keepbits >> (yy * 16 + r)) & 1u)) v = 0.f;
+                            const float v = acc[x][2 * yp + yy][r];
                             const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                            uint32_t p;
-                            if (EPI == PEPI_PLANES_FWD && fmt == 0) { p = split_pack<_Float16>(v); big |= fabsf(v) > HOS_RANGE_LIMIT; }
-                            else p = split_pack<__bf16>(v);
+                            const uint32_t p = (EPI == PEPI_PLANES_FWD && fmt == 0) ? split_pack_pk(v, (_Float16)0) : split_pack_pk(v, (__bf16)0);
                             *reinterpret_cast<uint32_t*>(stg + (rl * 64 + yy * 32 + l31) * 4) = p;
                         }
-                    }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     uint16_t* const Po = fmt == 0 ? a.Y : a.Yb;
                     const int ldo = fmt == 0 ? a.ldy : a.ldyb;
@@ -627,7 +657,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 if (EPI == PEPI_PLANES_FWD && a.bits != nullptr && first && row0 < a.M && (col0 >> 6) < a.bits_nb)
                     a.bits[((size_t)(row0 >> 5) * a.bits_nb + (col0 >> 6)) * 64 + lane] = mybits;
             }
-        if (EPI == PEPI_PLANES_FWD && a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0)
+        if (EPI == PEPI_PLANES_FWD && a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(vmax > HOS_RANGE_LIMIT) != 0 && lane == 0)
             atomicOr(a.f32.range_flag, 1u);
     }
 #ifdef HOS_TRACE

@@ -146,7 +146,7 @@ int hos_split_planes2(const float* src, int lds, int R, int C, void* p16, int ld
  *  - plane outputs (Y != NULL and/or Yb != NULL): relu?(acc) as fp16 planes [M][ldy] (input of the next layer)
  *    and/or as bf16 planes [M][ldyb] (weight-gradient operand); padding columns zeroed; with relu and Y, relu_bits
  *    (may be NULL) receives one bit per element, acc + bias > 0: uint32 [ceil(M/32)][ceil(ldy/64)][64], per 32-row x
- *    64-column block in the accumulator layout of the kernel (dword l + 32 h, bit 16 y + r = row (r&3) + 8 (r>>2) + 4 h,
+ *    64-column block in the accumulator layout of the kernel (dword l + 32 h, bit 31 - (16 y + r) = row (r&3) + 8 (r>>2) + 4 h,
  *    column 32 y + l) -- the ReLU mask hos_linearp_dgrad reads back, opaque to everything else;
  *  - otherwise the fp32 epilogues of hos_linear_fwd (C/ldc/epilogue/aux/aux_col/p0). */
 int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
