@@ -35,6 +35,9 @@ PROTOTYPES = {
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "hos_thin_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P],
+    "hos_mlp_bwd_defer": [_I],
+    "hos_mlp_bwd_flush": [_P],
+    "hos_mlp_bwd_ws_floats": [_I, _I, _I, _I],
     "hos_linear_wgrad_tr": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P],
     "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P],
     "hos_camera_rays": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
@@ -97,7 +100,7 @@ PROTOTYPES = {
     "hos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _F, _P],
     "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
 }
-_RESTYPES = {"hos_error_string": c_char_p, "hos_train_losses_workspace_floats": c_int64,
+_RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "hos_train_losses_workspace_floats": c_int64,
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
              "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
              "hos_mlp_chain_aux_floats": c_int64, "hos_mlp_chain256_weight_bytes": c_int64,

@@ -374,9 +374,63 @@ __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __rest
     }
 }
 
+// The same reduction for up to MB_BATCH (dW, db) pairs in ONE launch (hos_mlp_bwd_defer / hos_mlp_bwd_flush): a thin MLP's
+// backward is 6-8 such launches, each ending in a 17-67 MB slab reduction that is almost pure launch + atomic latency
+// (17.7 us average, 40 of them = 0.72 ms of a 10 ms stage-2 step); batched they run as one grid.
+constexpr int MB_BATCH = 16;
+struct ReduceJob { const float* ws; float* dW; float* db; int slabs, n_, k_, nk, lddw, N, K, first_block; };
+struct ReduceBatch { ReduceJob j[MB_BATCH]; int count; };
+
+__global__ __launch_bounds__(256) void mlp_bwd_reduce_batch_kernel(const ReduceBatch b) {
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < b.count; ++i) if ((int)blockIdx.x >= b.j[i].first_block) ji = i;
+    const ReduceJob& J = b.j[ji];
+    const int e = (((int)blockIdx.x - J.first_block) * 256 + threadIdx.x) * 4;
+    const int slab = J.nk + J.n_;
+    if (e >= slab || (e >= J.nk && J.db == nullptr)) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int sy = gridDim.y;
+    for (int g0 = blockIdx.y; g0 < J.slabs; g0 += 8 * sy) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = g0 + i * sy;
+            v[i] = g < J.slabs ? *reinterpret_cast<const float4*>(J.ws + (size_t)g * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+    if (e >= J.nk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (e - J.nk + q < J.N) __hip_atomic_fetch_add(J.db + e - J.nk + q, sv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int n = e / J.k_, k = e % J.k_;
+    if (n < J.N) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k + q < J.K) __hip_atomic_fetch_add(J.dW + (size_t)n * J.lddw + k + q, sv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+thread_local bool g_defer = false;
+thread_local ReduceBatch g_batch = {};
+
 static inline int reduce_split() {
     static const int v = getenv("HOS_MB_RSPLIT") ? atoi(getenv("HOS_MB_RSPLIT")) : MB_RSPLIT;
     return v > 0 ? v : MB_RSPLIT;
+}
+
+static int flush_reduce_batch(hipStream_t stream) {
+    if (g_batch.count == 0) return 0;
+    const ReduceJob& L = g_batch.j[g_batch.count - 1];
+    const int blocks = L.first_block + hos_cdiv(L.nk + L.n_, 1024);
+    hipLaunchKernelGGL(mlp_bwd_reduce_batch_kernel, dim3(blocks, reduce_split()), dim3(256), 0, stream, g_batch);
+    g_batch.count = 0;
+    return hos_launch_status();
 }
 
 template <int NT, int KT, bool DG>
@@ -398,11 +452,28 @@ int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
     if (a.ws != nullptr && (grid < 32 || ws_floats < (size_t)grid * (nk + N_) || (!a.ws_dw && a.db == nullptr))) a.ws = nullptr;
     hipLaunchKernelGGL((mlp_bwd_kernel<NT, KT, DG>), dim3(grid), dim3(MB_NT), smem, stream, a);
 #ifndef HOS_MB_TRACE
-    if (a.ws != nullptr)
-        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), reduce_split()), dim3(256), 0, stream,
-                           a.ws, grid, N_, K_, nk, a.dW, a.lddw, a.db, a.N, a.K);
+    if (a.ws != nullptr) {
+        if (g_defer) {
+            if (g_batch.count == MB_BATCH) { const int rc = flush_reduce_batch(stream); if (rc != 0) return rc; }
+            ReduceJob& J = g_batch.j[g_batch.count];
+            J = ReduceJob{a.ws, a.dW, a.db, grid, N_, K_, nk, a.lddw, a.N, a.K,
+                          g_batch.count ? g_batch.j[g_batch.count - 1].first_block + hos_cdiv(g_batch.j[g_batch.count - 1].nk + g_batch.j[g_batch.count - 1].n_, 1024) : 0};
+            ++g_batch.count;
+        } else {
+            hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), reduce_split()), dim3(256), 0, stream,
+                               a.ws, grid, N_, K_, nk, a.dW, a.lddw, a.db, a.N, a.K);
+        }
+    }
 #endif
     return hos_launch_status();
+}
+
+// floats of slab workspace launch_mb<NT, KT, DG> uses for M rows (0: it accumulates with atomics)
+template <int NT, int KT, bool DG>
+int64_t ws_floats_mb(int M) {
+    const int nrb = hos_cdiv(M, mb_rows(DG));
+    const int grid = nrb < 256 ? nrb : 256;
+    return grid < 32 ? 0 : (int64_t)grid * (NT * 32 * KT * 32 + NT * 32);
 }
 
 }  // namespace
@@ -440,4 +511,22 @@ extern "C" int hos_linear_wgrad_tr(const float* dZ, int lddz, const float* X, in
     const int kt = hos_cdiv(K, 32);
     if (kt <= 4) return launch_mb<8, 4, false>(a, (size_t)ws_floats, s);
     return launch_mb<8, 8, false>(a, (size_t)ws_floats, s);
+}
+
+// Deferred slab reductions: between hos_mlp_bwd_defer(1) and hos_mlp_bwd_flush() every hos_linear_bwd_fused /
+// hos_linear_wgrad_tr call of this thread only RECORDS its reduction (so each call needs its own `ws` region, sized by
+// hos_mlp_bwd_ws_floats); the flush runs them all in one launch per 16 and the gradients are complete after it.
+extern "C" int hos_mlp_bwd_defer(int on) { g_defer = on != 0; return 0; }
+
+extern "C" int hos_mlp_bwd_flush(hos_stream_t stream) { return flush_reduce_batch(static_cast<hipStream_t>(stream)); }
+
+extern "C" long long hos_mlp_bwd_ws_floats(int M, int N, int K, int fused) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int nt = hos_cdiv(N, 32), kt = hos_cdiv(K, 32);
+    if (fused) {
+        if (nt <= 1 && kt <= 4) return ws_floats_mb<1, 4, true>(M);
+        if (kt <= 2) return ws_floats_mb<4, 2, true>(M);
+        return ws_floats_mb<4, 4, true>(M);
+    }
+    return kt <= 4 ? ws_floats_mb<8, 4, false>(M) : ws_floats_mb<8, 8, false>(M);
 }

@@ -447,16 +447,17 @@ class Network(FlatModule):
 
         dz6 = torch.zeros(Pn, 32, device=dev)
         ops.slice_mask(g_xyz, 0, None, 0, 3, dz6, rows_dev=rows_dev)
-        dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
-        dPE = dE = None
-        for i in range(5, -1, -1):
-            if i == 4:
-                dPE = layer_bwd(dz, PE, specs[4], 128, NR_LDPE, torch.empty(Pn, NR_LDPE, device=dev), False, w_col0=128, bias=False)
-                dz = layer_bwd(dz, acts[3], specs[4], 128, 128, torch.empty(Pn, 128, device=dev), True)
-            elif i == 0:
-                dE = layer_bwd(dz, E, specs[0], 128, NR_LDE, torch.empty(Pn, NR_LDE, device=dev), False)
-            else:
-                dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
+        with ops.deferred_bwd_reduce():          # the seven slab reductions of this chain as one launch at the end
+            dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
+            dPE = dE = None
+            for i in range(5, -1, -1):
+                if i == 4:
+                    dPE = layer_bwd(dz, PE, specs[4], 128, NR_LDPE, torch.empty(Pn, NR_LDPE, device=dev), False, w_col0=128, bias=False)
+                    dz = layer_bwd(dz, acts[3], specs[4], 128, 128, torch.empty(Pn, 128, device=dev), True)
+                elif i == 0:
+                    dE = layer_bwd(dz, E, specs[0], 128, NR_LDE, torch.empty(Pn, NR_LDE, device=dev), False)
+                else:
+                    dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
         g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
         ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True, rows_dev=rows_dev)
         return g_x
@@ -474,29 +475,30 @@ class Network(FlatModule):
         ops.linear_dgrad(dz8, Wt, 32, 256, dz, mask_src=acts[7])
         dCAT = dE = None
         tmp_b = {}
-        for i in range(7, -1, -1):
-            L = self._cnl[i]
-            Wt, _ = self._w(L)
-            gW, gb = self._w(L, grad=True)
-            if i == 5:
-                tmp_b[5] = torch.zeros(L.Npad, device=dev)
-                ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
-                dCAT = torch.empty(Pn, CNL_CAT, device=dev)
-                ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
-                nxt = torch.empty(Pn, 256, device=dev)
-                ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)                 # h-part of the concat, through layer 4's ReLU
-                dz = nxt
-            elif i == 0:
-                tmp_b[0] = torch.zeros(L.Npad, device=dev)
-                ops.linear_wgrad(dz, E, gW, tmp_b[0], 256, CNL_LDE)
-                dE = torch.empty(Pn, CNL_LDE, device=dev)
-                ops.linear_dgrad(dz, Wt, 256, CNL_LDE, dE)
-            else:
-                inp = acts[i - 1]
-                ops.linear_wgrad(dz, inp, gW, gb, 256, 256)
-                nxt = torch.empty(Pn, 256, device=dev)
-                ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp)
-                dz = nxt
+        with ops.deferred_bwd_reduce():          # the slab reductions of the eight 256-wide weight gradients as one launch at the end
+            for i in range(7, -1, -1):
+                L = self._cnl[i]
+                Wt, _ = self._w(L)
+                gW, gb = self._w(L, grad=True)
+                if i == 5:
+                    tmp_b[5] = torch.zeros(L.Npad, device=dev)
+                    ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
+                    dCAT = torch.empty(Pn, CNL_CAT, device=dev)
+                    ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
+                    nxt = torch.empty(Pn, 256, device=dev)
+                    ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)                 # h-part of the concat, through layer 4's ReLU
+                    dz = nxt
+                elif i == 0:
+                    tmp_b[0] = torch.zeros(L.Npad, device=dev)
+                    ops.linear_wgrad(dz, E, gW, tmp_b[0], 256, CNL_LDE)
+                    dE = torch.empty(Pn, CNL_LDE, device=dev)
+                    ops.linear_dgrad(dz, Wt, 256, CNL_LDE, dE)
+                else:
+                    inp = acts[i - 1]
+                    ops.linear_wgrad(dz, inp, gW, gb, 256, 256)
+                    nxt = torch.empty(Pn, 256, device=dev)
+                    ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp)
+                    dz = nxt
         # state embedding: its 64 columns are constant over samples -> d embed = db @ W[:, 63:127] (layers 0 and 5)
         g_embed = self._embeds.view(self.store.grad)[state]
         for i in (0, 5):

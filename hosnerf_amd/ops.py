@@ -139,9 +139,9 @@ def linear_wgrad(dY: torch.Tensor, X: torch.Tensor, dW: torch.Tensor, db: Option
     M = dY.shape[0]
     if WGRAD_TR and 128 < N <= 256 and M >= 16384 and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3:
         # many rows, thin layer: staged-planes kernel with transposed LDS reads (hos_mlpbwd.hip), K in chunks of <= 256
-        ws = _bwd_workspace(dY.device)
         for k0 in range(0, K, 256):
             kc = min(256, K - k0)
+            ws = _bwd_workspace(dY.device, M, N, kc, False)
             _timed(f"wgrad_tr[M={N},N={kc},K={M}]", 2.0 * M * N * kc, lambda: call(
                 "hos_linear_wgrad_tr", ptr(dY), dY.stride(0), ptr(X) + 4 * k0, X.stride(0), ptr(dW) + 4 * (w_col0 + k0), dW.stride(0),
                 ptr(db) if k0 == 0 else None, M, N, kc, ptr(ws), ws.numel()))
@@ -156,7 +156,7 @@ def linear_bwd_fused(dY: torch.Tensor, X: torch.Tensor, W: torch.Tensor, dW: tor
     """One thin layer's whole backward in one pass over (dY, X) (hos_mlpbwd.hip; N, K <= 128):
     out[M,:K] = (dY[:, :N] @ W[:N, w_col0:w_col0+K]) * (X > 0 if relu_mask);  dW[:N, w_col0:..+K] += dY^T @ X;  db += colsum(dY)."""
     M = dY.shape[0]
-    ws = _bwd_workspace(dY.device)
+    ws = _bwd_workspace(dY.device, M, N, K, True)
     _timed(f"mlp_bwd_fused[M={M},N={N},K={K}]", 4.0 * M * N * K, lambda: call(
         "hos_linear_bwd_fused", ptr(dY), dY.stride(0), ptr(X), X.stride(0), ptr(W) + 4 * w_col0, W.stride(0),
         ptr(out), 0 if out is None else out.stride(0), ptr(dW) + 4 * w_col0, dW.stride(0), ptr(db), M, N, K, int(relu_mask),
@@ -165,15 +165,52 @@ def linear_bwd_fused(dY: torch.Tensor, X: torch.Tensor, W: torch.Tensor, dW: tor
 
 
 _BWD_WS = {}
+_BWD_DEFER = {"on": False, "offset": 0}
 
 
-def _bwd_workspace(device) -> torch.Tensor:
-    """67 MB of per-workgroup dW / db partials (256 slabs of up to 256 x 256 + 256 floats) for hos_linear_bwd_fused; one per device -- launches on a stream are ordered and
-    the reduce kernel that reads it is enqueued by the same call."""
+def _bwd_workspace(device, M: int = 0, N: int = 0, K: int = 0, fused: bool = False) -> torch.Tensor:
+    """Per-workgroup dW / db partials of hos_linear_bwd_fused / hos_linear_wgrad_tr: 256 slabs of up to 256 x 256 + 256 floats
+    (67 MB) per call, one buffer per device -- launches on a stream are ordered and the reduce kernel that reads a call's slabs
+    is enqueued by the same call.  Inside `deferred_bwd_reduce()` the reductions are postponed to one batched launch, so every
+    call gets its OWN region of the (then larger) buffer."""
     key = str(device)
-    if key not in _BWD_WS:
-        _BWD_WS[key] = torch.empty(256 * (256 * 256 + 256), device=device)
-    return _BWD_WS[key]
+    if not _BWD_DEFER["on"]:
+        if key not in _BWD_WS:
+            _BWD_WS[key] = torch.empty(256 * (256 * 256 + 256), device=device)
+        return _BWD_WS[key][:256 * (256 * 256 + 256)]
+    need = max((int(_lib.load().hos_mlp_bwd_ws_floats(M, N, K, int(fused))) + 3) // 4 * 4, 4)
+    ws = _BWD_WS.get(key)
+    if ws is None or ws.numel() < max(need, BWD_DEFER_WS_FLOATS):
+        _BWD_WS[key] = ws = torch.empty(max(need, BWD_DEFER_WS_FLOATS), device=device)      # (replaces the 67 MB buffer of the immediate mode)
+    if _BWD_DEFER["offset"] + need > ws.numel():      # full: run the recorded reductions now and start over at the front
+        call("hos_mlp_bwd_flush")
+        _BWD_DEFER["offset"] = 0
+    off = _BWD_DEFER["offset"]
+    _BWD_DEFER["offset"] = off + need
+    return ws[off:off + need]
+
+
+BWD_DEFER = os.environ.get("HOS_DEFER_REDUCE", "1") != "0"
+BWD_DEFER_WS_FLOATS = 160 * 1024 * 1024       # 640 MB: the eight 256-wide layers of the canonical MLP (67 MB of slabs each) in one batch
+
+
+class deferred_bwd_reduce:
+    """with deferred_bwd_reduce(): the slab reductions of the linear_bwd_fused / linear_wgrad(tr) calls inside run as ONE
+    batched launch at the exit (hos_mlp_bwd_defer / hos_mlp_bwd_flush); dW / db are complete after the block."""
+
+    def __enter__(self):
+        self.nested = _BWD_DEFER["on"] or not BWD_DEFER
+        if not self.nested:
+            _BWD_DEFER["on"], _BWD_DEFER["offset"] = True, 0
+            _lib.check(_lib.load().hos_mlp_bwd_defer(1), "hos_mlp_bwd_defer")
+        return self
+
+    def __exit__(self, *exc):
+        if not self.nested:
+            _BWD_DEFER["on"] = False
+            _lib.check(_lib.load().hos_mlp_bwd_defer(0), "hos_mlp_bwd_defer")
+            call("hos_mlp_bwd_flush")
+        return False
 
 
 FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"

@@ -107,6 +107,16 @@ int hos_linear_bwd_fused(const float* dY, int lddy, const float* X, int ldx, con
                          int relu_mask, float* ws, int64_t ws_floats, const int32_t* rows_dev,
                          hos_stream_t stream);
 
+/* Deferred slab reductions of hos_linear_bwd_fused / hos_linear_wgrad_tr.  Each of those calls ends in a second launch
+ * that sums its per-workgroup partials (ws) into dW / db.  Between hos_mlp_bwd_defer(1) and hos_mlp_bwd_flush() the calls
+ * of the calling thread only RECORD that reduction (each call then needs its own ws region of hos_mlp_bwd_ws_floats(M, N, K,
+ * fused) floats; 0 = that call uses atomics and needs none); hos_mlp_bwd_flush runs all recorded reductions in one launch
+ * per 16 and dW / db are complete after it; hos_mlp_bwd_defer(0) restores the immediate reduction.  A thin MLP's backward
+ * is 6-8 such calls: 40 reduction launches per stage-2 step (0.72 ms) become 4. */
+int hos_mlp_bwd_defer(int on);
+int hos_mlp_bwd_flush(hos_stream_t stream);
+long long hos_mlp_bwd_ws_floats(int M, int N, int K, int fused);
+
 /* WGRAD of a layer up to 256 x 256 with the staging of hos_linear_bwd_fused (operands split once into LDS planes, transposed
  * LDS reads instead of in-register transposes): dW [N,ldw] += dY^T . X, db [N] += column sums (NULL: skip).  ws: optional
  * scratch (>= 256*(256*256+256) floats) for the per-workgroup dW / db partials (NULL: fp32 atomics).  Replaces hos_linear_wgrad for M >> N, K.

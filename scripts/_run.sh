@@ -1,4 +1,2 @@
-export GM=131072
-python scripts/bench_gemmp.py 10 2>&1 | grep "^planes\|err\|diff"
-GM=1000 GN=96 GK=64 python scripts/bench_gemmp.py 10 2>&1 | grep "err\|diff"
-python -m pytest tests -x -q -m gpu -k "gemm or plane or mip or stage1 or golden or bkgd or stress" 2>&1 | tail -3
+GM=4096 python scripts/bench_gemmp.py 3 2>&1 | grep "relu bits\|diff\|err"
+bash scripts/pmc_gemmp_r02.sh > gpurun_out/pmc_r02.log 2>&1; tail -50 gpurun_out/pmc_r02.log

@@ -19,7 +19,12 @@ C = torch.empty(M, N, device=dev)
 dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
 fl = 2.0 * M * N * K
 
+ONLY = os.environ.get("GONLY", "")          # comma list of line names: run only these (PMC passes: one configuration per kernel)
+
+
 def run(name, fn):
+    if ONLY and name not in ONLY.split(","):
+        return
     for _ in range(10): fn()
     torch.cuda.synchronize()
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -34,15 +39,35 @@ run("fwd(2fmt)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb))
 run("fwd(2fmt,nobits)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, Yb))
 run("fwd(f16)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, None))
 run("fwd(f32out)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU))
-Xm = ops.Planes.empty(M, K, torch.float16, dev, relu_bits=True)       # X as a layer output WITH bits: X = relu(X @ I)
+def relu_bits(Xf):
+    """The ReLU bit mask of include/hosrender.h (hos_linearp_fwd, relu_bits) built with torch ops: int32 [M/32, K/64, 64]."""
+    Mr, Kc = Xf.shape
+    m = (Xf > 0).view(Mr // 32, 32, Kc // 64, 2, 32).permute(0, 2, 1, 3, 4)             # [rb, cb, row, y, l]
+    r = torch.arange(16, device=Xf.device)
+    rowidx = ((r & 3) + 8 * (r >> 2))[None, :] + 4 * torch.arange(2, device=Xf.device)[:, None]      # [h, r]
+    mm = m[:, :, rowidx].permute(0, 1, 2, 5, 4, 3)                                      # [rb, cb, h, l, y, r]
+    w = (2 ** (31 - (16 * torch.arange(2, device=Xf.device)[:, None] + r[None, :]))).to(torch.int64)
+    v = (mm.to(torch.int64) * w).sum((-1, -2))
+    return torch.where(v >= 2**31, v - 2**32, v).to(torch.int32).reshape(Mr // 32, Kc // 64, 64).contiguous()
+
+
+Xm = ops.Planes.empty(M, K, torch.float16, dev, relu_bits=True)       # X as a layer output WITH its bits
 Xm.t.copy_(X16.t)
-eye16, _ = ops.split_planes(torch.eye(K, device=dev), dtype=torch.float16)
-ops.linearp_fwd(X16, K, eye16, None, M, K, True, Xm, None)
+if M % 32 == 0 and K % 64 == 0:
+    Xm.bits.copy_(relu_bits(X))
+else:
+    eye16, _ = ops.split_planes(torch.eye(K, device=dev), dtype=torch.float16)
+    ops.linearp_fwd(X16, K, eye16, None, M, K, True, Xm, None)
 run("dgrad(planes mask)", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX))
 run("dgrad(bits)", lambda: ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xm, dX=dX))
 run("wgrad", lambda: ops.linearp_wgrad(dZ, Xb, dW, db, M, N, K))
 run("split2", lambda: ops.split_planes2(X))
+if ONLY:
+    sys.exit(0)
 # accuracy
+if M % 32 == 0 and N % 64 == 0:
+    ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb)
+    print("relu bits: kernel vs torch restatement, mismatching dwords", int((Y.bits != relu_bits(Y.float())).sum()))
 ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb)
 ref = torch.relu(X[:512].double() @ W.double().T + b.double())
 print("fwd err fp16 planes", (Y.float()[:512].double() - ref).abs().max().item(), "bf16 planes", (Yb.float()[:512].double() - ref).abs().max().item())
@@ -51,7 +76,7 @@ print("fwd err fp32 out", (C[:512].double() - ref).abs().max().item())
 ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX)
 dX1 = dX.float().clone()
 ops.linearp_dgrad(dZ, WTb, N, M, K, mask=Xm, dX=dX)
-print("dgrad bits vs planes mask: max diff", (dX.float() - dX1).abs().max().item(), "bits check", (Xm.float() - torch.relu(X)).abs().max().item())
+print("dgrad bits vs planes mask: max diff", (dX.float() - dX1).abs().max().item())
 refd = (dYf[:512].double() @ W.double()) * (X[:512] > 0)
 print("dgrad err", (dX.float()[:512].double() - refd).abs().max().item(), "scale", refd.abs().max().item())
 dW.zero_(); db.zero_()

@@ -10,11 +10,13 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 for GM in 131072 32768; do
   export GM
+  # only the three launches of a training step: forward with both output formats + ReLU bits, dgrad with the bit mask, wgrad
+  export GONLY="fwd(2fmt),dgrad(bits),wgrad"
   run() { rocprofv3 --pmc $2 --output-format csv -d $OUT/$1_$GM -o t -- python $R/scripts/bench_gemmp.py 3 > /dev/null 2>&1; }
   run fetch "FETCH_SIZE"
   run write "WRITE_SIZE"
   run sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"
-  python $R/scripts/bench_gemmp.py 10 > $OUT/bench_$GM.txt 2>&1
+  GONLY= python $R/scripts/bench_gemmp.py 10 > $OUT/bench_$GM.txt 2>&1
 done
 python - <<PY
 import csv, glob, json, hashlib, os
@@ -32,13 +34,14 @@ for rel in ("hosnerf_amd/csrc/hos_gemmp.hip", "hosnerf_amd/csrc/hos_gemm_common.
 out = {"source_hash": h.hexdigest()[:16], "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of scripts/bench_gemmp.py; "
        "hbm_bytes_per_launch = 2 x FETCH_SIZE (gfx950 wide-load correction, MI355X_MICROARCH.md) + WRITE_SIZE, counters in KB", "kernels": {}}
 for GM in (131072, 32768):
-    # the micro-benchmark launches fwd with two output formats, one format and fp32 output: ELi1E = planes forward epilogue
+    # ELi1E = planes forward epilogue, ELi2E = dgrad, '3, ' = wgrad (transpose reads); the warm-up dispatches of each line are the same configuration
     for name, tag, key in (("gemmp_fwd", "ELi1E", "gemmp_fwd[M=%d,N=1024,K=1024]" % GM), ("gemmp_dgrad", "ELi2E", "gemmp_dgrad[M=%d,N=1024,K=1024]" % GM),
                            ("gemmp_wgrad", "3, ", "gemmp_wgrad[M=1024,N=1024,K=%d]" % GM)):
         f, w = mean("fetch_%d" % GM, tag), mean("write_%d" % GM, tag)
         if f is None or w is None:
             continue
-        alg = {"gemmp_fwd": 4.0 * GM * 1024 + 2 * 4.0 * GM * 1024 * 0.67, "gemmp_dgrad": 4.0 * GM * 1024 * 3, "gemmp_wgrad": 4.0 * GM * 1024 * 2}[name]
+        # fwd: A planes in, two plane formats out (+ 1 bit per element); dgrad: dZ in, dX out (+ bits in); wgrad: dZ and X in
+        alg = {"gemmp_fwd": 4.0 * GM * 1024 * 3 + GM * 1024 / 8, "gemmp_dgrad": 4.0 * GM * 1024 * 2 + GM * 1024 / 8, "gemmp_wgrad": 4.0 * GM * 1024 * 2}[name]
         out["kernels"][key] = {"fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
                                "algorithmic_bytes_approx": alg,
                                "mfma_busy_cycles": mean("sq1_%d" % GM, tag, "SQ_VALU_MFMA_BUSY_CYCLES"), "insts_mfma": mean("sq1_%d" % GM, tag, "SQ_INSTS_MFMA"),
