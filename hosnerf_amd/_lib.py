@@ -31,6 +31,7 @@ PROTOTYPES = {
     "hos_get_gemm_mode": [],
     "hos_set_range_flag": [_P],
     "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P, _P],
+    "hos_linear_fwd_splitk": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -44,6 +45,7 @@ PROTOTYPES = {
     "hos_rays_aabb": [_P, _P, _L, _P, _P, _P, _P, _P],
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],
     "hos_deconv3d_im2col": [_P, _I, _I, _P, _P],
+    "hos_deconv3d_dpre": [_P, _P, _L, _I, _F, _I, _P, _P, _P],
     "hos_outer_accum": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_split_planes": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_linearp_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],

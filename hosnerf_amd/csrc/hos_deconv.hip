@@ -109,7 +109,55 @@ __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restric
     }
 }
 
+// dpre = g * (out > 0 ? 1 : slope) (LeakyReLU backward; leaky == 0: dpre is g itself and nothing is written) and
+// db[c] += sum_rows dpre[row][c] in the same pass.  The 256 threads of a block form (256 / CP row lanes) x (CP column lanes),
+// CP = the power of two >= min(C, 256): the last layer has 27 channels and 32 768 voxels, the inner ones 256-512 channels and
+// 8-4 096 voxels.  A block owns `rows` rows (chosen for ~1000 blocks); the row lanes are reduced through LDS, then one atomic per column and block.
+__global__ __launch_bounds__(256) void deconv3d_dpre_kernel(const float* __restrict__ g, const float* __restrict__ out, long R, int C, int CP, int rows,
+                                                            float slope, int leaky, float* __restrict__ dpre, float* __restrict__ db) {
+    __shared__ float red[256];
+    const int rl = threadIdx.x / CP, cl = threadIdx.x % CP, RL = 256 / CP;
+    const long r0 = (long)blockIdx.x * rows;
+    const long r1 = r0 + rows < R ? r0 + rows : R;
+    for (int c0 = 0; c0 < C; c0 += CP) {
+        const int c = c0 + cl;
+        float s = 0.f;
+        if (c < C) {
+            for (long r = r0 + rl; r < r1; r += RL) {
+                float v = g[r * C + c];
+                if (leaky) { if (!(out[r * C + c] > 0.f)) v *= slope; dpre[r * C + c] = v; }
+                s += v;
+            }
+        }
+        if (db == nullptr) continue;
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            for (int k = 1; k < RL; ++k) s += red[k * CP + cl];
+            __hip_atomic_fetch_add(db + c, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
+
+// dpre [R, C] = g * (out > 0 ? 1 : slope) (leaky != 0; otherwise dpre is not touched and g is the pre-activation gradient)
+// and db [C] += column sums of it (db may be NULL).  R = (2D)^3 output voxels, C = Cout, channel-last.
+// Reference: LeakyReLU(0.2) + bias gradient of the ConvTranspose3d blocks, deconv_vol_decoder.py:17-42.
+extern "C" int hos_deconv3d_dpre(const float* g, const float* out, long long R, int C, float leaky_slope, int leaky, float* dpre,
+                                 float* db, hos_stream_t stream) {
+    if (!g || R <= 0 || C <= 0 || (leaky && (!out || !dpre))) return HOS_E_ARG;
+    int CP = 1;
+    while (CP < C && CP < 256) CP <<= 1;
+    const int RL = 256 / CP;
+    long rows = (R + 1023) / 1024;
+    rows = (rows + RL - 1) / RL * RL;
+    const long blocks = (R + rows - 1) / rows;
+    hipLaunchKernelGGL(deconv3d_dpre_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, out, (long)R, C, CP,
+                       (int)rows, leaky_slope, leaky, dpre, db);
+    return hos_launch_status();
+}
 
 // gW [K, ldw] += x[M, :K]^T . dy[M, :N] for M <= 64 rows; N % 4 == 0, 16-byte aligned dy / gW rows.  Exact fp32 (FMA order:
 // m ascending).  Reference: the weight gradient of ConvTranspose3d in deconv_vol_decoder.py:34-42 for its first layers.

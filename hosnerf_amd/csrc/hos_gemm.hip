@@ -196,7 +196,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
                 if (a.kt_per_split < a.nk) gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
                 else gemm_epilogue_tile<MODE_DGRAD>(a, acc[x][y], r0, c0, lane);
             } else {
-                gemm_epilogue_tile<MODE>(a, acc[x][y], r0, c0, lane);
+                // split-K FWD (hos_linear_fwd_splitk: small output, long reduction): partial tiles with atomics into a zeroed C
+                if (a.kt_per_split < a.nk) gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
+                else gemm_epilogue_tile<MODE>(a, acc[x][y], r0, c0, lane);
             }
         }
 
@@ -287,6 +289,32 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
     if (g_gemm_mode == HOS_GEMM_BF16X3) return hos_gemm3_launch(a, MODE_FWD, 1, s);
     a.tiles_m = hos_cdiv(M, 128); a.tiles_n = hos_cdiv(N, 128);
     return launch<128, 128, MODE_FWD>(a, 1, s);
+}
+
+// C[M, N] = A[M, K] . W[N, K]^T in exact fp32 MFMA for a SMALL output with a LONG reduction (the input gradient of the volume
+// decoder's transposed convolutions: [M <= 4096, N <= 1024] from K = 1 728 .. 32 768, i.e. 8-64 output tiles): the reduction is
+// split over ~512 workgroups that add their partial tiles into the zeroed C with fp32 atomics.  No bias / epilogue.
+extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                                     hos_stream_t stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
+    if (K % BK) return HOS_E_SHAPE;
+    if ((lda & 3) || (ldw & 3) || !al16(A) || !al16(W)) return HOS_E_ALIGN;
+    GemmArgs a{};
+    a.A0 = A; a.lda0 = lda; a.kt0 = K / BK; a.B = W; a.ldb = ldw; a.C = C; a.ldc = ldc;
+    a.M = M; a.N = N; a.Mload = M; a.Nload = N;
+    a.nk = K / BK; a.red_limit = 0x7fffffff; a.epi = HOS_EPI_NONE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool few = M <= 32;
+    a.tiles_m = hos_cdiv(M, few ? 32 : 128); a.tiles_n = hos_cdiv(N, 128);
+    int splits = hos_cdiv(512, a.tiles_m * a.tiles_n);
+    if (splits > a.nk / 4) splits = a.nk / 4 > 0 ? a.nk / 4 : 1;          // >= 4 K tiles per split
+    a.kt_per_split = hos_cdiv(a.nk, splits);
+    splits = hos_cdiv(a.nk, a.kt_per_split);
+    if (splits > 1) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return few ? launch<32, 128, MODE_FWD>(a, splits, s) : launch<128, 128, MODE_FWD>(a, splits, s);
 }
 
 extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad,

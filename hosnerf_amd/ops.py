@@ -368,26 +368,31 @@ class _Deconv3d(torch.autograd.Function):
         Cin, Cout = weight.shape[0], weight.shape[1]
         M = D * D * D
         g = g.contiguous()
-        dpre = torch.where(out > 0, g, 0.2 * g) if leaky else g
+        in_place = weight.grad is not None and weight.grad.is_contiguous()
+        db_in_place = in_place and bias.grad is not None and bias.grad.is_contiguous()
+        db = bias.grad if db_in_place else torch.zeros(Cout, device=g.device)
+        # LeakyReLU backward + bias gradient: one pass (was where / mul / sum / add: 4 torch launches per layer, the [32768, 27]
+        # column sum alone 88 us)
+        dpre = torch.empty_like(g) if leaky else g
+        call("hos_deconv3d_dpre", ptr(g), ptr(out), 8 * M, Cout, 0.2, int(leaky), ptr(dpre) if leaky else None, ptr(db))
         dycol = torch.empty(M, Cout * 64, device=g.device)
         call("hos_deconv3d_im2col", ptr(dpre), D, Cout, ptr(dycol))
         Wm = weight.detach().view(Cin, Cout * 64)
         dx = None
         if ctx.needs_input_grad[0]:
-            # [M <= 4096, Cout*64 up to 32768] x [Cout*64, Cin]: a tiny output with a huge reduction -- needs split-K,
-            # which the forward-form tile kernel does not have (8 workgroups, 2.5 ms); plain library GEMM (rocBLAS)
-            dx = torch.matmul(dycol, Wm.t())
+            # [M <= 4096, Cin <= 1024] from a reduction of Cout*64 = 1 728 .. 32 768: a tiny output with a huge reduction --
+            # the forward-form tile kernel with the reduction split over ~512 workgroups (hos_linear_fwd_splitk; the library
+            # GEMM picked for these shapes took 37-107 us per layer)
+            dx = torch.empty(M, Cin, device=g.device)
+            call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(Wm), Wm.stride(0), ptr(dx), dx.stride(0), M, Cin, Cout * 64)
         with gemm_mode(GEMM_FP32):
-            in_place = weight.grad is not None and weight.grad.is_contiguous()
             gW = weight.grad.view(Cin, Cout * 64) if in_place else torch.zeros(Cin, Cout * 64, device=g.device)
             if M <= 64:      # a few voxels against 33-134 MB of weights: outer-product stream, not a tiled GEMM
                 call("hos_outer_accum", ptr(x), x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW), gW.stride(0), M, Cin, Cout * 64)
             else:
                 linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)
-        db = dpre.sum(0)
-        if in_place and bias.grad is not None:
-            bias.grad += db
-            return dx, None, None, None, None
+        if db_in_place:
+            return dx, (None if in_place else gW.view_as(weight)), None, None, None
         return dx, (None if in_place else gW.view_as(weight)), db, None, None
 
 

@@ -83,6 +83,12 @@ int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1,
                    int M, int N, int epilogue, float* aux, int aux_col, float p0, float p1,
                    const int32_t* rows_dev, hos_stream_t stream);
 
+/* C[M,N] = A[M,K] . W[N,K]^T in exact fp32 MFMA for a small output with a long reduction (K % 32 == 0; the input gradients of
+ * the volume decoder's ConvTranspose3d layers, deconv_vol_decoder.py:17-42): the reduction is split over ~512 workgroups that
+ * accumulate into the zeroed C with fp32 atomics (sums in a launch-dependent order).  Replaces a library GEMM call. */
+int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                          hos_stream_t stream);
+
 /* dX[M,K] = (dY[M,Npad] @ W[Npad,K]) (* (Xact[M,K] > 0) if Xact != NULL).
  * Npad (the reduction dim = padded layer width) multiple of 32; rows >= N of W must be zero.
  * If accumulate != 0, dX += result (used for skip / multi-consumer activations). */
@@ -206,6 +212,12 @@ int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, int Cout, f
 /* dycol[D^3][Cout*64] = gather of dpre[(2D)^3][Cout] (gradient w.r.t. the pre-activation output); zeros where a tap
  * leaves the output volume. */
 int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream);
+
+/* Backward of the block's LeakyReLU and its bias gradient in one pass over the output gradient g [R, C] (channel-last, R =
+ * (2D)^3): dpre = g * (out > 0 ? 1 : leaky_slope) if leaky != 0 (else g is already the pre-activation gradient and dpre is not
+ * written), db [C] += column sums of it (NULL: skip).  deconv_vol_decoder.py:17-42. */
+int hos_deconv3d_dpre(const float* g, const float* out, long long R, int C, float leaky_slope, int leaky, float* dpre, float* db,
+                      hos_stream_t stream);
 /* Weight gradient of the decoder's first layers (1, 8, 64 input voxels): gW [K, ldw] += x[M, :K]^T . dy[M, :N], M <= 64,
  * exact fp32, one read-add-write pass over the weights.  Reference: deconv_vol_decoder.py:34-42 (ConvTranspose3d autograd). */
 int hos_outer_accum(const float* x, int ldx, const float* dy, int lddy, float* gW, int ldw, int M, int K, int N,

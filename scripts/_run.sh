@@ -1,8 +1,4 @@
-python bench.py > gpurun_out/bench_r02_mid.json 2> gpurun_out/bench_r02_mid.err; tail -c 600 gpurun_out/bench_r02_mid.err
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/bench_r02_mid.json') if l.startswith('{')][-1])
-print(d['value'], d['ms_per_step'], d['roofline'])
-for k,v in d.get('stages',{}).items(): print(k, {kk:v[kk] for kk in v if kk in ('value','ms_per_step','torch_rocm','speedup_vs_torch_rocm','rays')})
-print(d.get('cpu_baseline')); print(d.get('torch_rocm_baseline') or d.get('torch_baseline'))
-PY
+python -m pytest tests -x -q -m gpu -k "human or stage2 or deconv or split_backward" 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_s2i -- python /root/repo/bench.py --primary stage2 --only-primary --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_s2i.log 2>&1
+cd /root/repo; grep "dpre\|gemm_kernel<128, 128, 0>\|gemm_kernel<32, 128, 0>" gpurun_out/prof_s2i/*/*kernel_stats.csv | cut -c1-200
