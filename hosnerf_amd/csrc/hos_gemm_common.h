@@ -58,8 +58,12 @@ __device__ __forceinline__ bool fwd_epilogue_value(const GemmArgs& a, float& v, 
 // per tile) -- measured at ~1 TB/s, 45 % of the whole forward GEMM.  Each group of four accumulator registers is
 // therefore transposed 4x4 across the four lanes of a quad (two xor-shuffle stages), after which a lane owns four
 // CONSECUTIVE columns of one row: 16-byte stores, 4 instructions of 8x128 B per tile, and float4 bias / mask loads.
+// bias_reg (FWD, optional): the four bias values of this lane's columns already in registers.  A persistent kernel passes
+// them so that its epilogue issues NO global load: vmcnt retires in order, so a bias load issued behind the prefetch of a
+// later tile waits for that whole prefetch (hos_thin.hip forward: 179 -> 1xx us per [262144,256,256] layer).
 template <int MODE>
-__device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x16& acc, int row0, int col0, int lane) {
+__device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x16& acc, int row0, int col0, int lane,
+                                                   const float4* bias_reg = nullptr) {
     const int l31 = lane & 31, lhi = lane >> 5;
     if constexpr (MODE == MODE_WGRAD) {
         const int col = col0 + l31;
@@ -78,7 +82,8 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
         const bool m_vec = a.mask != nullptr && ((reinterpret_cast<uintptr_t>(a.mask) & 15u) == 0) && ((a.ldmask & 3) == 0);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         bool big = false;
-        if (MODE == MODE_FWD && a.bias != nullptr) {
+        if (MODE == MODE_FWD && bias_reg != nullptr) bias4 = *bias_reg;
+        else if (MODE == MODE_FWD && a.bias != nullptr) {
             if (colb + 0 < a.N) bias4.x = a.bias[colb + 0];
             if (colb + 1 < a.N) bias4.y = a.bias[colb + 1];
             if (colb + 2 < a.N) bias4.z = a.bias[colb + 2];

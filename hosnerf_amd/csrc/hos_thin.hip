@@ -16,6 +16,10 @@
 #include "hos_gemm_common.h"
 #include <type_traits>
 
+#ifndef HOS_THIN_R_FWD
+#define HOS_THIN_R_FWD 32          // rows per forward tile (64 measured 3-5 % slower once the epilogue stopped loading the bias)
+#endif
+
 namespace {
 
 template <typename E> struct V8 { typedef E t __attribute__((ext_vector_type(8))); typedef E q __attribute__((ext_vector_type(4))); };
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     typedef typename std::conditional<DGRAD, __bf16, _Float16>::type E;
     typedef typename V8<E>::t e8;
     typedef typename V8<E>::q e4;
-    constexpr int R = DGRAD ? 32 : 64;
+    constexpr int R = DGRAD ? 32 : HOS_THIN_R_FWD;
     constexpr int KD = KS * 16;
     constexpr int P = KD * 2 + 32;                       // LDS row pitch of one plane (bytes): +32 B = 8 banks per row
     constexpr int PLANE = R * P, BUF = 2 * PLANE;        // hi, lo
@@ -156,6 +160,16 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 
     GemmArgs ef{};                                       // FWD epilogue (bias, ReLU, 16-byte stores)
     ef.C = a.C; ef.ldc = a.ldc; ef.M = a.M; ef.N = a.N; ef.bias = a.bias; ef.epi = a.epi; ef.range_flag = a.range_flag;
+    // this lane's four bias values, once: the epilogue of a tile must not issue global loads (they would queue behind the
+    // prefetch of the tile after next and wait for all of it -- vmcnt retires in order)
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!DGRAD && a.bias != nullptr) {
+        const int cb = col0 + (l31 & ~3);
+        if (cb + 0 < a.N) bias4.x = a.bias[cb + 0];
+        if (cb + 1 < a.N) bias4.y = a.bias[cb + 1];
+        if (cb + 2 < a.N) bias4.z = a.bias[cb + 2];
+        if (cb + 3 < a.N) bias4.w = a.bias[cb + 3];
+    }
 
     const int ntiles = (a.M + R - 1) / R;
     const int G = gridDim.x;
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             for (int rt = 0; rt < R / 32; ++rt) {
                 const int row0 = tile * R + rt * 32;
                 if constexpr (!DGRAD) {
-                    gemm_epilogue_tile<MODE_FWD>(ef, acc[rt], row0, col0, lane);
+                    gemm_epilogue_tile<MODE_FWD>(ef, acc[rt], row0, col0, lane, &bias4);
                 } else {
                     // quad transpose -> a lane owns four consecutive columns of one row; mask bytes from LDS; 16-byte stores
                     const int q = l31 & 3, colb = col0 + (l31 & ~3);
@@ -233,7 +247,10 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             }
         }
         TH_STAMP();
-        __syncthreads();                                 // next buffer complete; this one free for the tile after next
+        // next buffer complete; this one free for the tile after next.  (__syncthreads() is also a workgroup-scope fence
+        // = vmcnt(0); an LDS-only `s_waitcnt lgkmcnt(0); s_barrier` was measured equal here: the waves wait for the
+        // prefetched tile either way.)
+        __syncthreads();
     }
     TH_STAMP();
 #undef TH_STAMP
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 
 template <int KS, bool DGRAD>
 int launch_thin(const ThinArgs& a, hipStream_t stream) {
-    constexpr int R = DGRAD ? 32 : 64;
+    constexpr int R = DGRAD ? 32 : HOS_THIN_R_FWD;
     constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + 32) + (DGRAD ? 2 * (size_t)R * 256 : 0);
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,4 +1,3 @@
-python -m pytest tests -x -q -m gpu -k "human or stage2 or deconv or split_backward" 2>&1 | tail -2
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_s2i -- python /root/repo/bench.py --primary stage2 --only-primary --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_s2i.log 2>&1
-cd /root/repo; grep "dpre\|gemm_kernel<128, 128, 0>\|gemm_kernel<32, 128, 0>" gpurun_out/prof_s2i/*/*kernel_stats.csv | cut -c1-200
+python -m pytest tests -x -q -m gpu -k "thin or human or stage2 or stage3" 2>&1 | tail -2
+python bench.py --primary stage2 --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage2', d['ms_per_step'], d['value'])"
+python bench.py --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage3', d['ms_per_step'], d['value'])"
