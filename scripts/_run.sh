@@ -1,3 +1,2 @@
-python -m pytest tests -x -q -m gpu -k "thin or human or stage2 or stage3" 2>&1 | tail -2
-python bench.py --primary stage2 --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage2', d['ms_per_step'], d['value'])"
-python bench.py --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage3', d['ms_per_step'], d['value'])"
+bash scripts/pmc_gemmp_r02.sh > gpurun_out/pmc_r02.log 2>&1; tail -12 gpurun_out/pmc_r02.log
+python bench.py --only-primary --no-cpu-baseline 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline'])"
