@@ -1,2 +1,3 @@
-bash scripts/pmc_gemmp_r02.sh > gpurun_out/pmc_r02.log 2>&1; tail -12 gpurun_out/pmc_r02.log
-python bench.py --only-primary --no-cpu-baseline 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline'])"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_512 -- python /root/repo/bench.py --only-primary --rays 512 --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_512.log 2>&1
+cd /root/repo; grep '^{' gpurun_out/prof_512.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('512 under rocprof', d['ms_per_step'])"

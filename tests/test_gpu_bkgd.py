@@ -343,7 +343,16 @@ def test_forward_vs_golden(dev, model, fw, case, mlp_mode):
         assert maxerr(hist[l]["sdist"], fw[f"{case}_sdist{l}"]) < 5e-5
         assert maxerr(hist[l]["weights"], fw[f"{case}_weights{l}"]) < 1e-4
         assert maxerr(rend[l]["rgb"], fw[f"{case}_render{l}"]) < 1e-4, "north-star: 1e-4 RGB L-inf vs the reference"
-    assert maxerr(hist[2]["rgb"], fw[case + "_rgb2"]) < 1e-3
+    # per-sample colours are not composited yet (samples with ~zero weight carry fp32 noise of the 2^11-frequency features):
+    # bounded by the distance of the reference's OWN fp32 values from the fp64 value of its graph
+    sd64 = {k: v.double() for k, v in synth.background_state_dict(777, 2).items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in _batch(8, 11, time).items()}
+    with torch.no_grad():
+        _, hist64 = ob.mipnerf360_forward(sd64, b64, frac, randomized, 0.1, 1e6, transitions_times=[0.4],
+                                          jitters=[T(fw[f"{case}_jitter{l}"]).double() for l in range(3)] if randomized else None)
+    e_ref = maxerr(T(fw[case + "_rgb2"]).double(), hist64[2]["rgb"])
+    e_hip = maxerr(hist[2]["rgb"].double().cpu(), hist64[2]["rgb"])
+    assert e_hip <= 2.0 * e_ref + 2e-5, (e_hip, e_ref)
 
 
 def test_forward_vs_oracle_indices(dev, model, mlp_mode):
@@ -377,6 +386,11 @@ def test_gradients_vs_oracle(dev, model, fw, mlp_mode):
     loss_o, _ = ob.stage1_loss(rend_o[-1]["rgb"], b["target"], hist_o)
     loss_o.backward()
 
+    sd64 = {k: v.detach().double().requires_grad_(True) for k, v in synth.background_state_dict(777, 2).items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in b.items()}
+    rend64, hist64 = ob.mipnerf360_forward(sd64, b64, frac, True, 0.1, 1e6, transitions_times=[0.4], jitters=[j.double() for j in jit])
+    ob.stage1_loss(rend64[-1]["rgb"], b64["target"], hist64)[0].backward()
+
     model.zero_grad()
     rend, hist = model({k: v.to(dev) for k, v in b.items()}, frac, True, True, 0.1, 1e6, jitters=[j.to(dev).reshape(-1) for j in jit])
     loss, parts = stage1_loss(rend[-1]["rgb"], b["target"].to(dev), hist)
@@ -393,10 +407,12 @@ def test_gradients_vs_oracle(dev, model, fw, mlp_mode):
         if go is not None and float(go.abs().max()) > 0:
             # elementwise comparison is fragile with 128 samples (one ReLU flipping under the fp32 noise of the
             # 2^11-frequency features changes a whole row), so: cosine similarity + a loose elementwise bound
-            a, b = g.detach().double().cpu().reshape(-1), go.double().reshape(-1)
-            cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+            # ... anchored on the fp64 value of the same graph: as close to it as the fp32 oracle's own gradient is
+            a, bo, t = g.detach().double().cpu().reshape(-1), go.double().reshape(-1), sd64[n].grad.reshape(-1)
+            cos = float((a @ t) / (a.norm() * t.norm() + 1e-30))
             assert cos > 0.9995, (n, cos)
-            assert maxerr(g, go) <= 8e-2 * float(go.abs().max()), (n, maxerr(g, go))
+            e_hip, e_ref = float((a - t).abs().max()), float((bo - t).abs().max())
+            assert e_hip <= 2.0 * e_ref + 2e-4 * float(t.abs().max()), (n, e_hip, e_ref)
     # padded regions of the flat gradient stay exactly zero
     L = model.mlps[2]._views
     assert float(L.W.view(model.flat_grad)[:, 283:].abs().max()) == 0
