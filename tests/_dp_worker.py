@@ -1,0 +1,39 @@
+"""Worker of tests/test_gpu_dist.py::test_two_rank_step_equals_gradient_averaging -- launched with torch.distributed.run, two
+ranks sharing the one GPU (gloo carries the collectives).  Each rank takes the data-parallel stage-2 step of bench.py on ITS
+item (different poses / rays per rank, like the reference's per-rank dataloader); rank 0 saves the parameters after STEPS steps."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.environ.get("HOS_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+RAYS, STEPS = 512, 2
+
+
+def seed_for(rank, step):
+    return 4242 + 1000 * rank + step
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w = bench.Stage2(dev, rank, world, RAYS)
+    for i in range(STEPS):
+        torch.manual_seed(seed_for(rank, i))          # the stratified jitter of this rank's step
+        w.host_prepare(i)
+        w.eager_step(i)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"param": w.net.store.param.detach().cpu(), "rays_local": w.rays_local}, os.environ["HOS_DP_OUT"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,3 +80,50 @@ def test_bench_two_ranks_share_one_gpu_strong_scaling():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_rays"] == 4096 and d["config"]["rays_per_gpu"] == 2048
     assert d["value"] > 0 and d["steps"] == 3 and "stage-3" in d["config"]["workload"]
     assert "eager all-reduce" in d["launch"], d["launch"]          # the step was captured; the collectives stay outside the graphs
+
+
+def test_two_rank_step_equals_gradient_averaging(tmp_path):
+    """Data-parallel correctness of the human network's exchange (3.5 MB volume gradient + 4.3 MB of other parameters, decoder
+    backward on the SUM): two ranks, each on its own item, take two optimiser steps; the parameters equal those of one process
+    that accumulates the plain (un-split) backward of both items, halves the gradient and steps -- the definition of DDP."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from tests import _dp_worker as W
+    e = _env()
+    e["HOS_BENCH_ONE_GPU"] = "1"
+    e["HOS_DP_OUT"] = str(tmp_path / "dp.pt")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "tests", "_dp_worker.py")]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    got = torch.load(e["HOS_DP_OUT"])
+    dev = torch.device("cuda")
+    A = bench.Stage2(dev, 0, 2, W.RAYS)          # the network + rank 0's item
+    B = bench.Stage2(dev, 1, 2, W.RAYS)          # only its item is used
+    assert got["rays_local"] == A.rays_local == W.RAYS // 2
+    from hosnerf_amd.train import stage2_losses
+    p0 = A.net.store.param.detach().clone()
+    for i in range(W.STEPS):
+        A.opt.zero_grad()
+        A.net.split_decoder_backward = False
+        for rank, item in ((0, A.batch), (1, B.batch)):
+            torch.manual_seed(W.seed_for(rank, i))
+            loss, _ = stage2_losses(A.net(static_cycle=True, **item), item)
+            loss.backward()                       # accumulates into the flat gradient
+        A.net.store.ensure_bound()
+        A.net.store.grad.mul_(0.5)
+        A.opt.step(A.lr(i))
+    want = A.net.store.param.detach().cpu()
+    moved = float((want - p0.cpu()).abs().max())
+    err = float((got["param"] - want).abs().max())
+    assert moved > 1e-4, "the steps must have moved the parameters"
+    # Adam normalises the update to ~lr per element, so the comparison is in units of the step, not of the parameter
+    # (an element whose gradient is rounding noise gets a noise-sized update from Adam's normalisation: the worst element is
+    # bounded loosely, the bulk tightly)
+    frac_close = float(((got["param"] - want).abs() < 1e-3 * moved).float().mean())
+    from tests._record import record
+    record("dist.two_rank_step_vs_gradient_averaging[stage 2, 2 x 256 rays, 2 steps]",
+           {"max_param_step": moved, "max_abs_diff": err, "fraction_within_1e-3_of_a_step": frac_close})
+    assert err < 0.1 * moved, (err, moved)
+    assert frac_close > 0.999, frac_close
