@@ -1,3 +1,9 @@
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_512 -- python /root/repo/bench.py --only-primary --rays 512 --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_512.log 2>&1
-cd /root/repo; grep '^{' gpurun_out/prof_512.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('512 under rocprof', d['ms_per_step'])"
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+python bench.py > gpurun_out/bench_r02_final2.json 2> gpurun_out/bench_r02_final2.err
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/bench_r02_final2.json') if l.startswith('{')][-1])
+print('stage3', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['kernel'])
+for k,v in d.get('stages',{}).items(): print(k, v['value'], v['ms_per_step'], v.get('speedup_vs_torch_rocm'))
+print(d['speedup_vs_torch_rocm'], d['cpu_baseline']['value'])
+PY
