@@ -1,0 +1,76 @@
+// One-column heads on planes: out[m] = softplus( sum_k A[m][k] * w[k] + bias + p0 )  for a matrix stored as fp16 (hi, lo) planes.
+//
+// The density heads of the proposal MLPs (Linear(256, 1), M:158-160 / M:325) and the density column of the NeRF MLP's 257-wide
+// head are GEMMs with ONE output column.  Through the planes GEMM they cost a whole 256 x 128 tile per 256 rows (127 us for
+// [262144, 1, 256], ~250 us for the remainder launch of [131072, 257, 1024]) although the work is one pass over A: 268 / 537 MB.
+// Here a row is shared by LPR lanes (one 32-column block = one 128-byte line per lane and step), the products are fp32 FMAs on
+// hi + lo with the fp32 weight row (the weight is not split: exact operand), the lanes of a row are summed with xor-shuffles in a
+// fixed order (bit-reproducible).  Roofline: HBM, 4 B per element of A.
+#include "hos_common.h"
+
+namespace {
+
+typedef _Float16 hh8 __attribute__((ext_vector_type(8)));
+
+template <int LPR>
+__global__ __launch_bounds__(256) void planes_rowdot_kernel(const uint16_t* __restrict__ A, int lda, int nblk, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float p0, int softplus, long M,
+                                                            float* __restrict__ out) {
+    constexpr int RPW = 64 / LPR;                       // rows per wave and pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rsub = lane / LPR, bl = lane % LPR;
+    const long wave_id = (long)blockIdx.x * 4 + wave, nwaves = (long)gridDim.x * 4;
+    const float add = (bias != nullptr ? bias[0] : 0.f) + p0;
+    for (long r0 = wave_id * RPW; r0 < M; r0 += nwaves * RPW) {
+        const long row = r0 + rsub;
+        const long lrow = row < M ? row : M - 1;        // clamped for the loads; never stored
+        float acc = 0.f;
+        for (int blk = bl; blk < nblk; blk += LPR) {
+            const uint4* p = reinterpret_cast<const uint4*>(A + (size_t)lrow * (2 * (size_t)lda) + (size_t)blk * 64);
+            const float4* wp = reinterpret_cast<const float4*>(w + blk * 32);
+            uint4 hv[4], lv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { hv[c] = p[c]; lv[c] = p[4 + c]; }     // the whole 128-byte line in flight before the first use
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                // 8 columns per step
+                const hh8 h = __builtin_bit_cast(hh8, hv[c]);
+                const hh8 l = __builtin_bit_cast(hh8, lv[c]);
+                const float4 w0 = wp[2 * c], w1 = wp[2 * c + 1];
+                const float ws[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf((float)h[e] + (float)l[e], ws[e], acc);
+            }
+        }
+#pragma unroll
+        for (int off = LPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (bl == 0 && row < M) {
+            const float v = acc + add;
+            out[row] = softplus ? softplus_f(v) : v;
+        }
+    }
+}
+
+}  // namespace
+
+// out[M] = act( A[M, :K] . w[:K] + bias[0] + p0 ), A = fp16 planes [M][lda] (K % 32 == 0, K <= lda), w fp32 [K] (16-byte aligned),
+// bias a device scalar (may be NULL); act = torch.nn.Softplus if softplus != 0.  Replaces hos_linearp_fwd with N = 1 /
+// HOS_EPI_DENSITY and the density column of HOS_EPI_NERF_HEAD (the reference's density heads: mipnerf360/model.py:158-160, 325).
+extern "C" int hos_planes_rowdot(const void* A, int lda, int K, const float* w, const float* bias, float p0, int softplus, int64_t M,
+                                 float* out, hos_stream_t stream) {
+    if (!A || !w || !out || M <= 0 || K <= 0) return HOS_E_ARG;
+    if ((K & 31) || (lda & 31) || K > lda) return HOS_E_SHAPE;
+    if ((((uintptr_t)A) | ((uintptr_t)w)) & 15u) return HOS_E_ALIGN;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nblk = K / 32;
+    const uint16_t* Ap = static_cast<const uint16_t*>(A);
+    if (nblk <= 8) {
+        long blocks = (M + 31) / 32;                    // 8 rows per wave and pass
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(planes_rowdot_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, s, Ap, lda, nblk, w, bias, p0, softplus, (long)M, out);
+    } else {
+        long blocks = (M + 7) / 8;                      // 2 rows per wave and pass
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(planes_rowdot_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, Ap, lda, nblk, w, bias, p0, softplus, (long)M, out);
+    }
+    return hos_launch_status();
+}

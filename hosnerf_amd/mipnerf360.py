@@ -388,14 +388,24 @@ class MipNeRF360MLP(FlatModule):
         Hs = self._head
         _, bt = self._w(Hs)
         saved0 = _PlanesSaved(X16, Xb, y16, yb, WT)
+        Wh, _ = self._w(Hs)
         if self.disable_rgb:
-            ops.linearp_fwd(h, W, W16[-1], bt, P, 1, False, None, None, epilogue=ops.EPI_DENSITY, aux=density,
-                            p0=self.density_bias)
+            # Linear(width, 1) + softplus: one pass over the activation planes (a GEMM tile for one column cost 127 us per
+            # 262 144 rows against 268 MB of input)
+            if ops.ROWDOT_HEADS:
+                ops.planes_rowdot(h, W, Wh[0], bt[0:1], density, p0=self.density_bias)
+            else:
+                ops.linearp_fwd(h, W, W16[-1], bt, P, 1, False, None, None, epilogue=ops.EPI_DENSITY, aux=density,
+                                p0=self.density_bias)
             return density, None, (saved0,)
         bw = self.bottleneck_width
         Xv = torch.empty(P, XV_LD, device=dev)
-        ops.linearp_fwd(h, W, W16[-1], bt, P, bw + 1, False, None, None, C=Xv, epilogue=ops.EPI_NERF_HEAD,
-                        aux=density, aux_col=bw, p0=self.density_bias)
+        if ops.ROWDOT_HEADS:         # [bottleneck 256 | density 1]: the 256 columns as ONE column tile, the density column as a row dot
+            ops.linearp_fwd(h, W, W16[-1], bt, P, bw, False, None, None, C=Xv, epilogue=ops.EPI_NONE)
+            ops.planes_rowdot(h, W, Wh[bw], bt[bw:bw + 1], density, p0=self.density_bias)
+        else:
+            ops.linearp_fwd(h, W, W16[-1], bt, P, bw + 1, False, None, None, C=Xv, epilogue=ops.EPI_NERF_HEAD,
+                            aux=density, aux_col=bw, p0=self.density_bias)
         ops.encode_viewdirs(viewdirs, S, Xv, bw)
         hv = torch.empty(P, self.netwidth_condition, device=dev)
         Wt, bt = self._w(self._views)

@@ -215,6 +215,7 @@ class deferred_bwd_reduce:
 
 FUSED_THIN_BWD = os.environ.get("HOS_FUSED_BWD", "1") != "0"
 WGRAD_TR = os.environ.get("HOS_WGRAD_TR", "1") != "0"
+ROWDOT_HEADS = os.environ.get("HOS_ROWDOT_HEADS", "1") != "0"      # one-column heads of the planes MLPs as a row dot (hos_planes_rowdot)
 THIN_GEMM = os.environ.get("HOS_THIN_GEMM", "1") != "0"
 WGRAD_WS = os.environ.get("HOS_WGRAD_WS", "1") == "1"       # planes WGRAD: split-K partials through the slab workspace
 WGRAD_WS_MIN = int(os.environ.get("HOS_WGRAD_WS_MIN", "0"))  # ... for gradients of at least this many elements
@@ -1078,6 +1079,15 @@ def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool 
         _pp(Y), 0 if Y is None else Y.ld, _pp(Yb), 0 if Yb is None else Yb.ld,
         ptr(Y.bits, torch.int32) if (relu and Y is not None and Y.bits is not None) else 0,
         ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
+
+
+def planes_rowdot(A: Planes, K: int, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, p0: float = 0.0, softplus: bool = True):
+    """out[M] = softplus?(A[:, :K] . w[:K] + bias[0] + p0): a one-column head as one pass over the fp16 planes A (w: fp32 row of the
+    weight, 16-byte aligned; bias: 1-element device tensor or None)."""
+    M = A.rows
+    _timed(f"planes_rowdot[M={M},K={K}]", 2.0 * M * K, lambda: call(
+        "hos_planes_rowdot", _pp(A), A.ld, K, ptr(w), ptr(bias), float(p0), int(softplus), M, ptr(out)))
+    return out
 
 
 def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optional[Planes] = None,

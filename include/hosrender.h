@@ -169,6 +169,13 @@ int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, in
                     const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
                     float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream);
 
+/* One-column head on fp16 planes: out[M] = act( A[M, :K] . w[:K] + bias[0] + p0 ); A planes [M][lda], K % 32 == 0, w fp32 [K]
+ * (not split: exact operand), bias a device scalar or NULL, act = torch.nn.Softplus if softplus != 0.  One pass over A instead of
+ * a 128-wide GEMM tile per 256 rows: the density heads of the proposal MLPs (Linear(width, 1)) and the density column of the NeRF
+ * MLP's head (mipnerf360/model.py:158-160, 325).  Sums in a fixed order. */
+int hos_planes_rowdot(const void* A, int lda, int K, const float* w, const float* bias, float p0, int softplus, int64_t M,
+                      float* out, hos_stream_t stream);
+
 /* Data gradient: dX[M,K] = dZ[M,Npad] @ WT[K,Npad]^T (bf16 planes; WT = transposed weight planes), masked by the
  * ReLU bit mask hos_linearp_fwd wrote next to the layer input (mask_bits != NULL, ldmask = that input's ld; see
  * relu_bits there) or by the fp16 planes of the layer input themselves (hi > 0, mask != NULL); bf16 planes [M][lddx]. */

@@ -1,9 +1,6 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py > gpurun_out/bench_r02_final2.json 2> gpurun_out/bench_r02_final2.err
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/bench_r02_final2.json') if l.startswith('{')][-1])
-print('stage3', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline']['kernel'])
-for k,v in d.get('stages',{}).items(): print(k, v['value'], v['ms_per_step'], v.get('speedup_vs_torch_rocm'))
-print(d['speedup_vs_torch_rocm'], d['cpu_baseline']['value'])
-PY
+python -m pytest tests -x -q -m gpu -k "bkgd or stage1 or stage3 or configs or edge or stress or fullsize" 2>&1 | tail -4
+for h in 1 0 1 0; do
+export HOS_ROWDOT_HEADS=$h
+python bench.py --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('heads=$h stage3', d['ms_per_step'], d['value'])"
+python bench.py --primary stage1 --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('heads=$h stage1', d['ms_per_step'], d['value'])"
+done

@@ -165,3 +165,25 @@ def test_deferred_slab_reductions(dev):
         assert float((dWa.double() - ref).abs().max()) < tol and float((dWb.double() - ref).abs().max()) < tol
         assert float((dWa - dWb).abs().max()) < 1e-5 * float(ref.abs().max()) + 1e-7       # same partials, fp32 atomics in another order
         assert float((dba.double() - dY.double().sum(0)).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,softplus", [(131072, 256, True), (65536, 1024, True), (1000, 256, True), (777, 1024, False), (3, 64, True)])
+def test_planes_rowdot_head(dev, M, K, softplus):
+    """One-column head as a row dot over fp16 planes == fp64 on the SAME planes values (the weight row is not split), with the
+    device-scalar bias and the density bias; and it agrees with the N = 1 planes GEMM it replaces."""
+    from hosnerf_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    X = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(1, device=dev, generator=g)
+    X16, _ = ops.split_planes2(X, wantb=False)
+    out = torch.full((M,), 9.0, device=dev)
+    ops.planes_rowdot(X16, K, w, b, out, p0=-1.0, softplus=softplus)
+    z = X16.float().double() @ w.double() + b.double() - 1.0
+    ref = torch.nn.functional.softplus(z) if softplus else z
+    assert float((out.double() - ref).abs().max()) < 3e-6
+    if softplus:
+        W16, _ = ops.split_planes(w.view(1, K).contiguous(), dtype=torch.float16)
+        dens = torch.empty(M, device=dev)
+        ops.linearp_fwd(X16, K, W16, b, M, 1, False, None, None, epilogue=ops.EPI_DENSITY, aux=dens, p0=-1.0)
+        assert float((out - dens).abs().max()) < 1e-5

@@ -213,7 +213,7 @@ def test_stage3_fullsize_parity_and_speedup():
         human = oh.human_forward(hsd, gb_ref, transitions_times=[0.4], t_rand=t_rand, stage=3)
         rgb, fg, order, hw, _ = oh.stage3_composite(hist[-1]["tdist"], hist[-1]["rgb"], hist[-1]["density"], human, bb["rays_o"], bb["rays_d"],
                                                     gb_ref["newsmpl_to_scale_world"])
-        return rgb, fg, hw, human
+        return rgb, fg, hw, order
 
     cfg = default_cfg(_basedir())
     cfg.perturb = 1.0
@@ -222,15 +222,26 @@ def test_stage3_fullsize_parity_and_speedup():
     hos.human.load_state_dict(synth.human_state_dict(777, 2), strict=True)
     hos = hos.to(dev)
     with torch.no_grad():
-        rgb_o, fg_o, _, _ = oracle_render([j.view(B, 1) for j in jit])
+        rgb_o, fg_o, _, order_o = oracle_render([j.view(B, 1) for j in jit])
         out = hos.render(gb, randomized=True, is_train=True, jitters=[j.to(dev) for j in jit], t_rand=t_rand)
     fg_h = out["idx_fg"].bool()
-    # a ray whose mask sum sits within fp32 noise of the 5e-3 threshold may flip sides; everything else must agree
+    # Two discrete decisions sit behind fp32 MLP outputs and may go either way within rounding: a ray whose mask sum is within
+    # noise of the 5e-3 threshold (foreground / background), and the z-ORDER of a background sample and a human sample that
+    # coincide.  The second is a real discontinuity of the reference's composite (the later of two coinciding samples gets the
+    # whole interval to the next sample, the earlier one a zero-length interval), so a swapped pair changes that ray's colour by
+    # up to weight x colour difference: such rays are counted and bounded, every other ray must agree to 1e-4.
     flips = int((fg_h != fg_o).sum())
-    same = fg_h == fg_o
-    err = float((out["rgb"] - rgb_o)[same].abs().max())
-    _record("stage3_fullsize_parity", {"rays": B, "rgb_linf": err, "fg_rays": int(fg_o.sum()), "fg_flips": flips})
+    same_fg = fg_h == fg_o
+    same_order = torch.ones(B, dtype=torch.bool, device=dev)          # the oracle's total_order has one row per FOREGROUND ray
+    same_order[fg_o] = (out["total_order"][fg_o].long() == order_o.to(dev).long()).all(-1)
+    swapped = int((same_fg & ~same_order).sum())
+    d = (out["rgb"] - rgb_o).abs().max(-1).values
+    err = float(d[same_fg & same_order].max())
+    err_swapped = float(d[same_fg & ~same_order].max()) if swapped else 0.0
+    _record("stage3_fullsize_parity", {"rays": B, "rgb_linf": err, "fg_rays": int(fg_o.sum()), "fg_flips": flips,
+                                       "rays_with_a_swapped_coinciding_pair": swapped, "rgb_linf_on_those": err_swapped})
     assert flips <= 2 and err < 1e-4, (flips, err)
+    assert swapped <= 4 and err_swapped < 2e-2, (swapped, err_swapped)
 
     import oracle.steps as osteps
     del bsd, hsd
