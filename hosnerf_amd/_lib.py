@@ -49,6 +49,7 @@ PROTOTYPES = {
     "hos_outer_accum": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_split_planes": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_linearp_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
+    "hos_split_planes_t_batch": [_I, _P, _P, _P, _P, _P, _P, _P],
     "hos_split_planes2": [_P, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_planes_rowdot": [_P, _I, _I, _P, _P, _F, _I, _L, _P, _P],
     "hos_linearp_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P],

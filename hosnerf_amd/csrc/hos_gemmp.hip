@@ -731,6 +731,36 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// Up to SPB_MAX transposed splits in ONE launch (blockIdx.z = job): the backward pass needs the transposed bf16 planes of every
+// weight of an MLP, 5-9 small matrices per MLP call -- 29 launches of ~5 us per stage-1 step.
+constexpr int SPB_MAX = 12;
+struct SplitJob { const float* src; int lds, R, C; uint16_t* outT; int ldt; };
+struct SplitBatch { SplitJob j[SPB_MAX]; };
+__global__ __launch_bounds__(256) void split_planes_T_batch_kernel(const SplitBatch b) {
+    const SplitJob J = b.j[blockIdx.z];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (c0 >= J.C || r0 >= (J.ldt > J.R ? J.ldt : J.R)) return;
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < J.R && c < J.C) ? J.src[(size_t)r * J.lds + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;       // transposed: row index c, column r
+        if (c < J.C && r < J.ldt) {
+            uint16_t h, l;
+            split1<__bf16>(r < J.R ? tile[tx][ty + 8 * k] : 0.f, h, l);
+            const size_t o = pl_off(c, r, J.ldt);
+            J.outT[o] = h;
+            J.outT[o + 32] = l;
+        }
+    }
+}
+
 // fp32 [R][lds] -> fp16 planes and/or bf16 planes in one pass (row-major, 4 elements per thread)
 __global__ __launch_bounds__(256) void split_planes2_kernel(const float* __restrict__ src, int lds, int R, int C,
                                                             uint16_t* __restrict__ p16, int ld16,
@@ -828,6 +858,28 @@ extern "C" int hos_split_planes2(const float* src, int lds, int R, int C, void* 
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(split_planes2_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, R, C,
                        (uint16_t*)p16, p16 ? ld16 : 0, (uint16_t*)pb, pb ? ldb : 0);
+    return hos_launch_status();
+}
+
+// n <= 12 transposed bf16 splits in one launch: job i = fp32 src[i] [R[i]][lds[i]] (C[i] columns used) -> planes outT[i] [C[i]][ldt[i]]
+// (columns [R, ldt) zeroed).  The arrays are host arrays, read during the call.
+extern "C" int hos_split_planes_t_batch(int n, const float* const* src, const int* lds, const int* R, const int* C, void* const* outT,
+                                        const int* ldt, hos_stream_t stream) {
+    if (n <= 0 || n > SPB_MAX || !src || !lds || !R || !C || !outT || !ldt) return HOS_E_ARG;
+    SplitBatch b{};
+    int gx = 0, gy = 0;
+    for (int i = 0; i < SPB_MAX; ++i) {
+        const int k = i < n ? i : 0;                     // unused slots repeat job 0 (never launched: grid.z = n)
+        if (!src[k] || !outT[k] || R[k] <= 0 || C[k] <= 0) return HOS_E_ARG;
+        if (ldt[k] & 31) return HOS_E_ALIGN;
+        b.j[i] = SplitJob{src[k], lds[k], R[k], C[k], (uint16_t*)outT[k], ldt[k]};
+        if (i < n) {
+            const int rows = ldt[k] > R[k] ? ldt[k] : R[k];
+            gx = hos_cdiv(C[k], 32) > gx ? hos_cdiv(C[k], 32) : gx;
+            gy = hos_cdiv(rows, 32) > gy ? hos_cdiv(rows, 32) : gy;
+        }
+    }
+    hipLaunchKernelGGL(split_planes_T_batch_kernel, dim3(gx, gy, n), dim3(256), 0, static_cast<hipStream_t>(stream), b);
     return hos_launch_status();
 }
 

@@ -346,8 +346,7 @@ class MipNeRF360MLP(FlatModule):
         W16 = [view16(L) for L in specs]
         WT = None
         if need_t:
-            WT = [ops.split_planes(L.W.view(st.param), dtype=torch.bfloat16, transposed=True, row_major=False)[1]
-                  for L in specs]
+            WT = ops.split_planes_T_batch([L.W.view(st.param) for L in specs])        # one launch for the whole MLP
         return W16, WT
 
     def _forward_planes(self, X, viewdirs, B: int, S: int, save: bool):

@@ -1057,6 +1057,24 @@ def split_planes(src: torch.Tensor, C: Optional[int] = None, dtype=torch.float16
     return out, outT
 
 
+def split_planes_T_batch(mats):
+    """Transposed bf16 planes [C][round_up(R, 32)] of every fp32 matrix [R, C(ld)] in `mats`, 12 per launch (one launch per MLP
+    call instead of one per layer)."""
+    import ctypes
+    outs = []
+    for i0 in range(0, len(mats), 12):
+        chunk = mats[i0:i0 + 12]
+        planes = [Planes.empty(m.shape[1], round_up(m.shape[0], 32), torch.bfloat16, m.device, m.shape[0]) for m in chunk]
+        n = len(chunk)
+        src = (ctypes.c_void_p * n)(*[ptr(m) for m in chunk])
+        out = (ctypes.c_void_p * n)(*[_pp(p) for p in planes])
+        ia = lambda vals: (ctypes.c_int * n)(*vals)
+        call("hos_split_planes_t_batch", n, src, ia([m.stride(0) for m in chunk]), ia([m.shape[0] for m in chunk]),
+             ia([m.shape[1] for m in chunk]), out, ia([p.ld for p in planes]))
+        outs += planes
+    return outs
+
+
 def split_planes2(src: torch.Tensor, C: Optional[int] = None, ld: Optional[int] = None, want16: bool = True, wantb: bool = True):
     """fp32 [R, lds] -> (fp16 Planes | None, bf16 Planes | None), both row-major [R][ld], in one pass."""
     R = src.shape[0]

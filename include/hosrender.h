@@ -154,6 +154,12 @@ int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, in
 int hos_split_planes(const float* src, int lds, int R, int C, int dtype, void* out, int ldo,
                      void* outT, int ldt, hos_stream_t stream);
 
+/* n <= 12 transposed bf16 splits in ONE launch: src[i] fp32 [R[i]][lds[i]] (C[i] columns) -> planes outT[i] [C[i]][ldt[i]],
+ * columns [R[i], ldt[i]) zeroed -- the transposed weight planes hos_linearp_dgrad needs for every layer of an MLP.  The argument
+ * arrays are HOST arrays of n entries, read during the call. */
+int hos_split_planes_t_batch(int n, const float* const* src, const int* lds, const int* R, const int* C, void* const* outT,
+                             const int* ldt, hos_stream_t stream);
+
 /* fp32 [R][lds] -> fp16 planes [R][ld16] and/or bf16 planes [R][ldb] in one pass (padding columns zeroed). */
 int hos_split_planes2(const float* src, int lds, int R, int C, void* p16, int ld16, void* pb, int ldb,
                       hos_stream_t stream);
