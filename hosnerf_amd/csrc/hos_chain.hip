@@ -121,6 +121,7 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long row = tile * CROWS + wave * 32 + r;
         const long lrow = row < P ? row : P - 1;                       // clamped for loads; never stored
+        const bool tile_full = (tile + 1) * CROWS <= P;
         h8 bh[KSMAX], bl[KSMAX];
         {
             const float* e = a.E + (size_t)lrow * a.lde + 4 * hh;
@@ -149,7 +150,11 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                 // This wave's share of the chunk has landed.  vmcnt retires in issue order and the chunk's requests were issued
                 // BEFORE the 16 activation stores of the previous layer's epilogue, so at a layer's first chunk only those may
                 // still be in flight: the stores drain under the MFMAs instead of being waited for.
-                if (ob == 0 && l > 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                // (Only in a tile whose 128 rows are all live: a wave whose rows are all past P issues NO store -- an instruction
+                // with an empty EXEC mask does not count -- so "16 younger operations" would include this chunk's own requests,
+                // the wave would pass the barrier before its share of the weights has landed and the whole workgroup would
+                // multiply by stale LDS in the boundary tile of the compacted cycle set.)
+                if (ob == 0 && l > 0 && tile_full) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();                                          // ... and everybody's; the other buffer is free
                 // the next chunk (wrapping to chunk 0 for the next tile) goes into the other buffer, one request every second
@@ -170,16 +175,40 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                 h8 fh[2], fl[2];
                 CH_RD128(fh[0], la, 0);
                 CH_RD128(fl[0], la, 1024);
+                // NO fragment read may be in flight across a RUN-TIME branch: at a control-flow merge hipcc is free to copy a
+                // register (v_mov) that it believes the asm statement has already written -- while the LDS is still filling
+                // it.  The original loop decided `ks == 12` inside k-step 7 with the reads of step 8 / the last reads of step 7
+                // outstanding; the copies hipcc placed there picked up half-written fragments a few times per 10^5 launches
+                // (garbage in some rows of one wave, layer 5: found by a 600-step soak with NaN-poisoned allocations).  Steps
+                // 0..7 are now straight-line code that ends with everything landed, and the four extra steps of the skip layer
+                // are a second straight-line group inside ONE branch.
 #pragma unroll
-                for (int s = 0; s < KSMAX; ++s) {
-                    if (s < 8 || ks == 12) {
-                        const bool more = s + 1 < 8 || (ks == 12 && s + 1 < 12);
-                        if (more) {
+                for (int s = 0; s < 8; ++s) {
+                    if (s < 7) {
+                        CH_RD128(fh[(s + 1) & 1], la, (2 * s + 2) * 1024);
+                        CH_RD128(fl[(s + 1) & 1], la, (2 * s + 3) * 1024);
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[0]), "+v"(fl[0]), "+v"(fh[1]), "+v"(fl[1]));
+                    }
+#ifndef HOS_CHAIN_NO_MFMA
+                    acc[ob] = mfma3(fh[s & 1], fl[s & 1], bh[s], bl[s], acc[ob]);
+#else
+                    acc[ob][s & 15] += (float)fh[s & 1][0] + (float)fl[s & 1][1];
+#endif
+                    if ((s & 1) == 0 && (s >> 1) < nrounds) issue_round(nl, nob, npar, s >> 1);
+                }
+                if (ks == 12) {
+                    CH_RD128(fh[0], la, 16 * 1024);
+                    CH_RD128(fl[0], la, 17 * 1024);
+#pragma unroll
+                    for (int s = 8; s < 12; ++s) {
+                        if (s < 11) {
                             CH_RD128(fh[(s + 1) & 1], la, (2 * s + 2) * 1024);
                             CH_RD128(fl[(s + 1) & 1], la, (2 * s + 3) * 1024);
                             asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
                         } else {
-                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[0]), "+v"(fl[0]), "+v"(fh[1]), "+v"(fl[1]));
                         }
 #ifndef HOS_CHAIN_NO_MFMA
                         acc[ob] = mfma3(fh[s & 1], fl[s & 1], bh[s], bl[s], acc[ob]);

@@ -1,0 +1,17 @@
+"""Short soak with NaN-poisoned allocations (scripts/soak_poison.py): a training step that reads memory nobody wrote, or consumes
+the garbage of a racing kernel, shows up as a non-finite gradient.  (The round-2 chain-kernel race needed ~500 steps to show;
+this is the cheap always-on version, the long one is the script.)"""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.mark.parametrize("stage,steps,rays", [(2, 60, 2048), (3, 12, 1024)])
+def test_poisoned_allocations_never_reach_a_gradient(stage, steps, rays):
+    import soak_poison
+    assert soak_poison.run(stage, steps, seed=3, rays=rays, verbose=False) is None
