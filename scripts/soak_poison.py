@@ -3,7 +3,7 @@ so a kernel that reads memory nobody wrote -- or garbage a racing kernel produce
 of perturbing training silently.  Per step (with a host synchronisation) the flat gradient is checked per module; the outputs of
 the chain kernel are checked right after each launch.
 
-  python scripts/soak_poison.py [2|3] [steps] [seed]          # stage, default 2 / 400 / 0
+  python scripts/soak_poison.py [1|2|3] [steps] [seed] [rays]      # stage, default 2 / 400 / 0 / 2048
 This is how the intermittent garbage of `chain128_kernel` (hipcc copying a fragment register an asm ds_read was still filling) was
 found and its fix verified: 9-10 events per 14 runs of 400 steps before, 0 of 12 after."""
 import collections
@@ -44,7 +44,7 @@ def run(stage=2, steps=400, seed=0, rays=2048, verbose=True):
         import bench
         from hosnerf_amd import ops
         dev = torch.device("cuda")
-        w = (bench.Stage3 if stage == 3 else bench.Stage2)(dev, 0, 1, rays)
+        w = {1: bench.Stage1, 2: bench.Stage2, 3: bench.Stage3}[stage](dev, 0, 1, rays)
         torch.manual_seed(seed)
         state = {}
         chain = ops.mlp_chain128_fwd
@@ -98,4 +98,5 @@ def run(stage=2, steps=400, seed=0, rays=2048, verbose=True):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    sys.exit(1 if run(int(a[0]) if a else 2, int(a[1]) if len(a) > 1 else 400, int(a[2]) if len(a) > 2 else 0) else 0)
+    sys.exit(1 if run(int(a[0]) if a else 2, int(a[1]) if len(a) > 1 else 400, int(a[2]) if len(a) > 2 else 0,
+                      int(a[3]) if len(a) > 3 else 2048) else 0)

@@ -161,3 +161,21 @@ def test_training_item_on_device(dev, hos):
     with ev.evaluating(hos):
         out = hos.render(b, randomized=False, is_train=False, with_cycle=False)
     assert out["rgb"].shape == (N * P * P, 3) and bool(torch.isfinite(out["rgb"]).all())
+
+
+def test_render_frame_with_poisoned_allocations(dev, hos):
+    """The inference loop under NaN-poisoned `torch.empty` (scripts/soak_poison.py): every pixel finite and equal to the normal
+    run -- no kernel of the evaluation path reads memory nobody wrote (ragged chunks included)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import soak_poison as sp
+    from hosnerf_amd import eval as ev
+    fr, _ = make_frame(dev, 36, 28, seed=43)
+    ref = ev.render_frame(hos, fr, chunk_bkg=300)
+    torch.empty, torch.empty_like = sp.pempty, sp.pempty_like
+    try:
+        got = ev.render_frame(hos, fr, chunk_bkg=300)
+    finally:
+        torch.empty, torch.empty_like = sp._empty, sp._empty_like
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) == 0.0
