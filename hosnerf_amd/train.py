@@ -95,10 +95,22 @@ class FusedAdam:
         bc1, bc2 = 1.0 - self.betas[0] ** self.step_count, 1.0 / math.sqrt(1.0 - self.betas[1] ** self.step_count)
         if self._hyper is None:
             self._hyper = torch.empty(len(ranges), 3, device=self.module.flat_param.device)
-            self._hyper_host = torch.empty(len(ranges), 3, dtype=torch.float32).pin_memory()
+            # a RING of pinned staging buffers: the copy below is asynchronous and the host runs many replays ahead of the GPU,
+            # so rewriting ONE staging buffer would hand an earlier step the hyper-parameters of a later one.  A slot is reused
+            # only after the copy that read it has executed (its event), which also bounds the run-ahead to the ring size.
+            self._hyper_ring = [torch.empty(len(ranges), 3, dtype=torch.float32).pin_memory() for _ in range(8)]
+            self._hyper_events = [None] * len(self._hyper_ring)
+        slot = self.step_count % len(self._hyper_ring)
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()
+        host = self._hyper_ring[slot]
         for r, (_, _, mult) in enumerate(ranges):
-            self._hyper_host[r, 0], self._hyper_host[r, 1], self._hyper_host[r, 2] = lr * mult, bc1, bc2
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+            host[r, 0], host[r, 1], host[r, 2] = lr * mult, bc1, bc2
+        self._hyper.copy_(host, non_blocking=True)
+        if self._hyper.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._hyper.device))
+            self._hyper_events[slot] = ev
 
     def zero_grad(self):
         self.module.store.zero_grad()

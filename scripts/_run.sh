@@ -1,3 +1,3 @@
-for sd in 1 2 3; do python scripts/soak_poison.py 1 500 $sd 1024 2>&1 | grep -v amdgpu | tail -1; done
-for sd in 1 2; do python scripts/soak_poison.py 3 200 $sd 4096 2>&1 | grep -v amdgpu | tail -1; done
-for sd in 21 22 23 24 25 26; do python scripts/soak_poison.py 2 500 $sd 2048 2>&1 | grep -v amdgpu | tail -1; done
+python -m pytest tests -x -q -m gpu -k "adam or stage2 or stage3 or dist or bkgd or launcher or soak" 2>&1 | tail -3
+python bench.py --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage3', d['ms_per_step'], d['value'], d['final_loss'])"
+python bench.py --primary stage2 --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage2', d['ms_per_step'], d['value'], d['final_loss'])"
