@@ -1,3 +1,3 @@
-python -m pytest tests -x -q -m gpu -k "adam or stage2 or stage3 or dist or bkgd or launcher or soak" 2>&1 | tail -3
-python bench.py --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage3', d['ms_per_step'], d['value'], d['final_loss'])"
-python bench.py --primary stage2 --only-primary 2>&1 | grep '^{' | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('stage2', d['ms_per_step'], d['value'], d['final_loss'])"
+for sd in 1 2 3 4 5 6; do SOAK_GEMM=fp32 python scripts/soak_poison.py 2 500 $sd 2048 2>&1 | grep -v amdgpu | tail -1 | cut -c1-300; done
+for sd in 61 62; do python scripts/soak_poison.py 3 500 $sd 4096 2>&1 | grep -v amdgpu | tail -1; done
+for sd in 71 72; do python scripts/soak_poison.py 1 1500 $sd 1024 2>&1 | grep -v amdgpu | tail -1; done

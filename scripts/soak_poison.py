@@ -3,7 +3,7 @@ so a kernel that reads memory nobody wrote -- or garbage a racing kernel produce
 of perturbing training silently.  Per step (with a host synchronisation) the flat gradient is checked per module; the outputs of
 the chain kernel are checked right after each launch.
 
-  python scripts/soak_poison.py [1|2|3] [steps] [seed] [rays]      # stage, default 2 / 400 / 0 / 2048
+  [SOAK_GEMM=planes|split|fp32] python scripts/soak_poison.py [1|2|3] [steps] [seed] [rays]      # stage, default 2 / 400 / 0 / 2048
 This is how the intermittent garbage of `chain128_kernel` (hipcc copying a fragment register an asm ds_read was still filling) was
 found and its fix verified: 9-10 events per 14 runs of 400 steps before, 0 of 12 after."""
 import collections
@@ -44,6 +44,7 @@ def run(stage=2, steps=400, seed=0, rays=2048, verbose=True):
         import bench
         from hosnerf_amd import ops
         dev = torch.device("cuda")
+        ops.set_gemm_mode({"planes": ops.GEMM_PLANES, "split": ops.GEMM_BF16X3, "fp32": ops.GEMM_FP32}[os.environ.get("SOAK_GEMM", "planes")])
         w = {1: bench.Stage1, 2: bench.Stage2, 3: bench.Stage3}[stage](dev, 0, 1, rays)
         torch.manual_seed(seed)
         state = {}
