@@ -107,6 +107,11 @@ __global__ __launch_bounds__(CT) void compact_scatter_kernel(const float* mask, 
     }
 }
 
+// (a kernel instead of hipMemsetAsync: see zero2d_kernel in hos_gemm.hip -- memset nodes of a captured graph)
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 __global__ __launch_bounds__(CT) void scatter_rows_kernel(const float* src, const int* sel, const int* count, long P, float* dst) {
     const long i = (long)blockIdx.x * CT + threadIdx.x;
     if (i >= P) return;
@@ -138,8 +143,11 @@ extern "C" int hos_compact_rows(const float* mask, float thr, const float* src_a
 extern "C" int hos_scatter_rows(const float* src, const int32_t* sel, const int32_t* count, int64_t P, float* dst, hos_stream_t stream) {
     if (!src || !sel || !count || !dst || P <= 0) return HOS_E_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(dst, 0, (size_t)P * 3 * sizeof(float), s);
-    if (e != hipSuccess) return static_cast<int>(e);
+    {
+        long blocks = (P * 3 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, (long)P * 3);
+    }
     hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((P + CT - 1) / CT)), dim3(CT), 0, s, src, sel, count, (long)P, dst);
     return hos_launch_status();
 }

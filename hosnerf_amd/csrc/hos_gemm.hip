@@ -240,6 +240,23 @@ int launch(const GemmArgs& a, int splits, hipStream_t stream) {
     return hos_launch_status();
 }
 
+// Zero a [rows][cols] window of a row-major fp32 matrix.  A KERNEL, not hipMemset2DAsync: inside a captured hipGraph the memset
+// node of ROCm 7.2 was observed to lose its ordering against the neighbouring kernel nodes once in ~10^4 replays (the split-K
+// accumulators then started from the previous replay's sums or were cleared under the atomics: gradients of 1e14 .. inf in
+// captured training steps, scripts/soak_graph.py); kernel nodes keep stream order.
+__global__ __launch_bounds__(256) void zero2d_kernel(float* __restrict__ p, long ld, int rows, int cols) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+inline int zero2d(float* p, long ld, int rows, int cols, hipStream_t s) {
+    const long total = (long)rows * cols;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero2d_kernel, dim3(blocks), dim3(256), 0, s, p, ld, rows, cols);
+    return hos_launch_status();
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int g_gemm_mode = HOS_GEMM_BF16X3;
@@ -311,8 +328,8 @@ extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, in
     a.kt_per_split = hos_cdiv(a.nk, splits);
     splits = hos_cdiv(a.nk, a.kt_per_split);
     if (splits > 1) {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
-        if (e != hipSuccess) return (int)e;
+        const int rc = zero2d(C, ldc, M, N, s);
+        if (rc != 0) return rc;
     }
     return few ? launch<32, 128, MODE_FWD>(a, splits, s) : launch<128, 128, MODE_FWD>(a, splits, s);
 }
@@ -347,8 +364,8 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
         a.kt_per_split = hos_cdiv(a.nk, splits);
         splits = hos_cdiv(a.nk, a.kt_per_split);
         if (splits > 1) {
-            hipError_t e = hipMemset2DAsync(dX, (size_t)lddx * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, s);
-            if (e != hipSuccess) return (int)e;
+            const int rc = zero2d(dX, lddx, M, K, s);
+            if (rc != 0) return rc;
         }
         return launch<32, 128, MODE_DGRAD>(a, splits, s);
     }

@@ -15,3 +15,13 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 def test_poisoned_allocations_never_reach_a_gradient(stage, steps, rays):
     import soak_poison
     assert soak_poison.run(stage, steps, seed=3, rays=rays, verbose=False) is None
+
+
+def test_captured_step_replays_stay_finite():
+    """scripts/soak_graph.py: the stage-2 step captured like bench.py does, 90 replays without host synchronisation, loss and
+    per-module gradient norms recorded after every replay.  Before the hipMemset nodes of the library were replaced by kernels
+    (hos_gemm.hip::zero2d_kernel) this configuration produced gradients of 1e14 .. inf at replay 40-53, every run."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_graph.py"), "2", "90"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "ok: 90 replays" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
