@@ -339,9 +339,10 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(MlpBwdArgs a) {
 }
 
 // dW[n][k] += sum over slabs g of ws[g][n][k].  Block (x, y): 256 threads x float4 = 1024 consecutive elements, slabs
-// y, y + 32, ... (8 of 256): all eight 16-byte loads of a thread are issued before the first add (one memory latency
-// per thread, 2048 blocks in flight), then 32-way fp32 atomics.
-constexpr int MB_RSPLIT = 32;
+// y, y + sy, ... in rounds of eight 16-byte loads issued before the first add (one memory latency per round), then
+// sy-way fp32 atomics into dW.  sy = 2: device-scope fp32 atomics are the bottleneck, not the loads -- the batched
+// reduction of a stage-2 step (770 MB of slabs) takes 4 x 98 us at sy = 32, 4 x 48 us (4 TB/s) at sy = 2..4, 59 us at 1.
+constexpr int MB_RSPLIT = 2;
 __global__ __launch_bounds__(256) void mlp_bwd_reduce_kernel(const float* __restrict__ ws, int slabs, int n_, int k_, int nk, float* __restrict__ dW,
                                                              int lddw, float* __restrict__ db, int N, int K) {
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;

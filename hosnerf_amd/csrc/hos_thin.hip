@@ -51,6 +51,7 @@ struct ThinArgs {
 };
 
 constexpr int TH_NT = 512;
+constexpr int TH_MP = 264;     // LDS pitch of a mask row: 256 columns + the 16-byte group a window at an unaligned column spills into
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // KS: reduction steps of 16 (K <= 16 KS).  R: rows per tile (64 FWD, 32 DGRAD: the mask tile needs the registers).
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     constexpr int KD = KS * 16;
     constexpr int P = KD * 2 + 32;                       // LDS row pitch of one plane (bytes): +32 B = 8 banks per row
     constexpr int PLANE = R * P, BUF = 2 * PLANE;        // hi, lo
-    constexpr int MSK = DGRAD ? R * 256 : 0;             // mask bytes [R][256] per buffer
+    constexpr int MSK = DGRAD ? R * TH_MP : 0;           // mask bytes [R][TH_MP] per buffer
     constexpr int AU = R * (KD / 4) / TH_NT;             // float4 units of the A tile per thread
     constexpr int MU = DGRAD ? R * 64 / TH_NT : 1;       // float4 units of the mask tile per thread (256 columns)
     static_assert(AU >= 1, "tile too small");
@@ -113,7 +114,13 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
         }
     }
 
-    float4 ra[AU], rm[MU];
+    // ReLU mask window at an unaligned column (the h part of a skip layer's concat row starts at column 127): msh = its offset
+    // inside a 16-byte group.  The loads stay ALIGNED on the enclosing groups (64 of them, +1 when msh != 0: `rmx`, by the
+    // first R threads) -- dwordx4 loads at 4-byte aligned addresses run at about half the rate (measured: +120 us on a 142 us
+    // launch) -- the byte tile in LDS keeps the group positions and the epilogue shifts by msh (v_alignbyte).
+    const int msh = (int)((reinterpret_cast<uintptr_t>(a.mask) >> 2) & 3u);
+    const float* const mbase = a.mask - msh;
+    float4 ra[AU], rm[MU], rmx = make_float4(0.f, 0.f, 0.f, 0.f);
     auto gload = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < AU; ++i) {
@@ -127,7 +134,11 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
                 for (int i = 0; i < MU; ++i) {
                     const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
                     const int gr = tile * R + row;
-                    rm[i] = (gr < a.M && c4 * 4 < a.N) ? ld4(a.mask + (size_t)gr * a.ldmask + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    rm[i] = (gr < a.M && c4 * 4 < a.N + msh) ? ld4(mbase + (size_t)gr * a.ldmask + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (msh != 0 && t < R) {
+                    const int gr = tile * R + t;
+                    rmx = (gr < a.M && 256 < a.N + msh) ? ld4(mbase + (size_t)gr * a.ldmask + 256) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -152,7 +163,12 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
                     const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
                     const uint32_t m = (rm[i].x > 0.f ? 1u : 0u) | (rm[i].y > 0.f ? 0x100u : 0u) | (rm[i].z > 0.f ? 0x10000u : 0u) |
                                        (rm[i].w > 0.f ? 0x1000000u : 0u);
-                    *reinterpret_cast<uint32_t*>(msk0 + b * MSK + row * 256 + c4 * 4) = m;
+                    *reinterpret_cast<uint32_t*>(msk0 + b * MSK + row * TH_MP + c4 * 4) = m;
+                }
+                if (msh != 0 && t < R) {
+                    const uint32_t m = (rmx.x > 0.f ? 1u : 0u) | (rmx.y > 0.f ? 0x100u : 0u) | (rmx.z > 0.f ? 0x10000u : 0u) |
+                                       (rmx.w > 0.f ? 0x1000000u : 0u);
+                    *reinterpret_cast<uint32_t*>(msk0 + b * MSK + t * TH_MP + 256) = m;
                 }
             }
         }
@@ -232,7 +248,9 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
                         if (row >= a.M || colb >= a.N) continue;
                         float v[4] = {v0, v1, v2, v3};
                         if (a.mask != nullptr) {
-                            const uint32_t m = *reinterpret_cast<const uint32_t*>(msk0 + b * MSK + (rt * 32 + lrow) * 256 + colb);
+                            const char* const mp = msk0 + b * MSK + (rt * 32 + lrow) * TH_MP + colb;
+                            uint32_t m = *reinterpret_cast<const uint32_t*>(mp);
+                            if (msh != 0) m = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(mp + 4), m, (uint32_t)msh);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) if (!((m >> (8 * k)) & 1u)) v[k] = 0.f;
                         }
@@ -259,7 +277,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 template <int KS, bool DGRAD>
 int launch_thin(const ThinArgs& a, hipStream_t stream) {
     constexpr int R = DGRAD ? 32 : HOS_THIN_R_FWD;
-    constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + 32) + (DGRAD ? 2 * (size_t)R * 256 : 0);
+    constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + 32) + (DGRAD ? 2 * (size_t)R * TH_MP : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_gemm_kernel<KS, DGRAD>),
@@ -287,12 +305,14 @@ extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int 
 }
 
 // dX[M, K] = (dY[M, :Npad] . W[:Npad, :K]) * [mask > 0], K <= 256 output columns, Npad <= 256 (Npad % 4 == 0; rows of W and
-// columns of dY beyond the layer's width are zero by contract).  mask: the layer's input activations [M, >= K] or NULL.
+// columns of dY beyond the layer's width are zero by contract).  mask: the layer's input activations [M, >= K] or NULL;
+// W and mask may start at ANY column of their matrices (4-byte aligned: the h part of a skip layer's concat row starts at
+// column 127; the mask's 16-byte groups around the window must be readable), dY and dX rows are 16-byte aligned.
 extern "C" int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
                                      float* dX, int lddx, int M, int K, hos_stream_t stream) {
     if (!dY || !W || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
     if (K > 256 || Npad > 256) return HOS_E_SHAPE;
-    if ((lddy & 3) || (Npad & 3) || (mask && (ldmask & 3)) || (((uintptr_t)dY | (uintptr_t)mask) & 15u)) return HOS_E_ALIGN;
+    if ((lddy & 3) || (Npad & 3) || (mask && (ldmask & 3)) || ((uintptr_t)dY & 15u) || (((uintptr_t)W | (uintptr_t)mask) & 3u)) return HOS_E_ALIGN;
     ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask, ldmask};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return Npad <= 128 ? launch_thin<8, true>(a, s) : launch_thin<16, true>(a, s);

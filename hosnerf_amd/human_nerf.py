@@ -483,10 +483,18 @@ class Network(FlatModule):
                 if i == 5:
                     tmp_b[5] = torch.zeros(L.Npad, device=dev)
                     ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
-                    dCAT = torch.empty(Pn, CNL_CAT, device=dev)
-                    ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
                     nxt = torch.empty(Pn, 256, device=dev)
-                    ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)                 # h-part of the concat, through layer 4's ReLU
+                    if ops.thin_dgrad_rows(Pn):
+                        # the two consumers of d(concat row) take their own column windows straight from the weight: the
+                        # Fourier part (63 columns; the state embedding's gradient goes through db below) and the h part
+                        # (columns 127..382, through layer 4's ReLU) -- no [P, 384] round trip, no slice + mask pass
+                        dCAT = torch.empty(Pn, 64, device=dev)
+                        ops.linear_dgrad(dz, Wt, 256, 64, dCAT, thin=True)
+                        ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=CAT, w_col0=127, mask_col0=127)
+                    else:
+                        dCAT = torch.empty(Pn, CNL_CAT, device=dev)
+                        ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
+                        ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)             # h-part of the concat, through layer 4's ReLU
                     dz = nxt
                 elif i == 0:
                     tmp_b[0] = torch.zeros(L.Npad, device=dev)

@@ -112,23 +112,31 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
     return out
 
 
+def thin_dgrad_rows(M: int) -> bool:
+    """True when `linear_dgrad` of a <= 256-wide layer over M rows runs on the thin kernel (which takes W / mask windows at any
+    column; the tiled GEMMs need 16-byte aligned windows)."""
+    return bool(THIN_GEMM and M >= 16384 and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3)
+
+
 def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torch.Tensor,
-                 mask_src: Optional[torch.Tensor] = None, accumulate: bool = False, w_col0: int = 0):
-    """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src > 0)."""
+                 mask_src: Optional[torch.Tensor] = None, accumulate: bool = False, w_col0: int = 0, mask_col0: int = 0,
+                 thin: bool = False):
+    """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src[:, mask_col0:mask_col0+K] > 0).
+    `thin`: take the thin kernel also for K <= 128 output columns (by default those go to the tiled GEMM)."""
     M = dY.shape[0]
     wptr = ptr(W) + 4 * w_col0
-    if (THIN_GEMM and not accumulate and Npad <= 256 and Npad % 4 == 0 and K > 128 and M >= 16384
-            and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
+    mptr = None if mask_src is None else ptr(mask_src) + 4 * mask_col0
+    if (not accumulate and Npad <= 256 and Npad % 4 == 0 and (K > 128 or thin) and thin_dgrad_rows(M)):
         # output columns in chunks of <= 256 (the skip layer's [P,384] input gradient is two launches)
         for k0 in range(0, K, 256):
             kc = min(256, K - k0)
             _timed(f"thin_dgrad[M={M},N={kc},K={Npad}]", 2.0 * M * kc * Npad, lambda: call(
                 "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr + 4 * k0, W.stride(0), Npad,
-                None if mask_src is None else ptr(mask_src) + 4 * k0, 0 if mask_src is None else mask_src.stride(0),
+                None if mptr is None else mptr + 4 * k0, 0 if mask_src is None else mask_src.stride(0),
                 ptr(out) + 4 * k0, out.stride(0), M, kc))
         return out
     _timed(f"gemm_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
-        "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, ptr(mask_src),
+        "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, mptr,
         0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K, int(accumulate)))
     return out
 

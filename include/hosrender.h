@@ -132,7 +132,9 @@ int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, floa
 
 /* Thin layers over very many rows with the weight slice of every wave resident in registers (hos_thin.hip): N, K <= 256.
  *   hos_thin_linear_fwd  : Y [M,N] = epi(X[:, :K] . W[:N, :K]^T + bias), epilogue HOS_EPI_NONE / HOS_EPI_RELU (fp16 hi/lo x3)
- *   hos_thin_linear_dgrad: dX [M,K] = (dY[:, :Npad] . W[:Npad, :K]) * [mask > 0]  (bf16 hi/lo x3; mask NULL: none)
+ *   hos_thin_linear_dgrad: dX [M,K] = (dY[:, :Npad] . W[:Npad, :K]) * [mask > 0]  (bf16 hi/lo x3; mask NULL: none); W and mask
+ *                          may start at any column of their matrices (4-byte alignment: the h part of the skip layer's concat row
+ *                          starts at column 127, mlp_rgb_sigma.py:53-55), dY and dX rows are 16-byte aligned
  * Same results contract as hos_linear_fwd / hos_linear_dgrad in split mode.
  * Reference: CanonicalMLP, canonical_mlps/mlp_rgb_sigma.py:49-58 (256-wide Linear + ReLU chain at M = rays x 128). */
 int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,

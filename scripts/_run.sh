@@ -1,4 +1,4 @@
-n=0; for t in $(seq 1 10); do r=$(python scripts/soak_graph.py 2 600 2>&1 | grep -v amdgpu | grep 'EVENT\|^ok' | cut -c1-60); case "$r" in ok*) ;; *) n=$((n+1)); echo "  $r";; esac; done; echo "soak_graph stage2 600 replays: $n events of 10"
-n=0; for t in $(seq 1 4); do r=$(python scripts/soak_graph.py 3 300 4096 2>&1 | grep -v amdgpu | grep 'EVENT\|^ok' | cut -c1-60); case "$r" in ok*) ;; *) n=$((n+1)); echo "  $r";; esac; done; echo "soak_graph stage3 300 replays: $n events of 4"
-n=0; for t in $(seq 1 4); do r=$(python scripts/soak_graph.py 1 800 1024 2>&1 | grep -v amdgpu | grep 'EVENT\|^ok' | cut -c1-60); case "$r" in ok*) ;; *) n=$((n+1)); echo "  $r";; esac; done; echo "soak_graph stage1 800 replays: $n events of 4"
-n=0; for t in $(seq 1 6); do r=$(SOAK_GEMM=fp32 python scripts/soak_graph.py 2 400 2>&1 | grep -v amdgpu | grep 'EVENT\|^ok' | cut -c1-60); case "$r" in ok*) ;; *) n=$((n+1)); echo "  $r";; esac; done; echo "soak_graph fp32 stage2 400 replays: $n events of 6"
+python -m pytest tests/test_gpu_human.py -x -q 2>&1 | tail -2
+for v in 1 0 1 0; do echo "DPE_THIN=$v $(HOS_DPE_THIN=$v python bench.py --primary stage2 --only-primary --steps 100 --warmup 10 2>&1 | grep -o '"ms_per_step": [0-9.]*' | head -1)"; done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/prof_dcat2 -- python /root/repo/bench.py --primary stage2 --only-primary --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_dcat2.log 2>&1

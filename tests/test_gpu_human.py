@@ -400,6 +400,30 @@ def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     assert bool(torch.isnan(out[:, K:]).all())
 
 
+def test_thin_linear_dgrad_unaligned_windows(dev):
+    """The skip layer of the canonical MLP: the h part of the concat row starts at column 127, so the backward takes a
+    [256, 256] window of the weight and of the ReLU mask source at a 4-byte aligned column (no [P, 384] round trip)."""
+    from hosnerf_amd import ops
+    ops.set_gemm_mode(ops.GEMM_PLANES)
+    M = 16500
+    g = torch.Generator().manual_seed(127)
+    dY = torch.randn(M, 256, generator=g) * 1e-3
+    W = torch.randn(256, 384, generator=g) / 16
+    CAT = torch.randn(M, 384, generator=g)
+    CAT = torch.where(torch.rand(M, 384, generator=g) < 0.4, torch.zeros_like(CAT), CAT.abs())
+    out = torch.full((M, 256), float("nan"), device=dev)
+    ev = ops.KernelEvents()
+    ops.set_kernel_events(ev)
+    try:
+        ops.linear_dgrad(dY.to(dev), W.to(dev), 256, 256, out, mask_src=CAT.to(dev), w_col0=127, mask_col0=127)
+    finally:
+        ops.set_kernel_events(None)
+    assert all(k.startswith("thin_dgrad") for k in ev.records), list(ev.records)
+    want = (dY.double() @ W[:, 127:383].double()) * (CAT[:, 127:383] > 0)
+    got = out.double().cpu()
+    assert float((got - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("M", [1, 37, 64, 129])
 def test_thin_and_fused_entry_points_small_m(dev, M):
     """The C-ABI entries are routed to only for many rows, but they are complete kernels: ragged / tiny row counts through
