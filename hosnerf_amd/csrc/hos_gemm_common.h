@@ -61,9 +61,13 @@ __device__ __forceinline__ bool fwd_epilogue_value(const GemmArgs& a, float& v, 
 // bias_reg (FWD, optional): the four bias values of this lane's columns already in registers.  A persistent kernel passes
 // them so that its epilogue issues NO global load: vmcnt retires in order, so a bias load issued behind the prefetch of a
 // later tile waits for that whole prefetch (hos_thin.hip forward: 179 -> 1xx us per [262144,256,256] layer).
+// relu_bits (FWD, optional): receives one bit per element this lane stores -- bit 15 - (4 g + k) = (row row0 + q + 8 g +
+// 4 (lane>>5), column col0 + (lane & 28) + k) came out > 0 -- the ReLU mask of the backward pass in the ownership a lane has
+// AFTER the quad transpose (hos_thin.hip keeps it as 2 bytes per lane and tile instead of re-reading the fp32 activations).
+// Two VALU per element: the sign of 0 - v is shifted in from the right (v_sub, v_alignbit).
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x16& acc, int row0, int col0, int lane,
-                                                   const float4* bias_reg = nullptr) {
+                                                   const float4* bias_reg = nullptr, uint32_t* relu_bits = nullptr) {
     const int l31 = lane & 31, lhi = lane >> 5;
     if constexpr (MODE == MODE_WGRAD) {
         const int col = col0 + l31;
@@ -101,12 +105,21 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                 if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
             }
             const int row = row0 + q + 8 * g + 4 * lhi;
-            if (row >= a.M || colb >= a.N) continue;
+            if (row >= a.M || colb >= a.N) {
+                if (MODE == MODE_FWD && relu_bits != nullptr) *relu_bits <<= 4;
+                continue;
+            }
             float v[4] = {v0, v1, v2, v3};
             const bool full = colb + 3 < a.N;
             if constexpr (MODE == MODE_FWD) {
                 v[0] += bias4.x; v[1] += bias4.y; v[2] += bias4.z; v[3] += bias4.w;
                 const bool simple = (a.epi == HOS_EPI_NONE || a.epi == HOS_EPI_RELU);
+                if (relu_bits != nullptr) {
+                    uint32_t rb = *relu_bits;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rb = __builtin_amdgcn_alignbit(rb, __float_as_uint(0.f - v[k]), 31);
+                    *relu_bits = rb;
+                }
                 if (simple && full && c_vec) {
                     if (a.epi == HOS_EPI_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                     big |= fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT;

@@ -48,6 +48,8 @@ struct ThinArgs {
     int epi;                          // FWD: HOS_EPI_NONE / HOS_EPI_RELU
     const float* mask; int ldmask;    // DGRAD: ReLU mask source [M, >= N] (NULL: none)
     unsigned int* range_flag;         // FWD: see HOS_RANGE_LIMIT
+    uint16_t* bits;                   // ReLU bit mask [ceil(M/32)][8 waves][64 lanes] x 16 bits (FWD: written; DGRAD: read instead of
+                                      // `mask`), bit 15 - (4 g + k) of a lane = the element it owns after the quad transpose (NULL: none)
 };
 
 constexpr int TH_NT = 512;
@@ -121,6 +123,9 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     const int msh = (int)((reinterpret_cast<uintptr_t>(a.mask) >> 2) & 3u);
     const float* const mbase = a.mask - msh;
     float4 ra[AU], rm[MU], rmx = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ReLU mask as bits (a.bits, written by the forward kernel of the layer below in THIS kernel's tile / wave / lane order):
+    // 2 bytes per lane and tile travel with the prefetch instead of 32 x 256 x 4 B of activations through LDS
+    uint32_t rbits = 0, bits_staged = 0, bits_cur = 0;
     auto gload = [&](int tile) {
 #pragma unroll
         for (int i = 0; i < AU; ++i) {
@@ -129,7 +134,8 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             ra[i] = (gr < a.M && c4 * 4 < a.K) ? ld4(a.A + (size_t)gr * a.lda + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if constexpr (DGRAD) {
-            if (a.mask != nullptr) {
+            if (a.bits != nullptr) rbits = a.bits[(size_t)tile * TH_NT + t];
+            else if (a.mask != nullptr) {
 #pragma unroll
                 for (int i = 0; i < MU; ++i) {
                     const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             *reinterpret_cast<e4*>(lo + row * P + c4 * 8) = l;
         }
         if constexpr (DGRAD) {
-            if (a.mask != nullptr) {
+            if (a.bits != nullptr) bits_staged = rbits;
+            else if (a.mask != nullptr) {
 #pragma unroll
                 for (int i = 0; i < MU; ++i) {
                     const int u = t + TH_NT * i, row = u >> 6, c4 = u & 63;
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     for (; tile < ntiles; tile += G, b ^= 1) {
         const bool more = tile + G < ntiles;
         TH_STAMP();
+        if constexpr (DGRAD) bits_cur = bits_staged;      // this tile's ReLU bits (staged together with its operands)
         const char* hi = buf0 + b * BUF + l31 * P + lhi * 16;
         f32x16 acc[R / 32];
 #pragma unroll
@@ -229,7 +237,9 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             for (int rt = 0; rt < R / 32; ++rt) {
                 const int row0 = tile * R + rt * 32;
                 if constexpr (!DGRAD) {
-                    gemm_epilogue_tile<MODE_FWD>(ef, acc[rt], row0, col0, lane, &bias4);
+                    uint32_t rb = 0;       // ReLU bits of this lane's 16 outputs (one copy of the epilogue code: the bits always
+                    gemm_epilogue_tile<MODE_FWD>(ef, acc[rt], row0, col0, lane, &bias4, &rb);      // form, the store is optional)
+                    if (a.bits != nullptr) a.bits[((size_t)tile * (R / 32) + rt) * TH_NT + t] = (uint16_t)rb;
                 } else {
                     // quad transpose -> a lane owns four consecutive columns of one row; mask bytes from LDS; 16-byte stores
                     const int q = l31 & 3, colb = col0 + (l31 & ~3);
@@ -247,7 +257,11 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
                         const int lrow = q + 8 * g + 4 * lhi, row = row0 + lrow;
                         if (row >= a.M || colb >= a.N) continue;
                         float v[4] = {v0, v1, v2, v3};
-                        if (a.mask != nullptr) {
+                        if (a.bits != nullptr) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)       // bit -> all-ones / zero (v_bfe_i32), AND: 2 VALU per element
+                                v[k] = __uint_as_float(__float_as_uint(v[k]) & (uint32_t)__builtin_amdgcn_sbfe((int)bits_cur, 15 - (4 * g + k), 1));
+                        } else if (a.mask != nullptr) {
                             const char* const mp = msk0 + b * MSK + (rt * 32 + lrow) * TH_MP + colb;
                             uint32_t m = *reinterpret_cast<const uint32_t*>(mp);
                             if (msh != 0) m = __builtin_amdgcn_alignbyte(*reinterpret_cast<const uint32_t*>(mp + 4), m, (uint32_t)msh);
@@ -294,12 +308,15 @@ int launch_thin(const ThinArgs& a, hipStream_t stream) {
 }  // namespace
 
 // Y[M, N] = epi(X[M, :K] . W[:N, :K]^T + bias), N <= 256, K <= 256 (K % 4 == 0), epilogue HOS_EPI_NONE or HOS_EPI_RELU.
+// relu_bits (optional, 2 * 512 * ceil(M / 32) bytes): one bit per output element = "came out > 0", in the order the backward
+// kernel (hos_thin_linear_dgrad, mask_bits) consumes it; a waves's 32 columns that lie at or beyond N are not written.
 extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
-                                   int M, int N, int K, int epilogue, hos_stream_t stream) {
+                                   int M, int N, int K, int epilogue, void* relu_bits, hos_stream_t stream) {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
     if (N > 256 || K > 256 || (epilogue != HOS_EPI_NONE && epilogue != HOS_EPI_RELU)) return HOS_E_SHAPE;
     if ((ldx & 3) || (ldw & 3) || (K & 3) || (((uintptr_t)X | (uintptr_t)W) & 15u)) return HOS_E_ALIGN;
-    ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0, hos_range_flag_ptr()};
+    if (relu_bits && ((uintptr_t)relu_bits & 1u)) return HOS_E_ALIGN;
+    ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0, hos_range_flag_ptr(), static_cast<uint16_t*>(relu_bits)};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return K <= 128 ? launch_thin<8, false>(a, s) : launch_thin<16, false>(a, s);
 }
@@ -308,12 +325,16 @@ extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int 
 // columns of dY beyond the layer's width are zero by contract).  mask: the layer's input activations [M, >= K] or NULL;
 // W and mask may start at ANY column of their matrices (4-byte aligned: the h part of a skip layer's concat row starts at
 // column 127; the mask's 16-byte groups around the window must be readable), dY and dX rows are 16-byte aligned.
+// mask_bits (optional): the bit mask hos_thin_linear_fwd wrote for the layer's input activations (its Y [M, K]); takes
+// precedence over `mask` and removes the re-read of the fp32 activations (a third of this kernel's HBM traffic).
 extern "C" int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
-                                     float* dX, int lddx, int M, int K, hos_stream_t stream) {
+                                     const void* mask_bits, float* dX, int lddx, int M, int K, hos_stream_t stream) {
     if (!dY || !W || !dX || M <= 0 || K <= 0 || Npad <= 0) return HOS_E_ARG;
     if (K > 256 || Npad > 256) return HOS_E_SHAPE;
     if ((lddy & 3) || (Npad & 3) || (mask && (ldmask & 3)) || ((uintptr_t)dY & 15u) || (((uintptr_t)W | (uintptr_t)mask) & 3u)) return HOS_E_ALIGN;
-    ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask, ldmask};
+    if (mask_bits && ((uintptr_t)mask_bits & 1u)) return HOS_E_ALIGN;
+    ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask_bits ? nullptr : mask, ldmask, nullptr,
+               static_cast<uint16_t*>(const_cast<void*>(mask_bits))};
     hipStream_t s = static_cast<hipStream_t>(stream);
     return Npad <= 128 ? launch_thin<8, true>(a, s) : launch_thin<16, true>(a, s);
 }

@@ -406,25 +406,30 @@ class Network(FlatModule):
             acts = [CAT if i == 4 else torch.empty(Pn, 256, device=dev) for i in range(8)]
             raw = torch.empty(Pn, 4, device=dev)
             ops.mlp_chain256_fwd(E, bufs[0], bufs[1], acts, [127 if i == 4 else 0 for i in range(8)], raw)
-            return raw, ((E, acts) if save else None)
-        acts = []
+            return raw, ((E, acts, [None] * 8) if save else None)
+        acts, bits = [], []
         h = E
+        # training: every layer on the thin kernel also writes its ReLU mask as one bit per element (1 KB per 32 rows), which the
+        # backward reads instead of the fp32 activations (a third of a thin dgrad launch's HBM traffic)
+        want_bits = save and ops.RELU_BITS and ops.thin_dgrad_rows(Pn)
         for i in range(8):
             L = self._cnl[i]
             Wt, bt = self._w(L)
+            rb = ops.thin_relu_bits(Pn, dev) if (want_bits and L.Kpad <= 256) else None
             if i == 4:      # its output feeds the skip concat: write it at column 127 of CAT
-                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, CAT, ops.EPI_RELU, out_col0=127)
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, CAT, ops.EPI_RELU, out_col0=127, relu_bits=rb)
                 acts.append(CAT)
                 h = CAT
             else:
                 out = torch.empty(Pn, 256, device=dev)
-                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, out, ops.EPI_RELU)
+                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, out, ops.EPI_RELU, relu_bits=rb)
                 acts.append(out)
                 h = out
+            bits.append(rb)
         Wt, bt = self._w(self._cnl[8])
         raw = torch.empty(Pn, 4, device=dev)
         ops.linear_fwd(h, 256, Wt, bt, 4, raw, ops.EPI_SIGMOID_RELU4)
-        return raw, ((E, acts) if save else None)
+        return raw, ((E, acts, bits) if save else None)
 
     # ------------------------------------------------------------------ HIP MLP chains (backward)
     def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor, rows_dev=None):
@@ -463,7 +468,7 @@ class Network(FlatModule):
         return g_x
 
     def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):
-        E, acts = saved
+        E, acts, bits = saved
         CAT = acts[4]
         Pn, dev = cnl.shape[0], cnl.device
         dz8 = torch.zeros(Pn, 32, device=dev)
@@ -472,7 +477,7 @@ class Network(FlatModule):
         gW, gb = self._w(self._cnl[8], grad=True)
         ops.linear_wgrad(dz8, acts[7], gW, gb, 4, 256)
         dz = torch.empty(Pn, 256, device=dev)
-        ops.linear_dgrad(dz8, Wt, 32, 256, dz, mask_src=acts[7])
+        ops.linear_dgrad(dz8, Wt, 32, 256, dz, mask_src=acts[7], mask_bits=bits[7])
         dCAT = dE = None
         tmp_b = {}
         with ops.deferred_bwd_reduce():          # the slab reductions of the eight 256-wide weight gradients as one launch at the end
@@ -490,7 +495,7 @@ class Network(FlatModule):
                         # (columns 127..382, through layer 4's ReLU) -- no [P, 384] round trip, no slice + mask pass
                         dCAT = torch.empty(Pn, 64, device=dev)
                         ops.linear_dgrad(dz, Wt, 256, 64, dCAT, thin=True)
-                        ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=CAT, w_col0=127, mask_col0=127)
+                        ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=CAT, w_col0=127, mask_col0=127, mask_bits=bits[4])
                     else:
                         dCAT = torch.empty(Pn, CNL_CAT, device=dev)
                         ops.linear_dgrad(dz, Wt, 256, CNL_CAT, dCAT)
@@ -505,7 +510,7 @@ class Network(FlatModule):
                     inp = acts[i - 1]
                     ops.linear_wgrad(dz, inp, gW, gb, 256, 256)
                     nxt = torch.empty(Pn, 256, device=dev)
-                    ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp)
+                    ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp, mask_bits=bits[i - 1])
                     dz = nxt
         # state embedding: its 64 columns are constant over samples -> d embed = db @ W[:, 63:127] (layers 0 and 5)
         g_embed = self._embeds.view(self.store.grad)[state]

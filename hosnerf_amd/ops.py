@@ -92,9 +92,12 @@ def get_gemm_mode() -> int:
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
                out: Optional[torch.Tensor], epilogue: int = EPI_NONE, A1: Optional[torch.Tensor] = None,
                K1: int = 0, aux: Optional[torch.Tensor] = None, aux_col: int = -1, p0: float = 0.0,
-               ldc: Optional[int] = None, M: Optional[int] = None, out_col0: int = 0, rows_dev: Optional[torch.Tensor] = None):
+               ldc: Optional[int] = None, M: Optional[int] = None, out_col0: int = 0, rows_dev: Optional[torch.Tensor] = None,
+               relu_bits: Optional[torch.Tensor] = None):
     """out[M, out_col0:out_col0+N] = epi([A0[:, :K0] | A1[:, :K1]] @ W[:N, :K0+K1]^T + bias).  W is a [rows, ldw] buffer.
-    For EPI_RESIDUAL `aux` is the residual matrix [M, >=N] (its row stride is passed as aux_col)."""
+    For EPI_RESIDUAL `aux` is the residual matrix [M, >=N] (its row stride is passed as aux_col).
+    `relu_bits` (`thin_relu_bits(M)`, only where `thin_dgrad_rows(M)` holds): receives the ReLU mask of the backward pass as one bit
+    per output element, for `linear_dgrad(mask_bits=...)` of the layer above."""
     M = A0.shape[0] if M is None else M
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
@@ -103,8 +106,10 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
         # many rows through a thin layer: persistent kernel with the weight in registers (hos_thin.hip)
         _timed(f"thin_fwd[M={M},N={N},K={K0}]", 2.0 * M * N * K0, lambda: call(
             "hos_thin_linear_fwd", ptr(A0), A0.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, out.stride(0),
-            M, N, K0, epilogue))
+            M, N, K0, epilogue, ptr(relu_bits, torch.int16)))
         return out
+    if relu_bits is not None:
+        raise _lib.HosLibraryError("relu_bits: this layer does not run on the thin kernel (check ops.thin_dgrad_rows first)")
     _timed(f"gemm_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linear_fwd", ptr(A0), A0.stride(0), K0, ptr(A1), 0 if A1 is None else A1.stride(0), K1,
         ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, (0 if out is None else out.stride(0)) if ldc is None else ldc,
@@ -118,23 +123,37 @@ def thin_dgrad_rows(M: int) -> bool:
     return bool(THIN_GEMM and M >= 16384 and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3)
 
 
+RELU_BITS = os.environ.get("HOS_RELU_BITS", "1") == "1"      # thin layers: ReLU mask of the backward pass as bits (A/B switch)
+
+
+def thin_relu_bits(M: int, device) -> torch.Tensor:
+    """Storage of a thin layer's ReLU bit mask: 16 bits per lane, 512 lanes per 32-row tile (opaque; hos_thin.hip)."""
+    return torch.empty(((M + 31) // 32) * 512, dtype=torch.int16, device=device)
+
+
 def linear_dgrad(dY: torch.Tensor, W: torch.Tensor, Npad: int, K: int, out: torch.Tensor,
                  mask_src: Optional[torch.Tensor] = None, accumulate: bool = False, w_col0: int = 0, mask_col0: int = 0,
-                 thin: bool = False):
+                 thin: bool = False, mask_bits: Optional[torch.Tensor] = None):
     """out[M, :K] = (dY[:, :Npad] @ W[:Npad, w_col0:w_col0+K]) * (mask_src[:, mask_col0:mask_col0+K] > 0).
-    `thin`: take the thin kernel also for K <= 128 output columns (by default those go to the tiled GEMM)."""
+    `thin`: take the thin kernel also for K <= 128 output columns (by default those go to the tiled GEMM).
+    `mask_bits`: the bit mask `linear_fwd(relu_bits=...)` wrote for the K <= 256 columns of this layer's input (thin kernel only);
+    used instead of `mask_src`."""
     M = dY.shape[0]
     wptr = ptr(W) + 4 * w_col0
     mptr = None if mask_src is None else ptr(mask_src) + 4 * mask_col0
+    if mask_bits is not None and K > 256:
+        raise _lib.HosLibraryError("mask_bits cover one thin launch (K <= 256 columns)")
     if (not accumulate and Npad <= 256 and Npad % 4 == 0 and (K > 128 or thin) and thin_dgrad_rows(M)):
         # output columns in chunks of <= 256 (the skip layer's [P,384] input gradient is two launches)
         for k0 in range(0, K, 256):
             kc = min(256, K - k0)
             _timed(f"thin_dgrad[M={M},N={kc},K={Npad}]", 2.0 * M * kc * Npad, lambda: call(
                 "hos_thin_linear_dgrad", ptr(dY), dY.stride(0), wptr + 4 * k0, W.stride(0), Npad,
-                None if mptr is None else mptr + 4 * k0, 0 if mask_src is None else mask_src.stride(0),
+                None if mptr is None else mptr + 4 * k0, 0 if mask_src is None else mask_src.stride(0), ptr(mask_bits, torch.int16),
                 ptr(out) + 4 * k0, out.stride(0), M, kc))
         return out
+    if mask_bits is not None and mask_src is None:
+        raise _lib.HosLibraryError("mask_bits: this layer does not run on the thin kernel (check ops.thin_dgrad_rows first)")
     _timed(f"gemm_dgrad[M={M},N={K},K={Npad}]", 2.0 * M * K * Npad, lambda: call(
         "hos_linear_dgrad", ptr(dY), dY.stride(0), wptr, W.stride(0), Npad, mptr,
         0 if mask_src is None else mask_src.stride(0), ptr(out), out.stride(0), M, K, int(accumulate)))

@@ -135,12 +135,15 @@ int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, floa
  *   hos_thin_linear_dgrad: dX [M,K] = (dY[:, :Npad] . W[:Npad, :K]) * [mask > 0]  (bf16 hi/lo x3; mask NULL: none); W and mask
  *                          may start at any column of their matrices (4-byte alignment: the h part of the skip layer's concat row
  *                          starts at column 127, mlp_rgb_sigma.py:53-55), dY and dX rows are 16-byte aligned
+ *   relu_bits / mask_bits (optional, 1024 * ceil(M/32) bytes, opaque): the ReLU mask of the backward pass as ONE BIT per output
+ *                          element, written by the forward launch and read by the dgrad launch of the layer above instead of
+ *                          the fp32 activations (a third of that launch's HBM traffic); takes precedence over `mask`
  * Same results contract as hos_linear_fwd / hos_linear_dgrad in split mode.
  * Reference: CanonicalMLP, canonical_mlps/mlp_rgb_sigma.py:49-58 (256-wide Linear + ReLU chain at M = rays x 128). */
 int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
-                        int M, int N, int K, int epilogue, hos_stream_t stream);
+                        int M, int N, int K, int epilogue, void* relu_bits, hos_stream_t stream);
 int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
-                          float* dX, int lddx, int M, int K, hos_stream_t stream);
+                          const void* mask_bits, float* dX, int lddx, int M, int K, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward

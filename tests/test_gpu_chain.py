@@ -121,9 +121,9 @@ def _cnl_both(net, cnl, state):
     prev_c, prev_m, prev_2 = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256
     try:
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = True, 1, True
-        raw_c, (E, acts_c) = net._canonical_fwd(cnl, state, save=True)
+        raw_c, (E, acts_c, _) = net._canonical_fwd(cnl, state, save=True)
         ops.MLP_CHAIN = False
-        raw_l, (_, acts_l) = net._canonical_fwd(cnl, state, save=True)
+        raw_l, (_, acts_l, _) = net._canonical_fwd(cnl, state, save=True)
     finally:
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = prev_c, prev_m, prev_2
     return raw_c, acts_c, raw_l, acts_l, E

@@ -400,6 +400,32 @@ def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     assert bool(torch.isnan(out[:, K:]).all())
 
 
+@pytest.mark.parametrize("M,N,col0", [(20000, 256, 0), (16421, 256, 127), (16500, 200, 0)])
+def test_thin_relu_bits_roundtrip(dev, M, N, col0):
+    """linear_fwd(relu_bits=...) -> linear_dgrad(mask_bits=...) masks exactly like the fp32 activations do, also when the
+    forward output lands at an unaligned column of a wider row (the skip concat) and with a ragged last tile / column count."""
+    from hosnerf_amd import ops
+    ops.set_gemm_mode(ops.GEMM_PLANES)
+    g = torch.Generator().manual_seed(M + N + col0)
+    X = torch.randn(M, 256, generator=g).to(dev)
+    W = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    b = (torch.randn(256, generator=g) * 0.1).to(dev)
+    ld = 384 if col0 else 256
+    Y = torch.full((M, ld), float("nan"), device=dev)
+    bits = ops.thin_relu_bits(M, dev)
+    ops.linear_fwd(X, 256, W, b, N, Y, ops.EPI_RELU, out_col0=col0, relu_bits=bits)
+    Yw = Y[:, col0:col0 + N]
+    assert bool(torch.isfinite(Yw).all()) and float((Yw == 0).float().mean()) > 0.2
+    dY = (torch.randn(M, 256, generator=g) * 1e-3).to(dev)
+    W2 = (torch.randn(256, 256, generator=g) / 16).to(dev)
+    a = torch.full((M, 256), float("nan"), device=dev); c = torch.full((M, 256), float("nan"), device=dev)
+    ops.linear_dgrad(dY, W2, 256, N, a, mask_src=Y, mask_col0=col0)
+    ops.linear_dgrad(dY, W2, 256, N, c, mask_bits=bits)
+    assert torch.equal(a[:, :N], c[:, :N])
+    want = (dY.double().cpu() @ W2.double().cpu()[:, :N]) * (Yw.cpu() > 0)
+    assert float((c[:, :N].double().cpu() - want).abs().max()) < 2e-5 * float(want.abs().max())
+
+
 def test_thin_linear_dgrad_unaligned_windows(dev):
     """The skip layer of the canonical MLP: the h part of the concat row starts at column 127, so the backward takes a
     [256, 256] window of the weight and of the ReLU mask source at a 4-byte aligned column (no [P, 384] round trip)."""
@@ -435,13 +461,20 @@ def test_thin_and_fused_entry_points_small_m(dev, M):
     dY = torch.randn(M, N, generator=g) * 1e-3
     Xd, Wd, bd, dYd = X.to(dev), W.to(dev), b.to(dev), dY.to(dev)
     Y = torch.full((M, N), float("nan"), device=dev)
-    call("hos_thin_linear_fwd", ptr(Xd), K, ptr(Wd), K, ptr(bd), ptr(Y), N, M, N, K, 1)
+    bits = torch.zeros(((M + 31) // 32) * 512, dtype=torch.int16, device=dev)
+    call("hos_thin_linear_fwd", ptr(Xd), K, ptr(Wd), K, ptr(bd), ptr(Y), N, M, N, K, 1, ptr(bits, torch.int16))
     want = torch.relu(X.double() @ W.double().t() + b.double())
     assert float((Y.double().cpu() - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
     dX = torch.full((M, K), float("nan"), device=dev)
-    call("hos_thin_linear_dgrad", ptr(dYd), N, ptr(Wd), K, N, ptr(Xd), K, ptr(dX), K, M, K)
+    call("hos_thin_linear_dgrad", ptr(dYd), N, ptr(Wd), K, N, ptr(Xd), K, None, ptr(dX), K, M, K)
     want = (dY.double() @ W.double()) * (X > 0)
     assert float((dX.double().cpu() - want).abs().max()) < 2e-5 * float(want.abs().max())
+    # the same product masked by the forward launch's ReLU BITS (mask of Y, N == K here) == masked by the fp32 Y: bit-equal
+    dXf = torch.full((M, K), float("nan"), device=dev); dXb = torch.full((M, K), float("nan"), device=dev)
+    call("hos_thin_linear_dgrad", ptr(dYd), N, ptr(Wd), K, N, ptr(Y), N, None, ptr(dXf), K, M, K)
+    call("hos_thin_linear_dgrad", ptr(dYd), N, ptr(Wd), K, N, None, 0, ptr(bits, torch.int16), ptr(dXb), K, M, K)
+    assert torch.equal(dXf, dXb)
+    assert float((dXf == 0).float().mean()) > 0.2          # the mask did something
     dW = torch.zeros(N, K, device=dev); db = torch.zeros(N, device=dev)
     call("hos_linear_wgrad_tr", ptr(dYd), N, ptr(Xd), K, ptr(dW), K, ptr(db), M, N, K, None, 0)
     want = dY.double().t() @ X.double()
