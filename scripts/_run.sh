@@ -1,1 +1,1 @@
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+bash scripts/pmc_gemmp_r02.sh > gpurun_out/pmc_gemmp.log 2>&1; tail -5 gpurun_out/pmc_gemmp.log
