@@ -75,6 +75,7 @@ PROTOTYPES = {
     "hos_lbs_forward_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P],
     "hos_embed_bwd": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _P, _I, _P, _P],
     "hos_slice_mask": [_P, _I, _I, _P, _I, _I, _L, _I, _P, _I, _P, _P],
+    "hos_slice_pad": [_P, _I, _I, _L, _I, _P, _I, _P, _P],
     "hos_rgbsigma_grad": [_P, _P, _L, _P, _I, _P],
     "hos_raw2outputs_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _P, _P, _P, _P],
     "hos_raw2outputs_bwd": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _F, _I, _I, _P, _I, _P, _I, _P, _P],

@@ -762,15 +762,40 @@ __global__ __launch_bounds__(256) void slice_mask_kernel(const float* __restrict
     }
 }
 
-// d(pre-activation) of the canonical head: cols 0..2 sigmoid' = s(1-s), col 3 relu' ; written zero-padded [P, ldo]
+// d(pre-activation) of the canonical head: cols 0..2 sigmoid' = s(1-s), col 3 relu'; the whole [P, ldo] row is written
+// (16 bytes per thread, columns 4.. zero): the caller passes uninitialised storage, no fill launch
 __global__ __launch_bounds__(256) void rgbsigma_grad_kernel(const float* __restrict__ g, const float* __restrict__ y, long P,
                                                             float* __restrict__ out, int ldo) {
-    const long total = P * 4;
+    const int q = ldo >> 2;
+    const long total = P * q;
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-        const long p = it >> 2;
-        const int c = (int)(it & 3);
-        const float yv = y[it], gv = g[it];
-        out[p * ldo + c] = (c < 3) ? gv * yv * (1.f - yv) : (yv > 0.f ? gv : 0.f);
+        const long p = it / q;
+        const int c4 = (int)(it % q);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c4 == 0) {
+            const float4 yv = *reinterpret_cast<const float4*>(y + p * 4), gv = *reinterpret_cast<const float4*>(g + p * 4);
+            o = make_float4(gv.x * yv.x * (1.f - yv.x), gv.y * yv.y * (1.f - yv.y), gv.z * yv.z * (1.f - yv.z), yv.w > 0.f ? gv.w : 0.f);
+        }
+        *reinterpret_cast<float4*>(out + p * ldo + c4 * 4) = o;
+    }
+}
+
+// out[p, :] = [src[p*lds + col0 .. + width) | 0 ...]  for the whole [P, ldo] row (ldo % 4 == 0, width <= 4): a narrow gradient
+// ([P,3] offsets) widened to the zero-padded operand row of the layer backward, without a fill launch
+__global__ __launch_bounds__(256) void slice_pad_kernel(const float* __restrict__ src, int lds, int col0, long P, int width,
+                                                        float* __restrict__ out, int ldo, const int* __restrict__ p_dev) {
+    if (p_dev) P = min(P, (long)*p_dev);
+    const int q = ldo >> 2;
+    const long total = P * q;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+        const long p = it / q;
+        const int c4 = (int)(it % q);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c4 == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < width) v[c] = src[p * lds + col0 + c];
+        }
+        *reinterpret_cast<float4*>(out + p * ldo + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -841,7 +866,18 @@ extern "C" int hos_slice_mask(const float* src, int lds, int col0, const float* 
 extern "C" int hos_rgbsigma_grad(const float* g_rgbsigma, const float* rgbsigma, int64_t P, float* dz, int ldz,
                                  hos_stream_t stream) {
     if (!g_rgbsigma || !rgbsigma || !dz || P <= 0 || ldz < 4) return HOS_E_ARG;
-    hipLaunchKernelGGL(rgbsigma_grad_kernel, dim3(grid_for(P * 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    if ((ldz & 3) || (((uintptr_t)g_rgbsigma | (uintptr_t)rgbsigma | (uintptr_t)dz) & 15u)) return HOS_E_ALIGN;
+    hipLaunchKernelGGL(rgbsigma_grad_kernel, dim3(grid_for(P * (ldz >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        g_rgbsigma, rgbsigma, (long)P, dz, ldz);
+    return hos_launch_status();
+}
+
+extern "C" int hos_slice_pad(const float* src, int lds, int col0, int64_t P, int width, float* out, int ldo,
+                             const int32_t* rows_dev, hos_stream_t stream) {
+    if (!src || !out || P <= 0 || width <= 0) return HOS_E_ARG;
+    if (width > 4 || ldo < 4) return HOS_E_SHAPE;
+    if ((ldo & 3) || ((uintptr_t)out & 15u)) return HOS_E_ALIGN;
+    hipLaunchKernelGGL(slice_pad_kernel, dim3(grid_for(P * (ldo >> 2))), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds,
+                       col0, (long)P, width, out, ldo, rows_dev);
     return hos_launch_status();
 }

@@ -450,8 +450,8 @@ class Network(FlatModule):
                 ops.linear_dgrad(dz, Wt, dz.shape[1], K, out, mask_src=X if relu_mask else None, w_col0=w_col0)
             return out
 
-        dz6 = torch.zeros(Pn, 32, device=dev)
-        ops.slice_mask(g_xyz, 0, None, 0, 3, dz6, rows_dev=rows_dev)
+        dz6 = torch.empty(Pn, 32, device=dev)
+        ops.slice_pad(g_xyz, 0, 3, dz6, rows_dev=rows_dev)           # [P,3] -> zero-padded [P,32] operand rows, one launch
         with ops.deferred_bwd_reduce():          # the seven slab reductions of this chain as one launch at the end
             dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
             dPE = dE = None
@@ -471,8 +471,8 @@ class Network(FlatModule):
         E, acts, bits = saved
         CAT = acts[4]
         Pn, dev = cnl.shape[0], cnl.device
-        dz8 = torch.zeros(Pn, 32, device=dev)
-        ops.rgbsigma_grad(g_raw.contiguous(), raw, dz8)
+        dz8 = torch.empty(Pn, 32, device=dev)
+        ops.rgbsigma_grad(g_raw.contiguous(), raw, dz8)               # writes the whole zero-padded row
         Wt, _ = self._w(self._cnl[8])
         gW, gb = self._w(self._cnl[8], grad=True)
         ops.linear_wgrad(dz8, acts[7], gW, gb, 4, 256)
@@ -518,7 +518,7 @@ class Network(FlatModule):
             Wt, _ = self._w(self._cnl[i])
             _, gb = self._w(self._cnl[i], grad=True)
             gb += tmp_b[i]
-            g_embed += tmp_b[i][:256] @ Wt[:256, 63:127]
+            g_embed.addmv_(Wt[:256, 63:127].t(), tmp_b[i][:256])
         g_cnl = torch.empty(Pn, 3, device=dev)
         ops.embed_bwd(cnl, None, 10, True, dE, 0, dCAT, 0, g_cnl, False)
         return g_cnl
@@ -556,11 +556,12 @@ class Network(FlatModule):
             leaf = vol.detach().requires_grad_(True)
             self._pending_vol = (vol, leaf)
             vol = leaf
-        pro = {"flow": flow, "state": select_state(time, self.transitions_times), "R_b": Rb_[0], "T_b": Tb_[0],
-               "R_f": Rf_[0], "T_f": Tf_[0], "band_w": self._band_weights(iter_v, dst_Rs.device),
+        Rb, Tb, Rf, Tf = (ops.unbind_frames(t_) for t_ in (Rb_, Tb_, Rf_, Tf_))      # per-frame views, one-launch backward
+        pro = {"flow": flow, "state": select_state(time, self.transitions_times), "R_b": Rb[0], "T_b": Tb[0],
+               "R_f": Rf[0], "T_f": Tf[0], "band_w": self._band_weights(iter_v, dst_Rs.device),
                "cond": cond_of(dst_posevec).contiguous(), "vol": vol}
         if flow:
-            pro.update(R_fp=Rf_[1], T_fp=Tf_[1], cond_prev=cond_of(kwargs["dst_posevec_prev"]).contiguous())
+            pro.update(R_fp=Rf[1], T_fp=Tf[1], cond_prev=cond_of(kwargs["dst_posevec_prev"]).contiguous())
         # channel-last copy of the K bone channels for the K-channel forward tap
         pro["vol_cl"] = F.pad(pro["vol"][:K].permute(1, 2, 3, 0), (0, 32 - K)).contiguous()
         return pro

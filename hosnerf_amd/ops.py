@@ -938,6 +938,41 @@ def train_losses(rgb, target, mse_const=0.0, mse_count=None, pts_prev=None, weig
 
 
 # ------------------------------------------------------------------------------------------ human branch, backward
+def _zeros_like_many(*ts):
+    """Zeroed accumulators shaped like `ts` out of ONE allocation and ONE fill launch (every launch of a replayed step costs
+    4-5 us whatever its size; sizes are rounded to 16 bytes so that every view stays aligned)."""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in ts]
+    buf = torch.zeros(sum(sizes), device=ts[0].device, dtype=ts[0].dtype)
+    out, o = [], 0
+    for t, n in zip(ts, sizes):
+        out.append(buf[o:o + t.numel()].view(t.shape))
+        o += n
+    return out
+
+
+class _UnbindFrames(torch.autograd.Function):
+    """x [F, ...] -> (x[0], ..., x[F-1]).  The backward is one stack instead of a zero fill + slice copy per frame and an add per
+    extra frame (autograd's select backward); a single frame costs no launch at all."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return tuple(x[f] for f in range(x.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None
+        ref = next(g for g in gs if g is not None)
+        if len(gs) == 1:
+            return gs[0].unsqueeze(0)
+        return torch.stack([torch.zeros_like(ref) if g is None else g for g in gs], 0)
+
+
+def unbind_frames(x: torch.Tensor):
+    return _UnbindFrames.apply(x)
+
+
 class _SampleWarp(torch.autograd.Function):
     """(z, pts, x_skel, mask) with gradients to the motion-weight volume and the backward motion basis."""
 
@@ -954,9 +989,7 @@ class _SampleWarp(torch.autograd.Function):
         vol, R, T, pts, bmin, bscale = ctx.saved_tensors
         K = ctx.K
         P = pts.shape[0] * pts.shape[1]
-        g_vol = torch.zeros_like(vol)
-        g_R = torch.zeros_like(R)
-        g_T = torch.zeros_like(T)
+        g_vol, g_R, g_T = _zeros_like_many(vol, R, T)
         gx = torch.zeros(P, 3, device=pts.device) if g_xskel is None else g_xskel.contiguous()
         gm = torch.zeros(P, device=pts.device) if g_mask is None else g_mask.contiguous()
         scratch = torch.empty(P, 2, device=pts.device)
@@ -982,9 +1015,7 @@ class _LbsForward(torch.autograd.Function):
         cnl, vol_cl, R_f, T_f, bmin, bscale, rows_dev = ctx.saved_tensors
         P = cnl.shape[0]
         g_cnl = torch.empty_like(cnl)
-        g_vol = torch.zeros_like(vol_cl)
-        g_R = torch.zeros_like(R_f)
-        g_T = torch.zeros_like(T_f)
+        g_vol, g_R, g_T = _zeros_like_many(vol_cl, R_f, T_f)
         g = g.contiguous()
         call("hos_lbs_forward_bwd", ptr(cnl), ptr(R_f), ptr(T_f), ptr(vol_cl), vol_cl.shape[0], vol_cl.shape[-1], ptr(bmin),
              ptr(bscale), P, ctx.K, ptr(g), ptr(g_cnl), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(rows_dev, torch.int32))
@@ -1003,6 +1034,11 @@ def embed_bwd(x, band_w, num_freqs, identity, dA, colA, dB, colB, g_x, accumulat
 def slice_mask(src, col0, mask_src, mcol0, width, out, rows_dev=None):
     call("hos_slice_mask", ptr(src), src.stride(0), col0, ptr(mask_src), 0 if mask_src is None else mask_src.stride(0), mcol0,
          src.shape[0], width, ptr(out), out.stride(0), ptr(rows_dev, torch.int32))
+
+
+def slice_pad(src, col0, width, out, rows_dev=None):
+    """out[:, :] = [src[:, col0:col0+width] | 0 ...] over whole rows of `out` (uninitialised storage is fine)."""
+    call("hos_slice_pad", ptr(src), src.stride(0), col0, src.shape[0], width, ptr(out), out.stride(0), ptr(rows_dev, torch.int32))
 
 
 def rgbsigma_grad(g, y, dz):

@@ -372,7 +372,12 @@ int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identi
 /* out[p,c] = src[p*lds+col0+c] * (mask_src[p*ldm+mcol0+c] > 0), c < width (mask_src may be NULL). */
 int hos_slice_mask(const float* src, int lds, int col0, const float* mask_src, int ldm, int mcol0, int64_t P,
                    int width, float* out, int ldo, const int32_t* rows_dev, hos_stream_t stream);
-/* dz[p, 0..3] = g * (sigmoid' | relu') evaluated from the activated outputs (N:539-540); dz is [P, ldz] zero-padded by the caller. */
+/* out[p, :] = [src[p*lds+col0 .. +width) | 0 ...] over the WHOLE [P, ldo] row (width <= 4, ldo % 4 == 0): a [P,3] gradient widened
+ * to the zero-padded operand row of hos_linear_bwd_fused without a fill (autograd of the offset head, mlp_offset.py:63-70). */
+int hos_slice_pad(const float* src, int lds, int col0, int64_t P, int width, float* out, int ldo,
+                  const int32_t* rows_dev, hos_stream_t stream);
+/* dz[p, 0..3] = g * (sigmoid' | relu') evaluated from the activated outputs (N:539-540); the whole [P, ldz] row is written
+ * (columns 4.. zero; ldz % 4 == 0, 16-byte aligned pointers). */
 int hos_rgbsigma_grad(const float* g_rgbsigma, const float* rgbsigma, int64_t P, float* dz, int ldz,
                       hos_stream_t stream);
 
