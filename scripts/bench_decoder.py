@@ -19,11 +19,11 @@ def timeit(fn, n=50):
     return a.elapsed_time(b) / n * 1e3
 
 
-chans = [1024, 512, 256, 128, 64, 27]
+chans = [(1024, 512), (512, 512), (512, 256), (256, 256), (256, 27)]      # network_util.py:31-44 at volume_size 32, 26 bones
 D = 1
 print(f"{'layer':28s} {'fwd gemm':>9s} {'torch mm':>9s} {'col2im':>8s} | {'dpre':>7s} {'im2col':>7s} {'dx':>7s} {'mm':>7s} {'dW':>7s} {'mm':>7s}")
 for n in range(5):
-    Cin, Cout = chans[n], chans[n + 1]
+    Cin, Cout = chans[n]
     M = D ** 3
     x = torch.randn(M, Cin, device=dev)
     W = torch.randn(Cin, Cout * 64, device=dev) * 0.02
