@@ -204,6 +204,107 @@ __global__ __launch_bounds__(256) void embed_fourier_kernel(const float* __restr
     }
 }
 
+// Tiled forms of the two embedders (the per-element kernels above stay as the fallback for rows that are not 16-byte
+// aligned): a workgroup takes 64 rows, evaluates their sin / cos features ONCE into LDS (both destinations read them) and
+// writes whole rows with 16-byte stores; index arithmetic is 32-bit and per row, not a 64-bit division per element
+// (the per-element kernels ran at 2.2-2.6 TB/s of writes).
+constexpr int EM_RB = 64;          // rows per workgroup pass
+constexpr int EM_FMAX = 100;       // features per row kept in LDS (3 + 6 x 16 rounded up)
+
+__global__ __launch_bounds__(256) void embed_hannw_tiled_kernel(const float* __restrict__ x, const float* __restrict__ band_w,
+                                                                int F, const float* __restrict__ cond, int C, long P,
+                                                                float* __restrict__ E, int lde, float* __restrict__ PE, int ldpe,
+                                                                const int* __restrict__ p_dev) {
+    __shared__ float sF[EM_RB][EM_FMAX + 1];
+    if (p_dev) P = min(P, (long)*p_dev);
+    const int t = threadIdx.x, nf = 6 * F;
+    for (long row0 = (long)blockIdx.x * EM_RB; row0 < P; row0 += (long)gridDim.x * EM_RB) {
+        const int rows = (int)min((long)EM_RB, P - row0);
+        for (int i = t; i < rows * 3 * F; i += 256) {       // one (frequency, axis) per thread: sin and cos share the range reduction
+            const int r = i / (3 * F), e = i - r * (3 * F);
+            const int j = e / 3, ax = e - j * 3;
+            const float a = x[(row0 + r) * 3 + ax] * (float)(1 << j);
+            float sn, cs;
+            sincosf(a, &sn, &cs);
+            sF[r][j * 6 + ax] = band_w[j] * sn;
+            sF[r][j * 6 + 3 + ax] = band_w[j] * cs;
+        }
+        __syncthreads();
+        const int qe = lde >> 2;
+        for (int i = t; i < rows * qe; i += 256) {
+            const int r = i / qe, c0 = (i - r * qe) * 4;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k, f = c - C;
+                v[k] = c < C ? cond[c] : (f < nf ? sF[r][f] : 0.f);
+            }
+            *reinterpret_cast<float4*>(E + (row0 + r) * lde + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (PE != nullptr) {
+            const int qp = ldpe >> 2;
+            for (int i = t; i < rows * qp; i += 256) {
+                const int r = i / qp, c0 = (i - r * qp) * 4;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (c0 + k < nf) ? sF[r][c0 + k] : 0.f;
+                *reinterpret_cast<float4*>(PE + (row0 + r) * ldpe + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_fourier_tiled_kernel(const float* __restrict__ x, int F,
+                                                                  const float* __restrict__ state, int NE, long P,
+                                                                  float* __restrict__ E, int lde, float* __restrict__ E2, int lde2) {
+    __shared__ float sF[EM_RB][EM_FMAX + 1];
+    const int t = threadIdx.x, nf = 3 + 6 * F, nv = nf + NE;      // nv = columns that carry a value
+    for (long row0 = (long)blockIdx.x * EM_RB; row0 < P; row0 += (long)gridDim.x * EM_RB) {
+        const int rows = (int)min((long)EM_RB, P - row0);
+        for (int i = t; i < rows * 3 * (F + 1); i += 256) {  // e < 3: x itself; then one (frequency, axis) per thread
+            const int r = i / (3 * (F + 1)), e = i - r * (3 * (F + 1));
+            if (e < 3) {
+                sF[r][e] = x[(row0 + r) * 3 + e];
+            } else {
+                const int j = (e - 3) / 3, ax = (e - 3) - j * 3;
+                const float a = x[(row0 + r) * 3 + ax] * (float)(1 << j);
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                sF[r][3 + j * 6 + ax] = sn;
+                sF[r][3 + j * 6 + 3 + ax] = cs;
+            }
+        }
+        __syncthreads();
+        const int qe = lde >> 2;
+        for (int i = t; i < rows * qe; i += 256) {
+            const int r = i / qe, c0 = (i - r * qe) * 4;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k;
+                v[k] = c < nf ? sF[r][c] : (c < nv ? state[c - nf] : 0.f);
+            }
+            *reinterpret_cast<float4*>(E + (row0 + r) * lde + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (E2 != nullptr && c0 < nv) {               // second destination: only the nv value columns (the rest of its row is not ours)
+                float* d = E2 + (row0 + r) * lde2 + c0;
+                if (c0 + 3 < nv) *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (c0 + k < nv) d[k] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+inline bool em_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int em_grid(long P) {
+    const long b = (P + EM_RB - 1) / EM_RB;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
 inline int grid_for(long total) {
     long b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -242,6 +343,11 @@ extern "C" int hos_embed_hannw(const float* x, const float* band_w, int num_freq
                                int64_t P, float* E, int lde, float* PE, int ldpe, const int32_t* rows_dev, hos_stream_t stream) {
     if (!x || !band_w || !E || P <= 0 || (cond_size > 0 && !cond)) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16 || lde < cond_size + 6 * num_freqs || (PE && ldpe < 6 * num_freqs)) return HOS_E_SHAPE;
+    if (!(lde & 3) && em_al16(E) && (!PE || (!(ldpe & 3) && em_al16(PE))) && 6 * num_freqs <= EM_FMAX) {
+        hipLaunchKernelGGL(embed_hannw_tiled_kernel, dim3(em_grid(P)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, band_w, num_freqs, cond, cond_size, (long)P, E, lde, PE, ldpe, rows_dev);
+        return hos_launch_status();
+    }
     hipLaunchKernelGGL(embed_hannw_kernel, dim3(grid_for(P * (lde > cond_size + ldpe ? lde : cond_size + ldpe))), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, band_w, num_freqs, cond, cond_size, (long)P, E, lde, PE, ldpe, rows_dev);
     return hos_launch_status();
@@ -252,6 +358,11 @@ extern "C" int hos_embed_fourier(const float* x, int num_freqs, const float* sta
     if (!x || !E || P <= 0 || (state_size > 0 && !state)) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16 || lde < 3 + 6 * num_freqs + state_size) return HOS_E_SHAPE;
     if (E2 && lde2 < 3 + 6 * num_freqs + state_size) return HOS_E_SHAPE;
+    if (!(lde & 3) && em_al16(E) && (!E2 || (!(lde2 & 3) && em_al16(E2))) && 3 + 6 * num_freqs <= EM_FMAX) {
+        hipLaunchKernelGGL(embed_fourier_tiled_kernel, dim3(em_grid(P)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           x, num_freqs, state, state_size, (long)P, E, lde, E2, lde2);
+        return hos_launch_status();
+    }
     hipLaunchKernelGGL(embed_fourier_kernel, dim3(grid_for(P * lde)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        x, num_freqs, state, state_size, (long)P, E, lde, E2, lde2);
     return hos_launch_status();
@@ -746,6 +857,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     }
 }
 
+// Tiled form: a workgroup stages the feature gradients of 64 rows (dA + dB, 3 + 6F columns each) in LDS with coalesced
+// reads -- consecutive lanes read consecutive columns of a row -- and thread (row, axis) then walks ITS features in LDS.
+// The per-element kernel above has every lane of a wave reading another row (21 rows x 12 B per load instruction).
+__global__ __launch_bounds__(256) void embed_bwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ band_w, int F,
+                                                              int identity, const float* __restrict__ dA, int lda, int colA,
+                                                              const float* __restrict__ dB, int ldb, int colB, long P,
+                                                              float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev) {
+    __shared__ float sG[64][101];
+    if (p_dev) P = min(P, (long)*p_dev);
+    const int t = threadIdx.x, nf = (identity ? 3 : 0) + 6 * F;
+    for (long row0 = (long)blockIdx.x * 64; row0 < P; row0 += (long)gridDim.x * 64) {
+        const int rows = (int)min(64L, P - row0);
+        for (int i = t; i < rows * nf; i += 256) {
+            const int r = i / nf, c = i - r * nf;
+            float v = dA[(row0 + r) * lda + colA + c];
+            if (dB) v += dB[(row0 + r) * ldb + colB + c];
+            sG[r][c] = v;
+        }
+        __syncthreads();
+        if (t < rows * 3) {
+            const int r = t / 3, ax = t - r * 3;
+            const long it = (row0 + r) * 3 + ax;
+            const float xv = x[it];
+            float g = 0.f;
+            int base = 0;
+            if (identity) { g += sG[r][ax]; base = 3; }
+            for (int j = 0; j < F; ++j) {
+                const float fr = (float)(1 << j);
+                const float a = xv * fr;
+                const float wj = band_w ? band_w[j] : 1.f;
+                float sn, cs;
+                sincosf(a, &sn, &cs);
+                g += wj * fr * (cs * sG[r][base + j * 6 + ax] - sn * sG[r][base + j * 6 + 3 + ax]);
+            }
+            g_x[it] = accumulate ? g_x[it] + g : g;
+        }
+        __syncthreads();
+    }
+}
+
 // out[p, c] = src[p*lds + col0 + c] * (mask_src[p*ldm + mcol0 + c] > 0)   (c < width); used to pull the
 // h-part out of the canonical skip-concat gradient, and (mask NULL) for plain strided slices.
 __global__ __launch_bounds__(256) void slice_mask_kernel(const float* __restrict__ src, int lds, int col0,
@@ -850,6 +1001,13 @@ extern "C" int hos_embed_bwd(const float* x, const float* band_w, int num_freqs,
                              const int32_t* rows_dev, hos_stream_t stream) {
     if (!x || !dA || !g_x || P <= 0) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16) return HOS_E_SHAPE;
+    static const bool tiled = !(getenv("HOS_EMBED_BWD_TILED") && atoi(getenv("HOS_EMBED_BWD_TILED")) == 0);
+    if (tiled) {
+        const long b = (P + 63) / 64;
+        hipLaunchKernelGGL(embed_bwd_tiled_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                           band_w, num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev);
+        return hos_launch_status();
+    }
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(P * 3)), dim3(256), 0, static_cast<hipStream_t>(stream), x, band_w,
                        num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev);
     return hos_launch_status();
