@@ -71,7 +71,7 @@ PROTOTYPES = {
     "hos_lbs_forward": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P],
     "hos_embed_hannw": [_P, _P, _I, _P, _I, _L, _P, _I, _P, _I, _P, _P],
     "hos_embed_fourier": [_P, _I, _P, _I, _L, _P, _I, _P, _I, _P],
-    "hos_human_sample_warp_bwd": [_P, _P, _P, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P],
+    "hos_human_sample_warp_bwd": [_P, _P, _P, _P, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "hos_lbs_forward_bwd": [_P, _P, _P, _P, _I, _I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P],
     "hos_embed_bwd": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _P, _I, _P, _P],
     "hos_slice_mask": [_P, _I, _I, _P, _I, _I, _L, _I, _P, _I, _P, _P],

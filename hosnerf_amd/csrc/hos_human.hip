@@ -460,7 +460,8 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     const float* __restrict__ pts, const float* __restrict__ R, const float* __restrict__ T,
     const float* __restrict__ vol, int V, const float* __restrict__ bbox_min, const float* __restrict__ bbox_scale,
     long P, int K, const float* __restrict__ g_xskel, const float* __restrict__ g_mask,
-    float* __restrict__ g_vol, float* __restrict__ g_R, float* __restrict__ g_T, float* __restrict__ aux) {
+    float* __restrict__ g_vol, float* __restrict__ g_R, float* __restrict__ g_T, float* __restrict__ aux,
+    const float* __restrict__ fwd_xskel, const float* __restrict__ fwd_mask) {
     __shared__ float sR[KMAX * 9], sT[KMAX * 3], sB[6], sAcc[KMAX * 12];
     for (int i = threadIdx.x; i < K * 9; i += blockDim.x) sR[i] = R[i];
     for (int i = threadIdx.x; i < K * 3; i += blockDim.x) sT[i] = T[i];
@@ -476,18 +477,27 @@ __global__ __launch_bounds__(256) void human_sample_warp_bwd_kernel(
     const int lane = threadIdx.x & 63;
     const float px = pts[pp * 3], py = pts[pp * 3 + 1], pz = pts[pp * 3 + 2];
     const size_t V3 = (size_t)V * V * V;
-    // pass 1: recompute wsum and x_skel
-    float wsum = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    for (int i = 0; i < K; ++i) {
-        const float* r = sR + i * 9;
-        const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
-        const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
-        const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
-        const float w = trilinear_zero(vol + i * V3, V, (qx - sB[0]) * sB[3] - 1.f, (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f);
-        wsum += w; ax += w * qx; ay += w * qy; az += w * qz;
+    // pass 1: wsum and x_skel -- the forward kernel's own outputs when the caller kept them (mask = wsum, x_skel = the
+    // quotients below, computed by the same instruction sequence: bit-identical), else recomputed (K x 8 more taps per point)
+    float wsum, xs, ys, zs;
+    if (fwd_xskel != nullptr) {
+        wsum = fwd_mask[pp];
+        xs = fwd_xskel[pp * 3]; ys = fwd_xskel[pp * 3 + 1]; zs = fwd_xskel[pp * 3 + 2];
+    } else {
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        wsum = 0.f;
+        for (int i = 0; i < K; ++i) {
+            const float* r = sR + i * 9;
+            const float qx = (r[0] * px + r[1] * py + r[2] * pz) + sT[i * 3 + 0];
+            const float qy = (r[3] * px + r[4] * py + r[5] * pz) + sT[i * 3 + 1];
+            const float qz = (r[6] * px + r[7] * py + r[8] * pz) + sT[i * 3 + 2];
+            const float w = trilinear_zero(vol + i * V3, V, (qx - sB[0]) * sB[3] - 1.f, (qy - sB[1]) * sB[4] - 1.f, (qz - sB[2]) * sB[5] - 1.f);
+            wsum += w; ax += w * qx; ay += w * qy; az += w * qz;
+        }
+        const float d0 = fmaxf(wsum, 1e-4f);
+        xs = ax / d0; ys = ay / d0; zs = az / d0;
     }
     const float den = fmaxf(wsum, 1e-4f);
-    const float xs = ax / den, ys = ay / den, zs = az / den;
     const float clampg = (wsum >= 1e-4f) ? 1.f : 0.f;        // clamp(min) passes the gradient at >=
     const float gx_ = live ? g_xskel[pp * 3] : 0.f, gy_ = live ? g_xskel[pp * 3 + 1] : 0.f, gz_ = live ? g_xskel[pp * 3 + 2] : 0.f;
     const float gm = live ? g_mask[pp] : 0.f;
@@ -955,7 +965,8 @@ __global__ __launch_bounds__(256) void slice_pad_kernel(const float* __restrict_
 extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, const float* vol, int V,
                                          const float* bbox_min, const float* bbox_scale, int64_t P, int K,
                                          const float* g_x_skel, const float* g_mask, float* g_vol, float* g_R,
-                                         float* g_T, float* scratch, hos_stream_t stream) {
+                                         float* g_T, float* scratch, const float* fwd_x_skel, const float* fwd_mask,
+                                         hos_stream_t stream) {
     if (!pts || !R || !T || !vol || !bbox_min || !bbox_scale || !g_x_skel || !g_mask || !g_vol || !g_R || !g_T || P <= 0)
         return HOS_E_ARG;
     if (K <= 0 || K > KMAX || V < 2) return HOS_E_SHAPE;
@@ -966,7 +977,8 @@ extern "C" int hos_human_sample_warp_bwd(const float* pts, const float* R, const
     const size_t vol_bytes = (size_t)V * V * V * sizeof(float);
     const bool split = scratch != nullptr && vol_bytes <= 128 * 1024 && P >= 8192;
     hipLaunchKernelGGL(human_sample_warp_bwd_kernel, grid, dim3(256), 0, s, pts, R, T, vol, V, bbox_min, bbox_scale, (long)P, K,
-                       g_x_skel, g_mask, split ? (float*)nullptr : g_vol, g_R, g_T, split ? scratch : (float*)nullptr);
+                       g_x_skel, g_mask, split ? (float*)nullptr : g_vol, g_R, g_T, split ? scratch : (float*)nullptr,
+                       (fwd_x_skel && fwd_mask) ? fwd_x_skel : (const float*)nullptr, (fwd_x_skel && fwd_mask) ? fwd_mask : (const float*)nullptr);
     if (split) {
         static bool attr_set = false;
         if (!attr_set) {

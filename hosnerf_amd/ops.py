@@ -973,20 +973,24 @@ def unbind_frames(x: torch.Tensor):
     return _UnbindFrames.apply(x)
 
 
+SAMPLE_WARP_BWD_REUSE = os.environ.get("HOS_SAMPLE_WARP_BWD_REUSE", "1") == "1"   # A/B switch: backward reads the forward's x_skel / mask
+
+
 class _SampleWarp(torch.autograd.Function):
     """(z, pts, x_skel, mask) with gradients to the motion-weight volume and the backward motion basis."""
 
     @staticmethod
     def forward(ctx, vol, R, T, rays_o, rays_d, near, far, N, bmin, bscale, t_rand, K):
         z, pts, x_skel, mask = human_sample_warp(rays_o, rays_d, near, far, N, R, T, vol, bmin, bscale, t_rand, K)
-        ctx.save_for_backward(vol, R, T, pts, bmin, bscale)
+        # x_skel / mask are kept for the backward kernel (it would otherwise re-evaluate the 26 x 8 taps per point they came from)
+        ctx.save_for_backward(vol, R, T, pts, bmin, bscale, x_skel, mask)
         ctx.K = K
         ctx.mark_non_differentiable(z, pts)
         return z, pts, x_skel, mask
 
     @staticmethod
     def backward(ctx, gz, gpts, g_xskel, g_mask):
-        vol, R, T, pts, bmin, bscale = ctx.saved_tensors
+        vol, R, T, pts, bmin, bscale, x_skel, mask = ctx.saved_tensors
         K = ctx.K
         P = pts.shape[0] * pts.shape[1]
         g_vol, g_R, g_T = _zeros_like_many(vol, R, T)
@@ -994,7 +998,8 @@ class _SampleWarp(torch.autograd.Function):
         gm = torch.zeros(P, device=pts.device) if g_mask is None else g_mask.contiguous()
         scratch = torch.empty(P, 2, device=pts.device)
         call("hos_human_sample_warp_bwd", ptr(pts), ptr(R), ptr(T), ptr(vol), vol.shape[-1], ptr(bmin), ptr(bscale), P, K,
-             ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(scratch))
+             ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(scratch),
+             ptr(x_skel) if SAMPLE_WARP_BWD_REUSE else None, ptr(mask) if SAMPLE_WARP_BWD_REUSE else None)
         return g_vol, g_R, g_T, None, None, None, None, None, None, None, None, None
 
 

@@ -356,9 +356,11 @@ int hos_embed_fourier(const float* x, int num_freqs, const float* state, int sta
 int hos_human_sample_warp_bwd(const float* pts, const float* R, const float* T, const float* vol, int V,
                               const float* bbox_min, const float* bbox_scale, int64_t P, int K,
                               const float* g_x_skel, const float* g_mask, float* g_vol, float* g_R, float* g_T,
-                              float* scratch, hos_stream_t stream);
+                              float* scratch, const float* fwd_x_skel, const float* fwd_mask, hos_stream_t stream);
 /*   scratch: optional [P,2] floats; with it (and V^3 floats fitting LDS) the volume gradient is accumulated per bone in LDS
- *   by a second kernel instead of scattered global atomics per point (NULL: single kernel). */
+ *   by a second kernel instead of scattered global atomics per point (NULL: single kernel).
+ *   fwd_x_skel [P,3] / fwd_mask [P]: optional, the outputs hos_human_sample_warp wrote for these points; with them the kernel
+ *   does not re-evaluate the K x 8 taps of the forward pass per point (both NULL: recomputed, bit-identical result). */
 /* Backward of hos_lbs_forward: g_cnl [P,3] (written), g_vol_cl / g_R / g_T accumulated with atomics. */
 int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, const float* T_fwd, const float* vol_cl,
                         int V, int CL, const float* bbox_min, const float* bbox_scale, int64_t P, int K,
