@@ -46,6 +46,17 @@ def stage1_lr(step: int, max_steps: int, lr_init: float = 2.0e-3, lr_final: floa
     return delay * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+def allreduce_flat_grad_async(module: FlatModule, group=None, ranges=None) -> list:
+    """`allreduce_flat_grad` with the collectives only ENQUEUED (they run on the communicator's stream, ordered after the work
+    already on the current stream): returns the work handles; `h.wait()` makes the current stream wait for one.  Used to run
+    the volume decoder's backward under the gradient exchange of the other parameters (bench.py, N > 1)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    if ranges is None:
+        return [dist.all_reduce(module.flat_grad, group=group, async_op=True)]
+    return [dist.all_reduce(module.flat_grad[off:off + n], group=group, async_op=True) for off, n in ranges if n > 0]
+
+
 def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
     """Sum the flat gradient over the data-parallel group (RCCL on MI355X, gloo in the CPU tests) and return
     the world size; the 1/world averaging is folded into the Adam kernel's grad_scale.
