@@ -40,6 +40,17 @@ def _worker(rank, world, port, basedir, out_dir):
     expect = sum(r + 1 for r in range(world))
     ok = all(torch.all(p.grad == expect * (1 + (i % 3))) for i, p in enumerate(m.parameters()))
     pad_ok = float(m.mlps[2]._views.W.view(m.flat_grad)[:, 283:].abs().max()) == 0     # padding never becomes non-zero
+    # the enqueue-only form bench.py overlaps with the volume decoder's backward (N > 1): two spans, handles waited afterwards
+    from hosnerf_amd.train import allreduce_flat_grad_async
+    n_flat = m.flat_grad.numel()
+    keep = m.flat_grad.clone()
+    m.flat_grad.fill_(float(rank + 1))
+    hs = allreduce_flat_grad_async(m, None, [(0, 1000), (n_flat - 1000, 1000)])
+    for h in hs:
+        h.wait()
+    ok = ok and len(hs) == 2 and bool(torch.all(m.flat_grad[:1000] == expect)) and bool(torch.all(m.flat_grad[-1000:] == expect)) \
+        and bool(torch.all(m.flat_grad[1000:n_flat - 1000] == rank + 1))
+    m.flat_grad.copy_(keep)
     # inference side: contiguous ray ranges of a frame + one RGB all-gather (a frame of 101 rays: ragged over 2 ranks)
     from hosnerf_amd.train import gather_frame, shard_frame
     n = 101
