@@ -339,69 +339,75 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
     barrier()
     graph, graph2, graph3, static_loss, launch, overlap = None, None, None, None, "eager", False
     full_graph = world == 1        # RCCL stays outside the captured region: two graphs with the eager collectives in between
+    second_half = None
     if not args.no_graph:
-        try:
-            for o in wl.opts():
-                o.set_step_hyper(wl.lr(args.warmup))
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    wl.fwd_bwd(args.warmup)
-                    wl.reduce()
-                    wl.finish(args.warmup, True)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
-            mode = "thread_local" if world > 1 else "global"
-            with torch.cuda.graph(graph, capture_error_mode=mode):
-                static_loss = wl.fwd_bwd(args.warmup)
-                if full_graph:
-                    wl.finish(args.warmup, True)
-            overlap = (not full_graph) and wl.overlap and os.environ.get("HOS_BENCH_OVERLAP", "1") == "1"
-            if not full_graph:
-                wl.freeze_static()
-                if overlap:
-                    for h in wl.reduce_begin():
-                        h.wait()
-                    graph2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
-                        wl.finish_decoder()
-                    graph3 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph3, pool=graph.pool(), capture_error_mode=mode):
-                        wl.finish_optim(args.warmup, True)
-                else:
-                    wl.reduce()
-                    graph2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
-                        wl.finish(args.warmup, True)
-
-            def second_half():
-                if overlap:
-                    pending = wl.reduce_begin()         # all collectives enqueued; the volume gradient has arrived
-                    graph2.replay()                     # decoder backward under the remaining exchange
-                    for h in pending:
-                        h.wait()
-                    graph3.replay()                     # Adam on the reduced gradients
-                else:
-                    wl.reduce()
-                    graph2.replay()
-
-            for _ in range(2):
+        # N > 1: first the overlapped second half (async collectives), then the sequential one, then eager launches
+        want_overlap = (not full_graph) and wl.overlap and os.environ.get("HOS_BENCH_OVERLAP", "1") == "1"
+        for try_overlap in ([True, False] if want_overlap else [False]):
+            try:
                 for o in wl.opts():
                     o.set_step_hyper(wl.lr(args.warmup))
-                graph.replay()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        wl.fwd_bwd(args.warmup)
+                        wl.reduce()
+                        wl.finish(args.warmup, True)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: the RCCL watchdog thread of a multi-rank run may touch the runtime while this thread captures
+                mode = "thread_local" if world > 1 else "global"
+                with torch.cuda.graph(graph, capture_error_mode=mode):
+                    static_loss = wl.fwd_bwd(args.warmup)
+                    if full_graph:
+                        wl.finish(args.warmup, True)
+                overlap = try_overlap
                 if not full_graph:
-                    second_half()
-            torch.cuda.synchronize()
-            launch = ("hipGraph replay" if full_graph else
-                      "hipGraph replay (fwd+bwd) + async all-reduces + hipGraph replay (decoder bwd, under the exchange) + hipGraph replay (Adam)" if overlap else
-                      "hipGraph replay (fwd+bwd) + eager all-reduce + hipGraph replay (decoder bwd + Adam)")
-        except Exception as e:      # fall back to eager launches, and say so in the JSON
-            print(f"[bench] {wl.name}: graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
+                    wl.freeze_static()
+                    if overlap:
+                        for h in wl.reduce_begin():
+                            h.wait()
+                        graph2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
+                            wl.finish_decoder()
+                        graph3 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph3, pool=graph.pool(), capture_error_mode=mode):
+                            wl.finish_optim(args.warmup, True)
+                    else:
+                        wl.reduce()
+                        graph2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
+                            wl.finish(args.warmup, True)
+
+                def second_half():
+                    if overlap:
+                        pending = wl.reduce_begin()         # all collectives enqueued; the volume gradient has arrived
+                        graph2.replay()                     # decoder backward under the remaining exchange
+                        for h in pending:
+                            h.wait()
+                        graph3.replay()                     # Adam on the reduced gradients
+                    else:
+                        wl.reduce()
+                        graph2.replay()
+
+                for _ in range(2):
+                    for o in wl.opts():
+                        o.set_step_hyper(wl.lr(args.warmup))
+                    graph.replay()
+                    if not full_graph:
+                        second_half()
+                torch.cuda.synchronize()
+                launch = ("hipGraph replay" if full_graph else
+                          "hipGraph replay (fwd+bwd) + async all-reduces + hipGraph replay (decoder bwd, under the exchange) + hipGraph replay (Adam)" if overlap else
+                          "hipGraph replay (fwd+bwd) + eager all-reduce + hipGraph replay (decoder bwd + Adam)")
+                break
+            except Exception as e:      # fall back (sequential second half, then eager launches), and say so on stderr / in the JSON
+                print(f"[bench] {wl.name}: graph capture failed ({type(e).__name__}: {e}) with overlap={try_overlap}; "
+                      + ("retrying without the overlapped exchange" if try_overlap else "running eagerly"), file=sys.stderr)
+                graph, launch = None, "eager"
+                torch.cuda.synchronize()
     h2d, h2d_bytes = None, 0
     if getattr(args, "h2d", False):
         # the item as a data loader hands it over: pinned host tensors, copied into the (static) device batch every step
