@@ -106,6 +106,62 @@ def test_stratified_sampling(dev, net):
     assert maxerr(z0, oh.samples_along_ray(b["near"], b["far"], 128)) == 0
 
 
+@pytest.mark.parametrize("P", [1, 63, 1000, 4097])
+def test_tiled_embedders_ragged_rows_and_backward(dev, P):
+    """The tiled embed kernels (64 rows per workgroup pass) at row counts that are not multiples of 64, with a device-side row
+    limit, against the formulas of hannw_fourier.py:20-52 / fourier.py:18-40 in float64, and `hos_embed_bwd` against autograd."""
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(P)
+    x = (torch.rand(P, 3, generator=g) * 2 - 1)
+    w = torch.rand(6, generator=g)
+    cond = torch.randn(75, generator=g)
+    xd, wd = x.to(dev), w.to(dev)
+
+    def hann(xx, ww):                       # [w_j sin(2^j x), w_j cos(2^j x)]_j, 3 each
+        out = []
+        for j in range(6):
+            out += [ww[j] * torch.sin(xx * 2.0 ** j), ww[j] * torch.cos(xx * 2.0 ** j)]
+        return torch.cat(out, -1)
+
+    def fourier(xx):                        # [x, sin(2^j x), cos(2^j x)]_j
+        out = [xx]
+        for j in range(10):
+            out += [torch.sin(xx * 2.0 ** j), torch.cos(xx * 2.0 ** j)]
+        return torch.cat(out, -1)
+
+    live = max(1, (P * 3) // 4)
+    rows_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+    for rd, n in ((None, P), (rows_dev, live)):
+        E = torch.full((P, 128), -7.0, device=dev); PE = torch.full((P, 64), -7.0, device=dev)
+        ops.embed_hannw(xd, wd, cond.to(dev), E, PE, rows_dev=rd)
+        want = hann(x.double(), w.double())
+        assert maxerr(E[:n, 75:111], want[:n]) < 2e-6 and maxerr(PE[:n, :36], want[:n]) < 2e-6
+        assert torch.equal(E[:n, :75].cpu(), cond.expand(n, 75)) and float(E[:n, 111:].abs().max()) == 0 and float(PE[:n, 36:].abs().max()) == 0
+        assert torch.all(E[n:] == -7.0) and torch.all(PE[n:] == -7.0)          # rows past the device-side count are not touched
+    st = torch.arange(64, dtype=torch.float32, device=dev)
+    E = torch.full((P, 128), -7.0, device=dev); CAT = torch.full((P, 384), -7.0, device=dev)
+    ops.embed_fourier(xd, 10, st, E, CAT)
+    want = fourier(x.double())
+    assert maxerr(E[:, :63], want) < 5e-6 and torch.equal(E[:, :127], CAT[:, :127]) and torch.all(CAT[:, 127:] == -7.0)
+    assert torch.equal(E[:, 63:127].cpu(), st.cpu().expand(P, 64)) and float(E[:, 127].abs().max()) == 0
+    # backward: g_x = d/dx sum(dA . hann(x)) (+ dB . hann(x)), features at column offsets 75 / 0 of their rows
+    dA = torch.randn(P, 128, generator=g); dB = torch.randn(P, 64, generator=g)
+    xr = x.double().requires_grad_(True)
+    f = hann(xr, w.double())
+    ((f * dA[:, 75:111].double()).sum() + (f * dB[:, :36].double()).sum()).backward()
+    for rd, n in ((None, P), (rows_dev, live)):
+        g_x = torch.full((P, 3), 0.5, device=dev)
+        ops.embed_bwd(xd, wd, 6, False, dA.to(dev), 75, dB.to(dev), 0, g_x, True, rows_dev=rd)          # accumulate onto 0.5
+        assert maxerr(g_x[:n] - 0.5, xr.grad[:n]) < 2e-5 * max(1.0, float(xr.grad.abs().max()))
+        assert torch.all(g_x[n:] == 0.5)
+    xr2 = x.double().requires_grad_(True)
+    dC = torch.randn(P, 128, generator=g)
+    (fourier(xr2) * dC[:, :63].double()).sum().backward()
+    g_x = torch.full((P, 3), float("nan"), device=dev)
+    ops.embed_bwd(xd, None, 10, True, dC.to(dev), 0, None, 0, g_x, False)
+    assert maxerr(g_x, xr2.grad) < 2e-5 * max(1.0, float(xr2.grad.abs().max()))
+
+
 def test_embedders_and_mlps(dev, net, hp):
     from hosnerf_amd import ops
     cn = T(hp["flbs_pts"], dev)
