@@ -87,6 +87,36 @@ def test_lbs_kernels(dev, net, hp):
     assert maxerr(xf, hp["flbs_x"]) < 5e-5
 
 
+def test_backward_warp_with_and_without_forward_outputs(dev, net, hp):
+    """hos_human_sample_warp_bwd given the forward kernel's x_skel / mask == the same call recomputing them (bit-identical: the
+    aux scratch, g_R / g_T and the volume gradient up to the order of its fp32 atomics)."""
+    from hosnerf_amd import ops
+    from hosnerf_amd._lib import call, ptr
+    b = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in synth.human_batch(8, seed=3).items()}
+    with torch.no_grad():
+        vol = net._motion_weight_volume(b["motion_weights_priors"])
+    pts = T(hp["lbs_pts"], dev)
+    P = pts.shape[0]
+    R, Tt = T(hp["mb_R"], dev), T(hp["mb_T"], dev)
+    _, _, x_skel, mask = ops.human_sample_warp(pts, torch.zeros_like(pts), torch.zeros(P, device=dev), torch.zeros(P, device=dev), 1,
+                                               R, Tt, vol, b["cnl_bbox_min_xyz"], b["cnl_bbox_scale_xyz"])
+    g = torch.Generator().manual_seed(5)
+    gx, gm = torch.randn(P, 3, generator=g).to(dev), torch.randn(P, generator=g).to(dev)
+    res = []
+    for reuse in (True, False):
+        g_vol, g_R, g_T = torch.zeros_like(vol), torch.zeros_like(R), torch.zeros_like(Tt)
+        scratch = torch.full((P, 2), float("nan"), device=dev)
+        call("hos_human_sample_warp_bwd", ptr(pts), ptr(R), ptr(Tt), ptr(vol), vol.shape[-1], ptr(b["cnl_bbox_min_xyz"]),
+             ptr(b["cnl_bbox_scale_xyz"]), P, 26, ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(scratch),
+             ptr(x_skel) if reuse else None, ptr(mask) if reuse else None)
+        res.append((g_vol, g_R, g_T, scratch))
+    # den / clamp term per point (written when the launch takes the two-kernel form): the same bits
+    assert torch.equal(torch.nan_to_num(res[0][3], nan=-1.0), torch.nan_to_num(res[1][3], nan=-1.0))
+    for a, c in zip(res[0][:3], res[1][:3]):
+        assert float((a - c).abs().max()) <= 1e-6 * float(c.abs().max()) + 1e-12
+    assert float(res[0][0].abs().max()) > 0 and float(res[0][1].abs().max()) > 0
+
+
 def test_stratified_sampling(dev, net):
     from hosnerf_amd import ops
     b = synth.human_batch(8, seed=4)

@@ -187,3 +187,26 @@ def test_planes_rowdot_head(dev, M, K, softplus):
         dens = torch.empty(M, device=dev)
         ops.linearp_fwd(X16, K, W16, b, M, 1, False, None, None, epilogue=ops.EPI_DENSITY, aux=dens, p0=-1.0)
         assert float((out - dens).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("P", [1, 1000, 70001])
+def test_zero_padded_operand_rows(dev, P):
+    """hos_slice_pad / hos_rgbsigma_grad write WHOLE [P, 32] rows (values in the leading columns, zeros behind) into uninitialised
+    storage; rows past a device-side count stay untouched."""
+    from hosnerf_amd import ops
+    g = torch.Generator().manual_seed(P)
+    src = torch.randn(P, 3, generator=g).to(dev)
+    out = torch.full((P, 32), float("nan"), device=dev)
+    ops.slice_pad(src, 0, 3, out)
+    assert torch.equal(out[:, :3], src) and float(out[:, 3:].abs().max()) == 0
+    live = max(1, P // 2)
+    out = torch.full((P, 32), 7.0, device=dev)
+    ops.slice_pad(src, 0, 3, out, rows_dev=torch.tensor([live], dtype=torch.int32, device=dev))
+    assert torch.equal(out[:live, :3], src[:live]) and float(out[:live, 3:].abs().max()) == 0 and torch.all(out[live:] == 7.0)
+    y = torch.rand(P, 4, generator=g).to(dev)
+    y[:, 3] = torch.where(torch.rand(P, generator=g).to(dev) < 0.5, torch.zeros(P, device=dev), y[:, 3])
+    gy = torch.randn(P, 4, generator=g).to(dev)
+    dz = torch.full((P, 32), float("nan"), device=dev)
+    ops.rgbsigma_grad(gy, y, dz)
+    want = torch.cat([gy[:, :3] * y[:, :3] * (1 - y[:, :3]), torch.where(y[:, 3:] > 0, gy[:, 3:], torch.zeros_like(gy[:, 3:]))], -1)
+    assert float((dz[:, :4] - want).abs().max()) < 1e-6 and float(dz[:, 4:].abs().max()) == 0
