@@ -369,6 +369,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                     if overlap:
                         for h in wl.reduce_begin():
                             h.wait()
+                        torch.cuda.synchronize()           # nothing of the exchange is in flight while the next graphs are captured
                         graph2 = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
                             wl.finish_decoder()
@@ -377,6 +378,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                             wl.finish_optim(args.warmup, True)
                     else:
                         wl.reduce()
+                        torch.cuda.synchronize()
                         graph2 = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph2, pool=graph.pool(), capture_error_mode=mode):
                             wl.finish(args.warmup, True)
