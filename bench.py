@@ -40,6 +40,7 @@ SPLIT_MFMA_PEAK_TFLOPS = 2500.0 / 3   # 3 bf16/fp16 MFMAs (dense peak ~2.5 PFLOP
 # SURVEY 8(d) algorithmic FLOP per ray (2 FLOP per MAC; forward + weight gradients + the data gradients that are needed)
 FLOP_PER_RAY = {"stage1": 1841e6, "stage2": 558e6 + 77.7e6, "stage3": 2261e6 + 77.7e6}
 GLOBAL_RAYS_S3 = 4096
+GRAD_MAX_NORM = 0.001       # run.grad_max_norm of the reference's three Backpack.gin files -> Trainer(gradient_clip_val=..., "norm")
 
 
 def parse():
@@ -95,12 +96,10 @@ class Workload:
             allreduce_flat_grad(o.module, o.group)
 
     def finish(self, i, dynamic):
-        """Second half: optimiser steps on the (already reduced) gradients."""
-        for o in self.opts():
-            if dynamic:
-                o.step(dynamic=True, reduced=True)
-            else:
-                o.step(self.lr(i), reduced=True)
+        """Second half: ONE gradient norm over the (already reduced) flat gradients of every module of the step -- the Trainer's
+        `gradient_clip_val = run.grad_max_norm = 0.001`, norm clipping, bound by all three Backpack.gin files -- then the Adams."""
+        from hosnerf_amd.train import step_all
+        step_all(self.opts(), None if dynamic else self.lr(i), dynamic=dynamic, reduced=True)
 
     # N > 1, captured: the second half in two graphs so that the volume decoder's backward (0.7 ms, needs only the 3.5 MB
     # volume gradient) runs UNDER the exchange of the other gradients (38 MB + 4.3 MB on the communicator's stream)
@@ -137,7 +136,7 @@ class Stage1(Workload):
         self.model = MipNeRF360(basedir(), opaque_background=True)
         self.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)   # identical replicas on every rank
         self.model = self.model.to(dev)
-        self.opt = FusedAdam(self.model, lr=2e-3, max_grad_norm=0.001)
+        self.opt = FusedAdam(self.model, lr=2e-3, max_grad_norm=GRAD_MAX_NORM)
         self.batch = {k: v.to(dev) for k, v in synth.stage1_batch(rays, seed=777 + rank).items()}
         self.batch["times"] = 0.5      # python float: no host sync inside the step (the reference syncs on `time` every call)
         self.max_steps = 500000
@@ -211,7 +210,7 @@ class Stage2(Workload):
         self.net = self.net.to(dev)
         self.host_item, prepared = _human_item(self.rays_local, rank, 2)
         self.batch = batch_to_device(prepared, dev)      # control scalars (time, iter_val) stay on the host
-        self.opt = FusedAdam(self.net, lr=6.667e-4, lr_ranges=human_lr_ranges(self.net, 6.667e-4, 6.667e-5))
+        self.opt = FusedAdam(self.net, lr=6.667e-4, lr_ranges=human_lr_ranges(self.net, 6.667e-4, 6.667e-5), max_grad_norm=GRAD_MAX_NORM)
 
     def opts(self):
         return [self.opt]
@@ -263,7 +262,7 @@ class Stage3(Workload):
         from hosnerf_amd import synth
         from hosnerf_amd.hosnerf import HOSNeRF
         from hosnerf_amd.human_nerf import default_cfg
-        from hosnerf_amd.train import FusedAdam, batch_to_device, human_lr_ranges
+        from hosnerf_amd.train import FusedAdam, GradClip, batch_to_device, human_lr_ranges
         self.rays_global, self.rays_local = rays_global, rays_global // world
         cfg = default_cfg(basedir())
         cfg.perturb = 1.0
@@ -274,8 +273,9 @@ class Stage3(Workload):
         self.hos = self.hos.to(dev)
         self.host_item, prepared = _human_item(self.rays_local, rank, 3)
         self.batch = batch_to_device(prepared, dev)
-        self.ob = FusedAdam(self.hos.model, lr=6.667e-5)
-        self.oh = FusedAdam(self.hos.human, lr=6.667e-5, lr_ranges=human_lr_ranges(self.hos.human))
+        clip = GradClip(GRAD_MAX_NORM)      # ONE norm over both modules: the reference has a single Adam over both (optimizer.py:19-60)
+        self.ob = FusedAdam(self.hos.model, lr=6.667e-5, clip=clip)
+        self.oh = FusedAdam(self.hos.human, lr=6.667e-5, lr_ranges=human_lr_ranges(self.hos.human), clip=clip)
 
     def opts(self):
         return [self.ob, self.oh]

@@ -22,8 +22,8 @@ except Exception:
 from .hosnerf import HOSNeRF
 from .human_nerf import Network, default_cfg
 from .mipnerf360 import MipNeRF360
-from .train import (FusedAdam, FusedAdamOptimizer, human_lr_decay, human_lr_ranges, stage1_loss, stage1_lr, stage2_losses,
-                    stage3_losses)
+from .train import (FusedAdam, FusedAdamOptimizer, GradClip, backward_human, finish_backward_human, human_lr_decay, human_lr_from_cfg, lr_ranges_by_name, stage1_loss,
+                    stage1_lr, stage2_losses, stage3_losses)
 
 
 class _LitFlat(_Base):
@@ -45,21 +45,49 @@ class _LitFlat(_Base):
         tr = getattr(self, "trainer", None) if _Base is not nn.Module else None
         return int(getattr(tr, "global_step", self._step))
 
+    LR_BEFORE_STEP = False
+
     def optimizer_step(self, epoch=None, batch_idx=None, optimizer=None, *args, optimizer_closure=None, **kwargs):
-        """Lightning hook: run the step, then write the schedule's next learning rates into the param groups -- the
-        reference does both in this hook (M1:541-569, M2:606-634, M:1631-1658)."""
+        """Lightning hook: the step and the schedule, in the reference's order -- stage 1 writes lr(global_step) into the param
+        groups and THEN steps (M1:541-569: the first update runs at the warm-up rate lr_init * lr_delay_mult), stages 2 / 3 step
+        and then write the decayed rates for the next step (M2:606-634, M:1631-1658)."""
         closure = optimizer_closure if optimizer_closure is not None else (args[1] if len(args) > 1 and callable(args[1]) else None)
-        optimizer.step(closure=closure)
-        self.apply_lr(optimizer, self._global_step())
+        step = self._global_step()          # the reference reads trainer.global_step BEFORE optimizer.step: the index of this step
+        human = getattr(self, "human", None)
+        if closure is None and human is not None and human.pending_volume_grad() is not None:
+            # the loop called loss.backward() itself instead of this module's `backward` hook: finish the split backward here
+            finish_backward_human(human, self._human_opt, getattr(self._human_opt, "group", None))
+        if self.LR_BEFORE_STEP:
+            self.apply_lr(optimizer, step)
+            optimizer.step(closure=closure)
+        else:
+            optimizer.step(closure=closure)
+            self.apply_lr(optimizer, step)
+        self._step += 1                     # without a Trainer this module counts the optimiser steps itself
 
     def apply_lr(self, optimizer, step: int):
         raise NotImplementedError
+
+    _human_opt: Optional[FusedAdam] = None
+
+    def backward(self, loss, *args, **kwargs):
+        """Lightning's `backward` hook (a plain loop calls it instead of `loss.backward()`).  Modules that own the human network
+        run the data-parallel form: its volume decoder -- 253 of its 259 MB of parameters, fed by a learned constant, no ray
+        enters it -- is reduced at its 3.5 MB OUTPUT gradient and backpropagated on the sum (`train.backward_human`), the other
+        4.3 MB are all-reduced as one span; the optimiser step that follows skips the whole-buffer exchange."""
+        human = getattr(self, "human", None)
+        if human is not None and human.split_decoder_backward:
+            backward_human(human, loss, self._human_opt, getattr(self._human_opt, "group", None))
+        else:
+            loss.backward()
 
 
 class LitMipNeRF360(_LitFlat):
     """Stage 1 (S1/src/model/mipnerf360/model.py:464-563): `self.model = MipNeRF360(basedir)`; one step =
     forward + Charbonnier/interlevel/distortion losses.  `configure_optimizers` returns the flat fused Adam behind a
     `torch.optim.Optimizer` face (zero_grad-safe, see train.FusedAdamOptimizer); `fused_optimizer()` the bare object."""
+
+    LR_BEFORE_STEP = True
 
     def __init__(self, basedir, lr_init: float = 2.0e-3, lr_final: float = 2.0e-5, lr_delay_steps: int = 512,
                  lr_delay_mult: float = 0.01, max_steps: int = 500000, grad_max_norm: float = 0.001,
@@ -77,7 +105,6 @@ class LitMipNeRF360(_LitFlat):
         step = self._global_step()
         rend, hist = self.model(batch, step / self.max_steps, True, True, self.near, self.far)
         loss, _ = stage1_loss(rend[-1]["rgb"], batch["target"], hist)
-        self._step += 1
         return loss
 
     def learning_rate(self, step: int) -> float:
@@ -104,9 +131,12 @@ class LitHumanObject(_LitFlat):
 
     LR = 6.667e-4           # configs/default.yaml train.lr (cnl_mlp, human_stateembeds); the other modules train at LR / 10
 
-    def __init__(self, basedir, cfg=None):
+    def __init__(self, basedir, cfg=None, grad_max_norm: float = 0.0):
+        """`grad_max_norm`: `run.grad_max_norm` (0.001 in configs/human-object/Backpack.gin), which 2nd_.../run.py:185-186 hands
+        to the Trainer as `gradient_clip_val` with algorithm "norm"; here it is part of the fused optimiser step."""
         super().__init__()
         self.cfg = default_cfg(basedir) if cfg is None else cfg
+        self.grad_max_norm = float(grad_max_norm)
         self.human = Network(self.cfg, stage=2)
         self._step = 0
 
@@ -117,17 +147,16 @@ class LitHumanObject(_LitFlat):
         return self.human(**batch)
 
     def _base_lr(self) -> float:
-        tr = getattr(self.cfg, "train", None)
-        return float(getattr(tr, "lr", self.LR)) if tr is not None else self.LR
+        return human_lr_from_cfg(self.cfg, self.LR)[0]
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
         """M2:571-605.  `batch` is the dataset item (leading DataLoader dimension already stripped) after
         `train.prepare_patch_targets` + `train.batch_to_device`."""
         batch = dict(batch)
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M2:576
+        self.human.split_decoder_backward = self._human_opt is not None and torch.is_grad_enabled()
         out = self.human(static_cycle=True, **batch)
         loss, _ = stage2_losses(out, batch)
-        self._step += 1
         return loss
 
     def apply_lr(self, optimizer, step: int):
@@ -138,8 +167,9 @@ class LitHumanObject(_LitFlat):
         return FusedAdamOptimizer(self.fused_optimizer())
 
     def fused_optimizer(self) -> FusedAdam:
-        lr = self._base_lr()
-        return FusedAdam(self.human, lr=lr, lr_ranges=human_lr_ranges(self.human, lr_cnl=lr, lr_other=lr / 10.0))
+        lr, lr_of = human_lr_from_cfg(self.cfg, self.LR)         # cfg.train.lr / lr_<module> (optimizer.py:19-60), shipped defaults otherwise
+        self._human_opt = FusedAdam(self.human, lr=lr, lr_ranges=lr_ranges_by_name(self.human, lr_of, lr), max_grad_norm=self.grad_max_norm)
+        return self._human_opt
 
 
 class LitHOSNeRF(_LitFlat):
@@ -148,9 +178,12 @@ class LitHOSNeRF(_LitFlat):
 
     LR = 6.667e-5           # configs/default.yaml train.lr_bkgd / lr_cnl_mlp; the other human modules train at LR / 10
 
-    def __init__(self, basedir, cfg=None):
+    def __init__(self, basedir, cfg=None, grad_max_norm: float = 0.0):
+        """`grad_max_norm`: `run.grad_max_norm` (0.001 in configs/HOSNeRF/Backpack.gin) = the Trainer's `gradient_clip_val`
+        (3rd_.../run.py:188-189): ONE norm over the parameters of both modules, which share the reference's single Adam."""
         super().__init__()
         self.cfg = default_cfg(basedir) if cfg is None else cfg
+        self.grad_max_norm = float(grad_max_norm)
         net = HOSNeRF(self.cfg)
         # registered under the reference's attribute names so that `state_dict()` has its keys (`model.*`, `human.*`);
         # the composite renderer that owns the same two modules is kept as a plain attribute
@@ -165,20 +198,31 @@ class LitHOSNeRF(_LitFlat):
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
         batch = dict(batch)
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M:1506
+        self.human.split_decoder_backward = self._human_opt is not None and torch.is_grad_enabled()
         out = self.net.render(batch, randomized=True, is_train=True, static_cycle=True)
         loss, _ = stage3_losses(out, batch)
-        self._step += 1
         return loss
 
+    def _lr_bkgd(self) -> float:
+        tr = getattr(self.cfg, "train", None) or {}
+        return float(tr.get("lr_bkgd", self.LR) if isinstance(tr, dict) else getattr(tr, "lr_bkgd", self.LR))
+
     def apply_lr(self, optimizer, step: int):
-        for g in optimizer.param_groups:
-            g["lr"] = self.LR * human_lr_decay(step, int(getattr(getattr(self.cfg, "train", None), "lrate_decay", 500)))
+        """M:1631-1656: every group's rate = its OWN base (cfg.train.lr_<name>; lr_bkgd for the background model) * decay.  One
+        param group per flat module here: the group's `lr` is the module's base rate, the per-module ratios inside the human
+        network are the `lr_ranges` multipliers its FusedAdam was built with (`fused_optimizers`)."""
+        decay = human_lr_decay(step, int(getattr(getattr(self.cfg, "train", None), "lrate_decay", 500)))
+        for g, base in zip(optimizer.param_groups, (self._lr_bkgd(), human_lr_from_cfg(self.cfg, self.LR)[0])):
+            g["lr"] = base * decay
 
     def configure_optimizers(self):
         return FusedAdamOptimizer(list(self.fused_optimizers()))
 
-    def fused_optimizers(self, lr: float = LR):
-        return (FusedAdam(self.net.model, lr=lr), FusedAdam(self.net.human, lr=lr, lr_ranges=human_lr_ranges(self.net.human)))
+    def fused_optimizers(self):
+        lr_h, lr_of = human_lr_from_cfg(self.cfg, self.LR)
+        clip = GradClip(self.grad_max_norm)                   # shared: one global norm over both flat gradients
+        self._human_opt = FusedAdam(self.net.human, lr=lr_h, lr_ranges=lr_ranges_by_name(self.net.human, lr_of, lr_h), clip=clip)
+        return (FusedAdam(self.net.model, lr=self._lr_bkgd(), clip=clip), self._human_opt)
 
 
 _MODELS = {"state_mipnerf360": LitMipNeRF360, "state_humanobject": LitHumanObject, "hosnerf": LitHOSNeRF}

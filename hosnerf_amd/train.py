@@ -77,23 +77,51 @@ def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
     return world
 
 
+class GradClip:
+    """`Trainer(gradient_clip_val=max_norm, gradient_clip_algorithm="norm")` of the reference's launchers (S1/run.py:155,
+    2nd_.../run.py:185-186, 3rd_.../run.py:188-189; every Backpack.gin binds `run.grad_max_norm = 0.001`): Lightning calls
+    `clip_grad_norm_` on ALL parameters of the step's optimiser, i.e. ONE norm -- in stage 3 over the background model AND the
+    human network, which live in two flat buffers here.  The object owns the device scalar the sum of squares of every
+    participating flat gradient is accumulated into (one `hos_sumsq` launch per buffer); the Adam launches of all
+    participants read it and scale their gradients by min(max_norm / (norm + 1e-6), 1)."""
+
+    def __init__(self, max_norm: float):
+        self.max_norm = float(max_norm)
+        self._buf = None
+
+    def sumsq(self, opts) -> Optional[torch.Tensor]:
+        """Sum of squares of the (already reduced) flat gradients of `opts` in one device scalar; None when clipping is off."""
+        if self.max_norm <= 0:
+            return None
+        dev = opts[0].module.flat_grad.device
+        if self._buf is None or self._buf.device != dev:
+            self._buf = torch.zeros(1, device=dev)
+        self._buf.zero_()
+        for o in opts:
+            ops.sumsq(o.module.flat_grad, self._buf)
+        return self._buf
+
+
 class FusedAdam:
     """torch.optim.Adam semantics over the flat parameter buffer of a FlatModule: one sum-of-squares
     launch (norm clipping), one RCCL all-reduce of the whole gradient (multi-GPU) and one Adam launch."""
 
     def __init__(self, module: FlatModule, lr: float = 2e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_grad_norm: float = 0.0, process_group=None, lr_ranges=None):
+                 max_grad_norm: float = 0.0, process_group=None, lr_ranges=None, clip: Optional[GradClip] = None):
         """`lr_ranges`: optional [(offset, numel, lr_multiplier), ...] over the flat buffer for per-module learning
-        rates (the reference's name-keyed param groups, core/train/optimizers/human_nerf/optimizer.py:19-60)."""
+        rates (the reference's name-keyed param groups, core/train/optimizers/human_nerf/optimizer.py:19-60).
+        `clip`: a GradClip SHARED with the other FusedAdams of the same step (stage 3: one global norm over both modules,
+        applied by `step_all`); `max_grad_norm` alone gives this optimiser its own."""
         self.module = module
         self.lr_ranges = lr_ranges
-        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.clip = clip if clip is not None else GradClip(max_grad_norm)
         self.group = process_group
         p = module.flat_param
         self.exp_avg = torch.zeros_like(p)
         self.exp_avg_sq = torch.zeros_like(p)
-        self._sumsq = torch.zeros(1, device=p.device)
         self.step_count = 0
+        self.grad_is_reduced = False     # set by `backward_human`: the next step must not all-reduce the flat gradient again
         self._hyper = None      # device [lr, 1-b1^t, 1/sqrt(1-b2^t)] for graph-captured steps
 
     def set_step_hyper(self, lr: Optional[float] = None):
@@ -129,32 +157,29 @@ class FusedAdam:
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def step(self, lr: Optional[float] = None, dynamic: bool = False, reduced: bool = False):
+    @property
+    def max_grad_norm(self) -> float:
+        return self.clip.max_norm
+
+    def step(self, lr: Optional[float] = None, dynamic: bool = False, reduced: bool = False, clip_sumsq=False):
         """`reduced=True`: the caller already all-reduced the flat gradient (e.g. overlapped with other work); only the
-        1/world scaling is applied here."""
+        1/world scaling is applied here.  `clip_sumsq`: the joint sum of squares `step_all` formed over every optimiser of
+        the step (a device scalar, or None = no clipping); left at False this optimiser clips by its own norm."""
         self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
+        reduced, self.grad_is_reduced = reduced or self.grad_is_reduced, False
         g = self.module.flat_grad
         if self.exp_avg.device != g.device:       # the module was moved after the optimiser was built (`lit.to(device)`)
-            self.exp_avg, self.exp_avg_sq, self._sumsq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device), self._sumsq.to(g.device)
+            self.exp_avg, self.exp_avg_sq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device)
             self._hyper = None
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
+        sumsq = self.clip.sumsq([self]) if clip_sumsq is False else clip_sumsq      # after the exchange: the norm of the SUMMED gradient
         if dynamic:
-            sumsq = None
-            if self.max_grad_norm > 0:
-                self._sumsq.zero_()
-                ops.sumsq(g, self._sumsq)
-                sumsq = self._sumsq
             p = self.module.flat_param
             for r, (off, n, _) in enumerate(self.lr_ranges or [(0, p.numel(), 1.0)]):
                 ops.adam_step_dyn(p[off:off + n], g[off:off + n], self.exp_avg[off:off + n], self.exp_avg_sq[off:off + n],
                                   self._hyper[r], self.betas[0], self.betas[1], self.eps, 1.0 / world, sumsq, self.max_grad_norm)
             return
         self.step_count += 1
-        sumsq = None
-        if self.max_grad_norm > 0:
-            self._sumsq.zero_()
-            ops.sumsq(g, self._sumsq)
-            sumsq = self._sumsq
         lr = self.lr if lr is None else lr
         p = self.module.flat_param
         for off, n, mult in (self.lr_ranges or [(0, p.numel(), 1.0)]):
@@ -172,6 +197,31 @@ class FusedAdam:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+
+
+def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
+    """The optimiser step of a training step that owns several flat modules (stage 3: background + human; the reference has
+    ONE torch Adam over both, optimizer.py:19-60, and Lightning clips ONE norm over it): (1) every flat gradient that was
+    not exchanged yet is all-reduced, (2) the joint sum of squares of the reduced gradients is formed once (`GradClip`,
+    shared by the optimisers), (3) every Adam launch scales by the same clip coefficient.  `lr`: a float or one per optimiser;
+    `reduced`: a bool or one per optimiser."""
+    opts = list(opts)
+    lrs = list(lr) if isinstance(lr, (list, tuple)) else [lr] * len(opts)
+    red = list(reduced) if isinstance(reduced, (list, tuple)) else [reduced] * len(opts)
+    for o, r in zip(opts, red):
+        o.module.store.ensure_bound()
+        if not (r or o.grad_is_reduced):
+            allreduce_flat_grad(o.module, o.group)
+        o.grad_is_reduced = False
+    clip = opts[0].clip
+    shared = all(o.clip is clip for o in opts)
+    for o, l in zip(opts, lrs):
+        if shared:
+            if o is opts[0]:
+                ss = clip.sumsq(opts)
+            o.step(l, dynamic=dynamic, reduced=True, clip_sumsq=ss)
+        else:
+            o.step(l, dynamic=dynamic, reduced=True)
 
 
 class FusedAdamOptimizer(torch.optim.Optimizer):
@@ -198,8 +248,7 @@ class FusedAdamOptimizer(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for f, g in zip(self.fused, self.param_groups):
-            f.step(float(g["lr"]))
+        step_all(self.fused, [float(g["lr"]) for g in self.param_groups])
         return loss
 
     def state_dict(self):
@@ -272,6 +321,45 @@ def human_lr_ranges(net, lr_cnl: float = 6.667e-5, lr_other: float = 6.667e-6):
     start = net._cnl[0].W.offset
     start -= start % 4
     return [(0, start, lr_other / lr_cnl), (start, net.flat_param.numel() - start, 1.0)]
+
+
+def lr_ranges_by_name(module: FlatModule, lr_of, base_lr: float):
+    """Per-parameter learning rates as contiguous ranges of the flat buffer: `lr_of(name)` is the learning rate of the
+    parameter `name` (the reference builds one Adam param group per parameter, keyed by the first `cfg.train.lr_<key>`
+    whose key occurs in the name, optimizer.py:19-60); returns [(offset, numel, lr / base_lr), ...] with neighbouring
+    regions of equal rate merged (regions start on 64-float boundaries, so every range is float4-aligned)."""
+    names = {id(p): n for n, p in module.named_parameters()}
+    spans = sorted({r.offset: names[id(p)] for p, r, _, _ in module.store._bindings}.items())
+    total = module.flat_param.numel()
+    out = []
+    for i, (off, name) in enumerate(spans):
+        end = spans[i + 1][0] if i + 1 < len(spans) else total
+        mult = float(lr_of(name)) / base_lr
+        if out and abs(out[-1][2] - mult) < 1e-12 * max(1.0, abs(mult)):
+            out[-1] = (out[-1][0], end - out[-1][0], out[-1][2])
+        else:
+            out.append((off, end - off, mult))
+    if out and out[0][0] != 0:
+        out[0] = (0, out[0][0] + out[0][1], out[0][2])
+    return out
+
+
+def human_lr_from_cfg(cfg, default_lr: float):
+    """(base learning rate, name -> learning rate) of the human network from `cfg.train` (configs/default.yaml: `lr` and the
+    `lr_<module>` keys; stage 3 also `lr_bkgd`).  Missing keys fall back to the shipped defaults: the canonical MLP and the
+    state embeddings at the base rate, every other module at a tenth of it."""
+    tr = getattr(cfg, "train", None) or {}
+    get = (lambda k, d: tr.get(k, d)) if isinstance(tr, dict) else (lambda k, d: getattr(tr, k, d))
+    base = float(get("lr_cnl_mlp", get("lr", default_lr)))
+    keys = ("cnl_mlp", "human_stateembeds", "mweight_vol_decoder", "pose_decoder", "non_rigid_mlp", "non_rigid_forward_mlp")
+    rates = {k: float(get("lr_" + k, base if k in ("cnl_mlp", "human_stateembeds") else base / 10.0)) for k in keys}
+
+    def lr_of(name: str) -> float:
+        for k in keys:
+            if k in name:
+                return rates[k]
+        return float(get("lr", base))
+    return base, lr_of
 
 
 def prepare_patch_targets(batch: Dict) -> Dict:
@@ -359,9 +447,17 @@ def backward_human(net, loss: torch.Tensor, opt: "FusedAdam", group=None):
     if not net.split_decoder_backward:
         raise RuntimeError("backward_human: set net.split_decoder_backward = True before the forward pass")
     loss.backward()
+    finish_backward_human(net, opt, group)
+
+
+def finish_backward_human(net, opt: Optional["FusedAdam"] = None, group=None):
+    """The part of `backward_human` behind `loss.backward()`: exchange the volume gradient, run the decoder's backward on the
+    sum, exchange the other spans, and tell the optimiser that this flat gradient is already reduced."""
     net.decoder_backward(group)
     allreduce_flat_grad(net, group, net.reduce_ranges())
     net.split_decoder_backward = False
+    if opt is not None:
+        opt.grad_is_reduced = True
 
 
 def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, t_rand=None):
@@ -373,20 +469,21 @@ def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: O
     out = net(t_rand=t_rand, static_cycle=True, **batch)
     loss, parts = stage2_losses(out, batch)
     backward_human(net, loss, opt, opt.group)
-    opt.step(lr, reduced=True)
+    opt.step(lr, reduced=True)                  # clips by the optimiser's own GradClip (run.grad_max_norm), then Adam
     return loss.detach(), parts
 
 
-def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
+def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None,
+                      jitters=None, t_rand=None):
     """One stage-3 optimisation step (M:1501-1629 + optimizer_step :1631-1656): background forward (3 levels, only
     the NeRF level trains -- the proposal MLPs get no gradient in stage 3) + human branch + merge composite +
-    losses + backward + the two flat Adam updates."""
+    losses + backward + ONE gradient-norm clip over both modules (when the optimisers share a `GradClip`: the Trainer's
+    `gradient_clip_val`, 3rd_.../run.py:188-189) + the two flat Adam updates.  `jitters` / `t_rand`: injected sampling draws."""
     opt_bkgd.zero_grad()
     opt_human.zero_grad()
     hos.human.split_decoder_backward = True
-    out = hos.render(batch, randomized=True, is_train=True, static_cycle=True)
+    out = hos.render(batch, randomized=True, is_train=True, static_cycle=True, jitters=jitters, t_rand=t_rand)
     loss, parts = stage3_losses(out, batch)
     backward_human(hos.human, loss, opt_human, opt_human.group)
-    opt_bkgd.step(lr)
-    opt_human.step(lr, reduced=True)
+    step_all([opt_bkgd, opt_human], lr, reduced=[False, True])       # ONE gradient norm over both modules, then the two Adams
     return loss.detach(), parts

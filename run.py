@@ -126,9 +126,13 @@ def run(args, gin):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    model_kw = {}
+    # `run.grad_max_norm` -> Trainer(gradient_clip_val=..., algorithm "norm") in all three launchers (S1/run.py:155,
+    # 2nd_.../run.py:185-186, 3rd_.../run.py:188-189); every Backpack.gin binds 0.001
+    model_kw = {"grad_max_norm": float(kw.get("grad_max_norm", 0.0))}
+    if str(kw.get("grad_clip_algorithm", "norm")) != "norm":
+        raise SystemExit("run.grad_clip_algorithm: only 'norm' (the reference's default and the one its configs use) is implemented")
     if model_name == "state_mipnerf360":
-        model_kw.update(max_steps=int(kw.get("max_steps", 500000)), grad_max_norm=float(kw.get("grad_max_norm", 0.0)))
+        model_kw.update(max_steps=int(kw.get("max_steps", 500000)))
         for k in ("lr_init", "lr_final", "lr_delay_steps", "lr_delay_mult"):
             if gin.get_param(f"LitMipNeRF360.{k}") is not None:
                 model_kw[k] = gin.get_param(f"LitMipNeRF360.{k}")
@@ -145,6 +149,13 @@ def run(args, gin):
             if path and os.path.exists(str(path)):
                 missing, unexpected = select_option.load_checkpoint(lit, path, strict=False)
                 print(f"[run] {key}: loaded {path} ({len(missing)} missing, {len(unexpected)} unexpected keys)")
+            elif path and args.items:
+                # the reference fails in pl_load when a bound warm-start file is missing; training a real scene's stage 3
+                # from random initialisation is never what was asked for
+                raise SystemExit(f"run.{key} = {path!r} does not exist")
+            elif path:
+                print(f"[run] WARNING: run.{key} = {path!r} does not exist -- stage 3 starts from RANDOM initialisation "
+                      f"(tolerated for synthetic items only)", file=sys.stderr)
     opt = lit.configure_optimizers()
     ckpt = args.ckpt_path or os.path.join(logdir, "last.ckpt")
     step0 = 0
@@ -188,20 +199,31 @@ def run(args, gin):
     log_every = int(kw.get("log_every_n_steps", 100))
     t0 = time.perf_counter()
     lit._step = step0
+    # `last.ckpt` every `run.save_every_n_steps` steps (default 5000; the reference's ModelCheckpoint writes per validation
+    # epoch), written to a temporary name and renamed so that a crash during the write never leaves a truncated file
+    save_every = int(kw.get("save_every_n_steps", 5000)) if bool(kw.get("save_last", True)) else 0
+
+    def save_last(global_step):
+        tmp = ckpt + ".tmp"
+        select_option.save_checkpoint(lit, tmp, global_step=global_step, optimizer=opt)
+        os.replace(tmp, ckpt)
+
     if run_train:
         for step in range(step0, max_steps):
             item = items[step % len(items)] if items else synthetic_item(model_name, rays, args.seed + 1000 * rank, step)
             batch = batch_to_device(item, dev) if model_name != "state_mipnerf360" else {k: v.to(dev) for k, v in item.items()}
             opt.zero_grad()
             loss = lit.training_step(batch, step)
-            loss.backward()
+            lit.backward(loss)           # human stages: volume decoder reduced at its 3.5 MB output gradient (train.backward_human)
             lit.optimizer_step(0, step, opt)
+            if save_every > 0 and (step + 1) % save_every == 0 and step + 1 < max_steps and rank == 0:
+                save_last(step + 1)
             if (step + 1) % log_every == 0 and rank == 0:
                 dt = time.perf_counter() - t0
                 print(f"[run] step {step + 1}/{max_steps} loss {float(loss):.5f} lr {opt.param_groups[0]['lr']:.3e} "
                       f"{(step + 1 - step0) * rays * world / dt:.0f} rays/s")
         if rank == 0 and bool(kw.get("save_last", True)):
-            select_option.save_checkpoint(lit, ckpt, global_step=max_steps, optimizer=opt)
+            save_last(max_steps)
             print(f"[run] wrote {ckpt}")
     if world > 1:
         import torch.distributed as dist

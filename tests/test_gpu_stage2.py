@@ -166,4 +166,6 @@ def test_lit_stage2_module_under_a_trainer_style_loop(dev):
     for mod in ("cnl_mlp", "non_rigid_mlp", "non_rigid_forward_mlp", "mweight_vol_decoder", "pose_decoder", "human_stateembeds"):
         moved = max(float((after[k] - before[k]).abs().max()) for k in before if k.startswith(mod))
         assert moved > 0, f"{mod} did not train"
-    assert abs(opt.param_groups[0]["lr"] - 6.667e-4 * 0.1 ** (lit._global_step() / 5e5)) < 1e-9
+    # M2:606-634: the rate written after step i is base * 0.1 ** (i / 500k), i = trainer.global_step read BEFORE optimizer.step
+    assert lit._global_step() == 300006
+    assert abs(opt.param_groups[0]["lr"] - 6.667e-4 * 0.1 ** ((lit._global_step() - 1) / 5e5)) < 1e-9

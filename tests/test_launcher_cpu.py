@@ -72,3 +72,87 @@ def test_flags_of_the_reference_launcher_exist():
     assert a.ginc == ["a.gin", "b.gin"] and a.ginb == ["run.x=1"] and a.resume_training is True and a.ckpt_path == "p"
     assert a.scene_name == "s" and a.seed == 3 and a.logbase == "l" and a.cfg == "c.yaml"
     assert launcher.parse_args([]).seed == 220901                                                      # S3/run.py:270
+
+
+def _basedir(tmp_path):
+    with open(os.path.join(str(tmp_path), "transitions_times.json"), "w") as f:
+        json.dump({"f0": {"time": 0.4}}, f)
+
+
+class _RecordingOpt:
+    """Stands in for the optimiser: remembers the learning rate each group had at the moment step() ran."""
+
+    def __init__(self, n_groups=1):
+        self.param_groups = [{"lr": -1.0} for _ in range(n_groups)]
+        self.seen = []
+
+    def step(self, closure=None):
+        self.seen.append([g["lr"] for g in self.param_groups])
+
+
+def test_schedule_order_matches_the_reference(tmp_path):
+    """stage 1 writes lr(step) BEFORE optimizer.step (M1:541-569: the first update runs at the warm-up rate
+    lr_init * lr_delay_mult), stages 2/3 step first and then write base * 0.1 ** (step / 500k) with step = the index of the
+    step just taken (M2:606-634, M:1631-1656)."""
+    from hosnerf_amd.select_option import select_model
+    from hosnerf_amd.train import stage1_lr
+    _basedir(tmp_path)
+    lit = select_model("state_mipnerf360", str(tmp_path), max_steps=1000, grad_max_norm=0.001)
+    opt = _RecordingOpt()
+    for i in range(3):
+        lit.optimizer_step(0, i, opt)
+    assert [s[0] for s in opt.seen] == [stage1_lr(i, 1000) for i in range(3)]
+    assert abs(opt.seen[0][0] - 2e-3 * 0.01) < 1e-12 and lit._global_step() == 3
+    lit3 = select_model("hosnerf", str(tmp_path), grad_max_norm=0.001)
+    lit3._step = 1000
+    opt3 = _RecordingOpt(2)
+    lit3.optimizer_step(0, 0, opt3)
+    assert opt3.seen[0] == [-1.0, -1.0]                                      # stepped with the rates it had
+    want = 6.667e-5 * 0.1 ** (1000 / 5e5)
+    assert all(abs(g["lr"] - want) < 1e-15 for g in opt3.param_groups) and lit3._global_step() == 1001
+
+
+def test_per_module_learning_rates_follow_cfg_train(tmp_path):
+    """`cfg.train.lr_<module>` of a --cfg yaml decide the rates (optimizer.py:19-60); the shipped defaults otherwise.
+    The ranges tile the flat buffer exactly and reproduce `human_lr_ranges` for the defaults."""
+    from hosnerf_amd.human_nerf import Cfg, default_cfg
+    from hosnerf_amd.select_option import select_model
+    from hosnerf_amd.train import human_lr_from_cfg, human_lr_ranges, lr_ranges_by_name
+    _basedir(tmp_path)
+    lit = select_model("state_humanobject", str(tmp_path), grad_max_norm=0.001)
+    f = lit.fused_optimizer()
+    assert f.max_grad_norm == 0.001 and abs(f.lr - 6.667e-4) < 1e-12
+    n = lit.human.flat_param.numel()
+    assert f.lr_ranges[0][0] == 0 and sum(r[1] for r in f.lr_ranges) == n
+    assert all(a[0] + a[1] == b[0] for a, b in zip(f.lr_ranges, f.lr_ranges[1:])) and all(r[0] % 4 == 0 for r in f.lr_ranges)
+    ref = human_lr_ranges(lit.human, 6.667e-4, 6.667e-5)
+    # same rate at every flat element (the merge boundaries may differ by padding that belongs to neither module)
+    import numpy as np
+
+    def dense(ranges):
+        v = np.zeros(n)
+        for off, cnt, mult in ranges:
+            v[off:off + cnt] = mult
+        return v
+    d1, d2 = dense(f.lr_ranges), dense(ref)
+    live = np.zeros(n, bool)
+    for p, r, _, _ in lit.human.store._bindings:
+        live[r.offset:r.offset + r.numel] = True
+    assert np.allclose(d1[live], d2[live])
+    cfg = default_cfg(str(tmp_path))
+    cfg.train = Cfg(lr=1e-3, lr_cnl_mlp=2e-4, lr_pose_decoder=5e-5, lr_bkgd=3e-4, lrate_decay=250)
+    base, lr_of = human_lr_from_cfg(cfg, 6.667e-4)
+    assert base == 2e-4 and lr_of("pose_decoder.block_mlps.0.weight") == 5e-5 and lr_of("cnl_mlp.pts_linears.0.weight") == 2e-4
+    assert lr_of("non_rigid_mlp.block_mlps.0.weight") == 2e-5
+    lit3 = select_model("hosnerf", str(tmp_path), cfg=cfg, grad_max_norm=0.001)
+    ob_, oh_ = lit3.fused_optimizers()
+    assert ob_.clip is oh_.clip and ob_.lr == 3e-4 and oh_.lr == 2e-4
+    rng = lr_ranges_by_name(lit3.human, lr_of, base)
+    pd = lit3.human._plain["pose_decoder.block_mlps.0.weight"]
+    off = (pd.data_ptr() - lit3.human.flat_param.data_ptr()) // 4
+    assert any(r[0] <= off < r[0] + r[1] and abs(r[2] - 0.25) < 1e-12 for r in rng)
+    opt3 = _RecordingOpt(2)
+    lit3._step = 500
+    lit3.optimizer_step(0, 0, opt3)
+    dec = 0.1 ** (500 / 250e3)
+    assert abs(opt3.param_groups[0]["lr"] - 3e-4 * dec) < 1e-15 and abs(opt3.param_groups[1]["lr"] - 2e-4 * dec) < 1e-15
