@@ -35,33 +35,43 @@ def load_poses_bounds(path: str, image_hw: Tuple[int, int], factor: float = 1.0)
     return poses, bds
 
 
+def _minimal_rotation(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """The rotation about a x b that carries the unit vector a onto the unit vector b:  R = c I + [v]x + v v^T / (1 + c)  with
+    v = a x b, c = a . b (Rodrigues' formula with sin / cos expressed through v and c, so no angle is ever formed)."""
+    v = np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
+    c = float(a @ b)
+    vx = np.zeros((3, 3))
+    vx[0, 1], vx[0, 2], vx[1, 2] = -v[2], v[1], -v[0]
+    vx -= vx.T
+    return c * np.eye(3) + vx + np.outer(v, v) / (1.0 + c)
+
+
 def similarity_from_cameras(c2w: np.ndarray, strict_scaling: bool = False):
-    """nerf_360_v2.py:295-350: rotate the world so that z+ is up (mean camera up axis), recentre on the median of the points
-    of the camera centre rays closest to the origin, rescale by the median (or max) camera distance.  Returns (T [4,4], scale)."""
-    t = c2w[:, :3, 3]
-    R = c2w[:, :3, :3]
-    ups = np.sum(R * np.array([0, -1.0, 0]), axis=-1)
-    world_up = np.mean(ups, axis=0)
-    world_up /= np.linalg.norm(world_up)
-    up_camspace = np.array([0.0, -1.0, 0.0])
-    c = (up_camspace * world_up).sum()
-    cross = np.cross(world_up, up_camspace)
-    skew = np.array([[0.0, -cross[2], cross[1]], [cross[2], 0.0, -cross[0]], [-cross[1], cross[0], 0.0]])
-    if c > -1:
-        R_align = np.eye(3) + skew + (skew @ skew) * 1 / (1 + c)
+    """Scene normalisation of the stage-1 loader (what nerf_360_v2.py:295-350 computes), from camera-to-world matrices in the
+    OpenCV convention (x right, y DOWN, z forward).  Returns (T [4,4], scale):
+      1. orientation -- a camera's up direction in the world is minus the second column of its rotation; the mean of those,
+         normalised, is carried onto (0, -1, 0) by the minimal rotation `align`;
+      2. origin -- for every camera the foot of the perpendicular from the origin onto its (aligned) optical axis,
+         p = t - (t . f) f; the component-wise median of the feet moves to the origin;
+      3. size -- the median (strict_scaling: the largest) distance of the recentred camera centres becomes 1.
+    T = [align | shift] acts on world points; `scale` multiplies the translated result."""
+    rot, centres = c2w[:, :3, :3], c2w[:, :3, 3]
+    down = np.array([0.0, -1.0, 0.0])
+    mean_up = -rot[:, :, 1].mean(axis=0)
+    mean_up = mean_up / np.sqrt(mean_up @ mean_up)
+    if float(mean_up @ down) > -1.0:
+        align = _minimal_rotation(mean_up, down)
     else:
-        R_align = np.array([[-1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
-    R = R_align @ R
-    fwds = np.sum(R * np.array([0, 0.0, 1.0]), axis=-1)
-    t = (R_align @ t[..., None])[..., 0]
-    nearest = t + (fwds * -t).sum(-1)[:, None] * fwds
-    translate = -np.median(nearest, axis=0)
-    transform = np.eye(4)
-    transform[:3, 3] = translate
-    transform[:3, :3] = R_align
-    scale_fn = np.max if strict_scaling else np.median
-    scale = 1.0 / scale_fn(np.linalg.norm(t + translate, axis=-1))
-    return transform, scale
+        # exactly opposite directions have no minimal rotation; the reference returns this matrix for the case (:322-325)
+        align = np.diag([-1.0, 1.0, 1.0])
+    centres = centres @ align.T
+    axes = np.einsum("ij,njk->nik", align, rot)[:, :, 2]               # optical axes after the alignment
+    feet = centres - np.einsum("ni,ni->n", centres, axes)[:, None] * axes
+    shift = -np.median(feet, axis=0)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = align, shift
+    dist = np.sqrt(((centres + shift) ** 2).sum(axis=-1))
+    return T, 1.0 / float(dist.max() if strict_scaling else np.median(dist))
 
 
 def _r_to_axis_angle(m):
@@ -124,10 +134,11 @@ def load_scene(basedir: str, image_hw: Tuple[int, int], masks: Optional[np.ndarr
     `cameras_scaleworld.pkl` next to `cameras.pkl` for stages 2 and 3."""
     poses, bds = load_poses_bounds(os.path.join(basedir, "poses_bounds.npy"), image_hw, factor)
     cams = load_cameras(os.path.join(basedir, "cameras.pkl"))
-    # rotation-matrix ordering of LLFF -> OpenCV, variable dimension to axis 0 (nerf_360_v2.py:387-389)
-    poses = np.concatenate([poses[:, 1:2, :], -poses[:, 0:1, :], poses[:, 2:, :]], 1)
-    poses = np.concatenate([poses[:, 0:1, :], -poses[:, 1:2, :], -poses[:, 2:3, :], poses[:, 3:, :]], 1)
-    poses = np.moveaxis(poses, -1, 0).astype(np.float32)
+    # LLFF keeps the camera axes as the columns (down, right, back) of each 3x5 block; everything downstream expects OpenCV's
+    # (right, down, forward): exchange the first two columns, negate the third, frames to axis 0 (the net effect of
+    # nerf_360_v2.py:387-389)
+    poses = poses[:, [1, 0, 2, 3, 4], :] * np.array([1.0, 1.0, -1.0, 1.0, 1.0])[None, :, None]
+    poses = np.ascontiguousarray(np.transpose(poses, (2, 0, 1))).astype(np.float32)
     n = poses.shape[0]
     times = np.linspace(0.0, 1.0, n).astype(np.float32)
     extr = np.stack([np.eye(4) for _ in range(n)])

@@ -335,3 +335,78 @@ def add_patch_supervision(b: Dict[str, torch.Tensor], n_patches: int = 2, size: 
     out["newsmpl_to_camera_prev"] = torch.from_numpy(cam)
     out["intrinsics_prev"] = torch.tensor([[500.0, 0.0, 50.0], [0.0, 500.0, 50.0], [0.0, 0.0, 1.0]])
     return out
+
+
+# ------------------------------------------------------------------ a whole scene DIRECTORY
+def write_scene_dir(path: str, n_frames: int = 16, H: int = 96, W: int = 96, seed: int = 777):
+    """Write a geometrically consistent synthetic scene in the on-disk formats the stages read -- `poses_bounds.npy` (LLFF rows),
+    `cameras.pkl`, `mesh_infos.pkl`, `canonical_joints.pkl`, `transitions_times.json` -- and return the per-frame arrays a
+    loader would decode from the image files: {"images" [N,H,W,3] 0..1, "alphas" [N,H,W], "flows" [N,H,W,3], "frames"}.
+    A camera orbits a posed SMPL-like subject that stands somewhere in a 'world' frame; every frame has its own pose, global
+    orientation Rh and translation Th.  Consistency that the pipeline relies on: smpl_to_camera = world_to_camera @ smpl_to_world."""
+    import json
+    import os
+    import pickle
+    rs = np.random.RandomState(seed)
+    J24 = tpose_joints()[:24]
+    Rw = _axis_angle_to_matrix(np.array([0.2, 0.5, -0.1], np.float32)).astype(np.float64)       # SMPL frame -> world
+    smpl_to_world = np.eye(4)
+    smpl_to_world[:3, :3] = Rw
+    smpl_to_world[:3, 3] = np.array([0.4, -0.3, 0.8])
+    f = 1.1 * H
+    K = np.array([[f, 0.0, 0.5 * W], [0.0, f, 0.5 * H], [0.0, 0.0, 1.0]], dtype=np.float32)
+    names = [f"frame_{i:06d}" for i in range(n_frames)]
+    rows, cams, infos = [], {}, {}
+    base_pose = (rs.standard_normal((24, 3)) * 0.15).astype(np.float32)
+    for i, name in enumerate(names):
+        pose = base_pose + (rs.standard_normal((24, 3)) * 0.03).astype(np.float32)
+        Rh = np.array([0.05 * i, 0.3 + 0.04 * i, 0.0], np.float32)
+        Th = np.array([0.02 * i, 0.9, 0.01 * i], np.float32)
+        pose[0] = Rh
+        # posed joints in SMPL space: kinematic chain in the body frame, then the global transform
+        Rs = np.stack([_axis_angle_to_matrix(pose[k]) if k else np.eye(3, dtype=np.float32) for k in range(24)], 0)
+        G = [np.block([[Rs[0], J24[0][:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])]
+        for k in range(1, 24):
+            L = np.block([[Rs[k], (J24[k] - J24[SMPL_PARENT[k]])[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+            G.append(G[SMPL_PARENT[k]] @ L)
+        body = np.stack([g[:3, 3] for g in G], 0)
+        poses72 = pose.reshape(-1).copy()
+        # the stages pose the skeleton in the BODY frame (global orientation removed: `dst_poses[:3]` still holds Rh, but the
+        # joints / box they use are these) -- mesh_infos stores the body-frame joints
+        infos[name] = {"poses": poses72.astype(np.float32), "tpose_joints": J24.astype(np.float32), "joints": body.astype(np.float32),
+                       "Rh": Rh, "Th": Th}
+        # camera: orbit around the subject's position in the world, looking at it (OpenCV axes: x right, y down, z forward)
+        centre_world = smpl_to_world[:3, :3] @ (_axis_angle_to_matrix(Rh).astype(np.float64) @ np.array([0.0, 0.1, 0.0]) + Th) + smpl_to_world[:3, 3]
+        ang = 2.0 * math.pi * i / n_frames * 0.35
+        up_w = smpl_to_world[:3, :3] @ np.array([0.0, 1.0, 0.0])
+        side = smpl_to_world[:3, :3] @ np.array([math.sin(ang), 0.1, math.cos(ang)])
+        cam_c = centre_world + 3.2 * side / np.linalg.norm(side)
+        fwd = centre_world - cam_c
+        fwd /= np.linalg.norm(fwd)
+        right = np.cross(fwd, up_w)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, cam_c
+        w2c = np.linalg.inv(c2w)
+        cams[name] = {"intrinsics": K.copy(), "smpl_to_camera": (w2c @ smpl_to_world).astype(np.float32),
+                      "smpl_to_world": smpl_to_world.astype(np.float32)}
+        # LLFF row: columns (down, right, back) of the camera-to-world rotation | centre | (H, W, focal); then near / far bounds
+        llff = np.concatenate([np.stack([down, right, -fwd, cam_c], 1), np.array([[H], [W], [f]])], 1)
+        rows.append(np.concatenate([llff.reshape(-1), [0.5, 20.0]]))
+    os.makedirs(path, exist_ok=True)
+    np.save(os.path.join(path, "poses_bounds.npy"), np.stack(rows, 0))
+    for fname, obj in (("cameras.pkl", cams), ("mesh_infos.pkl", infos), ("canonical_joints.pkl", {"joints": J24.astype(np.float32)})):
+        with open(os.path.join(path, fname), "wb") as fh:
+            pickle.dump(obj, fh)
+    with open(os.path.join(path, "transitions_times.json"), "w") as fh:
+        json.dump({"f0": {"time": 0.4}}, fh)
+    # per-frame pixels: a smooth colour field, a disc-shaped subject mask around the image centre, a small smooth flow
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    images = np.stack([np.stack([0.5 + 0.5 * np.sin(0.07 * xx + i), 0.5 + 0.5 * np.cos(0.05 * yy - i), 0.5 + 0.4 * np.sin(0.03 * (xx + yy))], -1)
+                       for i in range(n_frames)], 0).astype(np.float32)
+    alphas = np.stack([((xx - 0.5 * W) ** 2 / (0.16 * W) ** 2 + (yy - 0.5 * H) ** 2 / (0.3 * H) ** 2 < 1.0).astype(np.float32)
+                       for _ in range(n_frames)], 0)
+    flows = np.stack([np.stack([0.5 * np.sin(0.1 * yy + i), 0.5 * np.cos(0.1 * xx), (rs.rand(H, W) > 0.2).astype(np.float32)], -1)
+                      for i in range(n_frames)], 0).astype(np.float32)
+    return {"images": images, "alphas": alphas, "flows": flows, "frames": names}

@@ -105,7 +105,7 @@ def crop_rays_64(seed: int = 777):
 
 def run(args, gin):
     from hosnerf_amd import select_option
-    from hosnerf_amd.train import batch_to_device
+    from hosnerf_amd.train import batch_to_device, prepare_patch_targets
     kw = gin.kwargs("run")
     model_name = kw.get("model_name")
     if model_name is None:
@@ -211,6 +211,8 @@ def run(args, gin):
     if run_train:
         for step in range(step0, max_steps):
             item = items[step % len(items)] if items else synthetic_item(model_name, rays, args.seed + 1000 * rank, step)
+            if items and model_name != "state_mipnerf360" and "mse_count" not in item:
+                item = prepare_patch_targets(item)          # items straight from the reference's dataset: derive the patch-MSE constants
             batch = batch_to_device(item, dev) if model_name != "state_mipnerf360" else {k: v.to(dev) for k, v in item.items()}
             opt.zero_grad()
             loss = lit.training_step(batch, step)
