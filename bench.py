@@ -12,7 +12,11 @@ SECONDARY objects in the same line (`stages`):
           unpacked patches + 0.01 flow + 0.01 cycle, Adam; 2048 rays = 2 patches of 32x32), N = 1 only, next to the SAME op
           graph as plain PyTorch-ROCm ops on the same GPU (`torch_rocm`: the denominator of the north-star's ">= 10x").
   stage1  BASELINE configs[1] -- stage-1 background mip-NeRF-360, 1024 rays per GPU (weak scaling), one all-reduce per step.
-One "step" = forward + losses + backward + gradient all-reduce (N > 1) + (clip +) Adam; nothing skipped, inputs resident in
+  infer_1080p  BASELINE configs[4] -- one whole synthetic 1920x1080 free-viewpoint frame (forward only, ray set-up included),
+          rays sharded over the N ranks with one RGB all-gather per ray list; rays/s, algorithmic TFLOP/s and the dominant
+          forward kernel's roofline fraction.
+One "step" = forward + losses + backward + gradient all-reduce (N > 1) + gradient-norm clip (the Trainer's gradient_clip_val =
+run.grad_max_norm = 0.001 of every Backpack.gin; ONE norm over both modules in stage 3) + Adam; nothing skipped, inputs resident in
 HBM.  Steps are captured once in a hipGraph (forward + backward [+ optimiser at N = 1]) and replayed; per-step scalars that
 change (learning rate, Adam bias corrections) live in device memory.
 
@@ -37,8 +41,12 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 SPLIT_MFMA_PEAK_TFLOPS = 2500.0 / 3   # 3 bf16/fp16 MFMAs (dense peak ~2.5 PFLOP/s) per algorithmic product
-# SURVEY 8(d) algorithmic FLOP per ray (2 FLOP per MAC; forward + weight gradients + the data gradients that are needed)
-FLOP_PER_RAY = {"stage1": 1841e6, "stage2": 558e6 + 77.7e6, "stage3": 2261e6 + 77.7e6}
+# SURVEY 8(d) algorithmic FLOP per ray (2 FLOP per MAC; forward + weight gradients + the data gradients that are needed):
+# (fixed part, part proportional to f_cyc = the fraction of the human sample points selected into the cycle set -- MEASURED on
+# the workload after warm-up, `cycle_count / (rays * 128)`, not assumed to be 1)
+FLOP_PER_RAY = {"stage1": (1841e6, 0.0), "stage2": (558e6, 77.7e6), "stage3": (2261e6, 77.7e6)}
+# SURVEY 8(d) config 5, forward only: background-only ray / ray through the subject's box (+ 160.2 M for the human branch core)
+FWD_FLOP_BG, FWD_FLOP_FG = 651.0e6, 811.3e6
 GLOBAL_RAYS_S3 = 4096
 GRAD_MAX_NORM = 0.001       # run.grad_max_norm of the reference's three Backpack.gin files -> Trainer(gradient_clip_val=..., "norm")
 
@@ -54,6 +62,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-infer", action="store_true", help="skip the config-5 leg (one 1080p inference frame, ~10 s)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant (never the headline `value`): every timed step first "
                     "re-uploads the item's tensors from pinned host memory into the step's device batch")
@@ -76,6 +85,13 @@ class Workload:
     name = ""
     scaling = "weak"
     static_vol_grad = None
+    cycle_count = None          # device scalar of the last forward (human stages): rows selected into the cycle set
+
+    def f_cyc(self):
+        """Measured fraction of the human sample points in the cycle set (one 4-byte read, outside the timed region)."""
+        if self.cycle_count is None:
+            return 0.0
+        return float(self.cycle_count.reshape(-1)[0]) / (self.rays_local * 128)
 
     def freeze_static(self):
         """After the first half of a step has been captured: remember the tensors the eager collectives act on."""
@@ -227,6 +243,7 @@ class Stage2(Workload):
         self.opt.zero_grad()
         self.net.split_decoder_backward = True          # the 253 MB decoder gradient is reduced at the decoder's 3.5 MB output
         out = self.net(static_cycle=True, **self.batch)
+        self.cycle_count = out.get("cycle_count")
         loss, _ = stage2_losses(out, self.batch)
         loss.backward()
         return loss.detach()
@@ -293,6 +310,7 @@ class Stage3(Workload):
         self.oh.zero_grad()
         self.hos.human.split_decoder_backward = True
         out = self.hos.render(self.batch, randomized=True, is_train=True, static_cycle=True)
+        self.cycle_count = out.get("cycle_count")
         loss, _ = stage3_losses(out, self.batch)
         loss.backward()
         return loss.detach()
@@ -337,6 +355,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
         wl.host_prepare(i)
         wl.eager_step(i)
     barrier()
+    f_cyc = wl.f_cyc() if args.warmup > 0 else None          # read once, after warm-up, before anything is captured or timed
     graph, graph2, graph3, static_loss, launch, overlap = None, None, None, None, "eager", False
     full_graph = world == 1        # RCCL stays outside the captured region: two graphs with the eager collectives in between
     second_half = None
@@ -438,7 +457,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    info = {"launch": launch, "final_loss": float(loss.detach())}
+    info = {"launch": launch, "final_loss": float(loss.detach()), "f_cyc": wl.f_cyc() if f_cyc is None else f_cyc}
     if h2d is not None:
         info["h2d_bytes_per_step"] = h2d_bytes
     table = None
@@ -481,6 +500,78 @@ def roofline_of(table, gemm):
     return {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,
             "traffic": traffic, "kernel": dom["kernel"], "launches": dom["launches"], "avg_us": dom["avg_us"],
             "flop_per_launch": dom["flop_per_launch"]}
+
+
+# ------------------------------------------------------------------------------------------------ config 5: 1080p inference
+def infer_1080p(dev, rank, world, dist, want_events, height=1080, width=1920, chunk=65536):
+    """BASELINE configs[4] / SURVEY 8(d).5: one whole synthetic 1920x1080 free-viewpoint frame through `eval.render_frame` -- the
+    reference's `free_view` loop (3rd_.../src/model/mipnerf360/model.py:1293-1494): rays through the subject's box take both
+    branches + the 160-sample z-merged composite, the others the background model + 32-sample composite; the frame's ray set-up
+    (two camera ray sets, radii, box test: `eval.frame_rays`) is inside the timed region.  N > 1: every rank renders a
+    contiguous share of both ray lists, one RGB all-gather per list (strong scaling).  One warm-up frame, one timed frame
+    (barrier + synchronize on both sides, max over ranks); then, on rank 0, one more frame under per-launch HIP events for the
+    dominant forward kernel's roofline fraction."""
+    from hosnerf_amd import eval as ev, ops, synth
+    from hosnerf_amd.hosnerf import HOSNeRF
+    from hosnerf_amd.human_nerf import default_cfg
+    cfg = default_cfg(basedir())
+    cfg.chunk = min(max(chunk, int(cfg.chunk)), 32768)      # human inner chunk: 32768 rays x 128 samples = 4.3 GB per activation
+    hos = HOSNeRF(cfg)
+    hos.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+    hos.human.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+    hos = hos.to(dev)
+    hb = synth.human_batch(8, seed=2, time=0.5, is_train=False, iter_val=3e5)
+    K, E, Ec = synth.eval_camera(height, width, hb)
+    bbox = {"min_xyz": hb["dst_bbox_min_xyz"].numpy(), "max_xyz": hb["dst_bbox_max_xyz"].numpy()}
+    per_frame = {k: (hb[k].to(dev) if isinstance(hb[k], torch.Tensor) else hb[k]) for k in ev.FRAME_KEYS}
+    group = dist.group.WORLD if world > 1 else None
+
+    def one_frame():
+        fr = ev.frame_rays(height, width, K, E, bbox, Ec, device=dev)
+        fr.update(per_frame)
+        return fr, ev.render_frame(hos, fr, chunk_bkg=chunk, group=group)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    one_frame()
+    barrier()
+    t0 = time.perf_counter()
+    fr, img = one_frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    n_rays = height * width
+    n_fg = int(fr["ray_mask"].sum())
+    flops = (n_rays - n_fg) * FWD_FLOP_BG + n_fg * FWD_FLOP_FG
+    res = {"workload": f"BASELINE configs[4]: stage-3 free-viewpoint inference, one synthetic {width}x{height} frame "
+                       f"({n_rays} rays, {n_fg / n_rays:.3f} of them through the subject's box), {chunk}-ray chunks, forward only",
+           "value": n_rays / dt, "unit": "rays/s", "frames_per_s": 1.0 / dt, "ms_per_frame": 1e3 * dt, "scaling": "strong",
+           "n_gpus": world, "rays_per_gpu": (n_rays + world - 1) // world, "foreground_fraction": n_fg / n_rays,
+           "algorithmic_tflops": flops / dt / 1e12, "frac_of_split_mfma_peak": flops / dt / 1e12 / (SPLIT_MFMA_PEAK_TFLOPS * world),
+           "finite": bool(torch.isfinite(img).all())}
+    if want_events and rank == 0 and world == 1:
+        prof = ops.KernelEvents()
+        ops.set_kernel_events(prof)
+        one_frame()
+        torch.cuda.synchronize()
+        ops.set_kernel_events(None)
+        table = prof.summary()
+        if table:
+            dom = max(table, key=lambda r: r["total_ms"])
+            res["roofline"] = {"bound": "mfma", "achieved": dom["tflops"], "peak": SPLIT_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": dom["tflops"] / SPLIT_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                               "launches": dom["launches"], "avg_us": dom["avg_us"], "flop_per_launch": dom["flop_per_launch"],
+                               "measured": "HIP events per launch over one extra (untimed) frame"}
+            res["kernels"] = table[:6]
+    del hos
+    torch.cuda.empty_cache()
+    return res
 
 
 # ------------------------------------------------------------------------------------------------ baseline legs
@@ -577,9 +668,11 @@ def main():
         wl = make(name)
         dt, info, table = run_workload(wl, args, dev, rank, world, dist, events)
         rays_total = wl.rays_global * args.steps
+        flop_ray = FLOP_PER_RAY[name][0] + FLOP_PER_RAY[name][1] * info["f_cyc"]
         res = {"value": rays_total / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": wl.scaling,
                "rays_per_gpu": wl.rays_local, "global_rays": wl.rays_global, "workload": wl.describe,
-               "algorithmic_tflops": rays_total * FLOP_PER_RAY[name] / dt / 1e12, **info}
+               "grad_max_norm": GRAD_MAX_NORM, "flop_per_ray": flop_ray,
+               "algorithmic_tflops": rays_total * flop_ray / dt / 1e12, **info}
         del wl
         torch.cuda.empty_cache()
         return res, table
@@ -592,6 +685,13 @@ def main():
             if name == args.primary or (name == "stage2" and world > 1):
                 continue
             stages[name], _ = measure(name, False)
+    infer = None
+    if not args.only_primary and not args.no_infer and args.gemm == "planes":
+        try:        # a secondary object must never cost the primary line
+            infer = infer_1080p(dev, rank, world, dist, events)
+        except Exception as e:
+            infer = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.synchronize()
     if rank == 0:
         out = {
             "metric": f"train rays/sec ({args.primary}: forward + losses + backward + gradient all-reduce + Adam)",
@@ -603,14 +703,22 @@ def main():
             "config": {"workload": prim["workload"], "rays_per_gpu": prim["rays_per_gpu"], "global_rays": prim["global_rays"],
                        "parallelism": f"dp{world} (ray shards; flat-gradient all-reduce per module per step)"},
             "final_loss": prim["final_loss"], "algorithmic_tflops": prim["algorithmic_tflops"],
+            "flop_per_ray": prim["flop_per_ray"], "f_cyc": prim["f_cyc"],
+            "step": f"forward + losses + backward + all-reduce + ONE gradient-norm clip (max_norm {GRAD_MAX_NORM}, the Trainer's "
+                    "gradient_clip_val of the reference's Backpack.gin) + Adam",
         }
         if "h2d_bytes_per_step" in prim:       # --h2d: the PCIe-inclusive variant, labelled so that it is never read as the headline
             out["metric"] += " + per-step host-to-device upload of the item"
             out["h2d_bytes_per_step"] = prim["h2d_bytes_per_step"]
         roof = roofline_of(table, args.gemm)
         if roof is not None:
+            src = ("HIP events around each GEMM launch in an EAGER post-pass of 3 forward+backward passes right after the timed "
+                   "region (same kernels and shapes as the replayed graph, which cannot host per-launch events); the rocprofv3 "
+                   "--kernel-trace --stats summary of the replayed graph is under profiles/")
+            roof["measured"] = "eager post-pass"
             out["roofline"] = roof
             out["kernels"] = table[:16]
+            out["kernels_source"] = src
         if world == 1 and not args.only_primary:
             if not args.no_torch_baseline:
                 for name, rays in (("stage2", 2048), (args.primary, prim["global_rays"])):
@@ -624,6 +732,8 @@ def main():
                         out["speedup_vs_torch_rocm"] = prim["value"] / tb["value"]
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.primary)
+        if infer is not None:
+            stages["infer_1080p"] = infer
         if stages:
             out["stages"] = stages
         print(json.dumps(out))
