@@ -342,8 +342,8 @@ def mipnerf360_forward(state_dict: Dict[str, torch.Tensor], batch: Dict[str, tor
     B = o.shape[0]
     time = float(torch.as_tensor(batch["times"]).reshape(-1)[0])
     state = select_state(time, transitions_times)
-    sdist = torch.cat([torch.zeros(B, 1, device=o.device), torch.ones(B, 1, device=o.device)], dim=-1)
-    weights = torch.ones(B, 1, device=o.device)
+    sdist = torch.cat([torch.zeros(B, 1, device=o.device, dtype=o.dtype), torch.ones(B, 1, device=o.device, dtype=o.dtype)], dim=-1)
+    weights = torch.ones(B, 1, device=o.device, dtype=o.dtype)
     prod = 1
     renderings, history = [], []
     for lvl in range(num_levels):

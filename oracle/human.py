@@ -329,12 +329,12 @@ def stage3_composite(bkg_tdist, bkg_rgb, bkg_density, human, rays_o_bkg, rays_d_
     idx_fg = mask.sum(-1) > 5e-3                                                        # M:1547-1551
     B = mask.shape[0]
     z_b = bkg_tdist[..., :-1]
-    rgb_out = torch.zeros(B, 3, device=z_b.device)
+    rgb_out = torch.zeros(B, 3, device=z_b.device, dtype=bkg_rgb.dtype)
     bkg = torch.cat([bkg_rgb, bkg_density[..., None]], -1)
     hum = torch.cat([human["human_rgb"], human["human_density"][..., None]], -1)
     fg, bg = idx_fg, ~idx_fg
     total_order = torch.zeros(0, z_b.shape[1] + z_h.shape[1], dtype=torch.int64, device=z_b.device)
-    hw = torch.zeros(0, z_h.shape[1], device=z_b.device)
+    hw = torch.zeros(0, z_h.shape[1], device=z_b.device, dtype=bkg_rgb.dtype)
     if int(fg.sum()) > 0:
         zz, total_order = torch.sort(torch.cat([z_b[fg], z_h[fg]], -1), dim=-1, stable=True)   # M:1565
         allv = torch.cat([bkg[fg], hum[fg]], 1)
