@@ -145,7 +145,7 @@ def test_stage2_clipped_steps_vs_oracle(dev):
     assert len(rep) >= 70
     for n, (e_ref, e_hip) in rep.items():
         if n.startswith(("pose_decoder", "mweight_vol_decoder")):
-            assert e_hip < 128.0 * e_ref + 2e-2, (n, e_ref, e_hip)      # see test_gpu_stage2.py: cancellation exposes the bf16-pair products
+            assert e_hip < 4.0 * e_ref + 2e-2, (n, e_ref, e_hip)        # measured 0.14 vs 0.05 (pose decoder heads)
         else:
             assert e_hip < 3.0 * e_ref + 2e-2, (n, e_ref, e_hip)
     k = "cnl_mlp.pts_linears.2.weight"
@@ -189,7 +189,7 @@ def test_stage3_clipped_steps_vs_oracle(dev):
     assert not any(".mlps.0." in k or ".mlps.1." in k for k in rep), "the proposal MLPs get no gradient in stage 3"
     for n, (e_ref, e_hip) in rep.items():
         if n.startswith(("human.pose_decoder", "human.mweight_vol_decoder")):
-            assert e_hip < 128.0 * e_ref + 2e-2, (n, e_ref, e_hip)
+            assert e_hip < 4.0 * e_ref + 2e-2, (n, e_ref, e_hip)
         else:
             assert e_hip < 3.0 * e_ref + 2e-2, (n, e_ref, e_hip)
 

@@ -78,12 +78,15 @@ def test_stage1_fullsize_bounds_are_reference_self_noise():
     noise_moved = max(r["rays_with_moved_samples"] for r in ref)
     noise_over = max(r["rays_over_1e-4"] for r in ref)
     noise_rgb = max(r["rgb_linf_moved_samples"] for r in ref)
+    # measured (profiles/r03_parity_counts.json): oracle fp32-CPU vs fp32-ROCm move a sample on 58 of the 1024 rays, each of
+    # them vs float64 on 179 (worst RGB on such rays 9.4e-5); the HIP path: 69 / 90 rays vs the two fp32 evaluations, 206 vs
+    # float64, 1 ray over 1e-4 (1.2-1.6e-4)
     for k in ("hip vs oracle_fp64", "hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
         h = pairs[k]
         assert h["rgb_linf_same_samples"] < 1e-4, (k, h)                                         # the north-star tolerance, identical samples
-        assert h["rays_with_moved_samples"] <= 2 * noise_moved + 8, (k, h, noise_moved)
-        assert h["rays_over_1e-4"] <= 2 * noise_over + 2, (k, h, noise_over)
-        assert h["rgb_linf_moved_samples"] <= 4 * noise_rgb + 1e-4, (k, h, noise_rgb)
+        assert h["rays_with_moved_samples"] <= 1.5 * noise_moved + 8, (k, h, noise_moved)
+        assert h["rays_over_1e-4"] <= noise_over + 3, (k, h, noise_over)
+        assert h["rgb_linf_moved_samples"] <= 2 * noise_rgb + 1e-4, (k, h, noise_rgb)
     # and the reference's own two fp32 evaluations are NOT within the tolerance of each other on every ray -- the premise
     assert noise_moved > 0
 
@@ -148,9 +151,16 @@ def test_stage3_fullsize_bounds_are_reference_self_noise():
     noise_sw = max(r["rays_with_a_swapped_pair"] for r in ref)
     noise_fg = max(r["fg_flips"] for r in ref)
     noise_rgb = max(r["rgb_linf_swapped"] for r in ref)
+    # measured (profiles/r03_parity_counts.json): the reference's two fp32 evaluations swap a coinciding pair on 10 of the 2048
+    # rays (worst 1.8e-3, 3 rays over 1e-4) and each is 19-21 swapped rays / 1.0e-4 on same-order rays away from float64; the
+    # HIP path: 2 and 8 swapped rays against the two fp32 evaluations, 19 against float64
+    for k in ("hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
+        assert pairs[k]["rgb_linf_same_order"] < 1e-4, (k, pairs[k])             # the north-star tolerance: against the fp32 reference
+    e64 = max(pairs[k]["rgb_linf_same_order"] for k in ("oracle_fp32_cpu vs oracle_fp64", "oracle_fp32_rocm vs oracle_fp64"))
+    assert pairs["hip vs oracle_fp64"]["rgb_linf_same_order"] <= 1.5 * e64 + 1e-5, (pairs["hip vs oracle_fp64"], e64)
     for k in ("hip vs oracle_fp64", "hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
         h = pairs[k]
-        assert h["rgb_linf_same_order"] < 1e-4, (k, h)
-        assert h["rays_with_a_swapped_pair"] <= 2 * noise_sw + 2, (k, h, noise_sw)
-        assert h["fg_flips"] <= 2 * noise_fg + 2, (k, h, noise_fg)
-        assert h["rgb_linf_swapped"] <= 4 * noise_rgb + 2e-3, (k, h, noise_rgb)
+        assert h["rays_with_a_swapped_pair"] <= noise_sw + 2, (k, h, noise_sw)
+        assert h["fg_flips"] <= noise_fg + 2, (k, h, noise_fg)
+        assert h["rgb_linf_swapped"] <= 2 * noise_rgb + 1e-4, (k, h, noise_rgb)
+    assert noise_sw > 0, "premise: two fp32 evaluations of the reference's own graph order some coinciding pair differently"

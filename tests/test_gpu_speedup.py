@@ -100,7 +100,9 @@ def test_stage1_vs_torch_rocm():
     par["rgb_linf_moved_samples"] = float(diff[moved].max()) if bool(moved.any()) else 0.0
     par["rays_over_1e-4"] = int((diff > 1e-4).sum())
     assert par["rgb_linf_same_samples"] < 1e-4, par
-    assert par["rays_with_moved_samples"] <= B // 8 and par["rgb_linf_moved_samples"] < 2e-3 and par["rays_over_1e-4"] <= B // 100, par
+    # bounds just above what is measured; tests/test_gpu_selfnoise.py shows the same class of rays moves between two fp32
+    # evaluations of the REFERENCE's own op graph (58 rays CPU vs ROCm, 179 vs float64; profiles/r03_parity_counts.json)
+    assert par["rays_with_moved_samples"] <= 120 and par["rgb_linf_moved_samples"] < 7e-4 and par["rays_over_1e-4"] <= 5, par
     assert par["loss_rel"] < 1e-4, par
     hg = {k: v.grad for k, v in model.named_parameters()}
     for name in ("mlps.2.pts_linear.3.weight", "mlps.2.pts_linear.7.weight", "mlps.2.density_layer.weight" if "mlps.2.density_layer.weight" in hg else "mlps.2.pts_linear.0.weight",
@@ -256,7 +258,9 @@ def test_stage3_fullsize_parity_and_speedup():
     _record("stage3_fullsize_parity", {"rays": B, "rgb_linf": err, "fg_rays": int(fg_o.sum()), "fg_flips": flips,
                                        "rays_with_a_swapped_coinciding_pair": swapped, "rgb_linf_on_those": err_swapped})
     assert flips <= 2 and err < 1e-4, (flips, err)
-    assert swapped <= 4 and err_swapped < 2e-2, (swapped, err_swapped)
+    # tests/test_gpu_selfnoise.py: the oracle on the host cores and the oracle on this device swap 10 such pairs between
+    # themselves (worst 1.8e-3) -- the bound below is already inside the reference's own noise
+    assert swapped <= 4 and err_swapped < 4e-3, (swapped, err_swapped)
 
     import oracle.steps as osteps
     del bsd, hsd
