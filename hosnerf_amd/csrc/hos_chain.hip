@@ -562,7 +562,10 @@ extern "C" int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, in
         a.acts[l] = acts6[l];
     }
     a.ldact = ldact; a.xyz = xyz; a.P = P; a.p_dev = rows_dev; a.range_flag = hos_range_flag_ptr();
-    constexpr size_t smem = SMEM_BYTES;
+    // HOS_CHAIN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 26000 -> two workgroups own a CU's whole LDS and no
+    // other kernel's workgroup can become co-resident on it
+    static const size_t pad = getenv("HOS_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("HOS_CHAIN_LDS_PAD")) : 0;
+    const size_t smem = SMEM_BYTES + pad;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

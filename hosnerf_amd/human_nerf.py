@@ -300,6 +300,7 @@ class Network(FlatModule):
     # 259 MB to 3.5 MB (volume gradient) + 6 MB (every other parameter) -- what makes strong scaling over xGMI possible.
     split_decoder_backward = False
     _pending_vol = None
+    _fwd_stream = None          # the stream the last training forward was queued on
 
     def decoder_span(self):
         """(offset, numel) of the volume decoder's parameters in the flat buffer (they are allocated first)."""
@@ -317,6 +318,11 @@ class Network(FlatModule):
         pend, self._pending_vol = self._pending_vol, None
         if pend is not None and pend[1].grad is not None:
             pend[0].backward(pend[1].grad)
+            # the decoder's forward may have run on a side stream (HOSNeRF.render): autograd runs this backward there, and its HIP
+            # weight-gradient kernels write the flat gradient directly -- the calling stream must wait for them
+            fs = self._fwd_stream
+            if fs is not None and pend[0].is_cuda and fs != torch.cuda.current_stream(pend[0].device):
+                torch.cuda.current_stream(pend[0].device).wait_stream(fs)
 
     def decoder_backward(self, group=None):
         """Second half of a split backward (`split_decoder_backward = True`): all-reduce (sum) the gradient w.r.t. the volume,
@@ -553,6 +559,7 @@ class Network(FlatModule):
         vol = self._motion_weight_volume(motion_weights_priors)
         if self.split_decoder_backward and torch.is_grad_enabled() and vol.requires_grad:
             # data-parallel training: cut the autograd graph at the volume (see decoder_backward)
+            self._fwd_stream = torch.cuda.current_stream(vol.device) if vol.is_cuda else None
             leaf = vol.detach().requires_grad_(True)
             self._pending_vol = (vol, leaf)
             vol = leaf

@@ -195,12 +195,18 @@ _BWD_WS = {}
 _BWD_DEFER = {"on": False, "offset": 0}
 
 
+def _stream_key(device):
+    """Scratch buffers that a launch and its follow-up reduce share are only ordered within ONE stream: key them by stream."""
+    d = torch.device(device)
+    return (str(d), torch.cuda.current_stream(d).cuda_stream if d.type == "cuda" else 0)
+
+
 def _bwd_workspace(device, M: int = 0, N: int = 0, K: int = 0, fused: bool = False) -> torch.Tensor:
     """Per-workgroup dW / db partials of hos_linear_bwd_fused / hos_linear_wgrad_tr: 256 slabs of up to 256 x 256 + 256 floats
     (67 MB) per call, one buffer per device -- launches on a stream are ordered and the reduce kernel that reads a call's slabs
     is enqueued by the same call.  Inside `deferred_bwd_reduce()` the reductions are postponed to one batched launch, so every
     call gets its OWN region of the (then larger) buffer."""
-    key = str(device)
+    key = _stream_key(device)            # one buffer per (device, stream): the two branches of a stage-3 step run on two streams
     if not _BWD_DEFER["on"]:
         if key not in _BWD_WS:
             _BWD_WS[key] = torch.empty(256 * (256 * 256 + 256), device=device)
@@ -836,7 +842,7 @@ _COMPACT_WS = {}
 
 
 def _compact_workspace(device) -> torch.Tensor:
-    key = str(device)
+    key = _stream_key(device)
     if key not in _COMPACT_WS:
         _COMPACT_WS[key] = torch.zeros(int(_lib.load().hos_compact_workspace_ints()), dtype=torch.int32, device=device)
     return _COMPACT_WS[key]
@@ -880,7 +886,7 @@ _LOSS_WS = {}
 
 def _loss_workspace(device) -> torch.Tensor:
     """Block partials + completion ticket of hos_train_losses_fwd (zero-initialised once: the kernel re-arms the ticket)."""
-    key = str(device)
+    key = _stream_key(device)
     if key not in _LOSS_WS:
         _LOSS_WS[key] = torch.zeros(int(_lib.load().hos_train_losses_workspace_floats()), device=device)
     return _LOSS_WS[key]
@@ -1186,15 +1192,16 @@ def linearp_dgrad(dZ: Planes, WT: Planes, Npad: int, M: int, K: int, mask: Optio
         0 if mask is None else mask.ld, ptr(bits, torch.int32), M, K, _pp(dX), dX.ld))
 
 
-_wgrad_ws = {}          # device index -> fp32 scratch for the split-K slabs of hos_linearp_wgrad
+_wgrad_ws = {}          # (device, stream) -> fp32 scratch for the split-K slabs of hos_linearp_wgrad
 WGRAD_WS_FLOATS = 16 * 1024 * 1024 + 4096      # 64 MB: 16 slabs of a 1024 x 1024 weight gradient
 
 
 def _wgrad_workspace(device: torch.device) -> torch.Tensor:
-    ws = _wgrad_ws.get(device.index)
+    key = _stream_key(device)
+    ws = _wgrad_ws.get(key)
     if ws is None:
         ws = torch.empty(WGRAD_WS_FLOATS, dtype=torch.float32, device=device)
-        _wgrad_ws[device.index] = ws
+        _wgrad_ws[key] = ws
     return ws
 
 

@@ -191,3 +191,43 @@ def test_stage3_train_step(dev, hos):
         hos.human.cfg.perturb = 0.0
         hos.human.flat_param.copy_(before[0])
         hos.model.flat_param.copy_(before[1])
+
+
+def test_two_stream_step_equals_one_stream_step(dev, hos):
+    """`HOSNeRF.two_streams`: the human branch on a side stream, the background branch on the caller's stream, joined before the
+    z-merge and (by a callback queued from the backward pass) after the backward.  Same outputs, same flat gradients as the
+    one-stream order -- compared right after `backward()` returns, on the calling stream, with NO device synchronisation in
+    between (a missing join would show here) -- and the split decoder backward on top of it."""
+    from hosnerf_amd.train import batch_to_device, prepare_patch_targets, stage3_losses
+    b = synth.add_patch_supervision(synth.human_batch(256, seed=9, time=0.5, is_train=True, iter_val=3e5), 1, 16, 9)
+    gb = batch_to_device(prepare_patch_targets(b), dev)
+    g = torch.Generator().manual_seed(2)
+    t_rand = torch.rand(256, 128, generator=g).to(dev)
+    jit = [torch.rand(256, generator=g).to(dev) for _ in range(3)]
+    hos.human.cfg.perturb = 1.0
+    res = {}
+    try:
+        for mode in (False, True, True):
+            hos.two_streams = mode
+            for split in (False, True):
+                hos.zero_grad()
+                hos.human.split_decoder_backward = split
+                out = hos.render(gb, randomized=True, is_train=True, static_cycle=True, jitters=jit, t_rand=t_rand)
+                loss, _ = stage3_losses(out, gb)
+                loss.backward()
+                if split:
+                    hos.human.finish_decoder_backward()
+                hos.human.split_decoder_backward = False
+                # stream-ordered copies on the CALLING stream: they see the side stream's work only if the joins are in place
+                res[(mode, split, len(res))] = (out["rgb"].detach().clone(), hos.model.flat_grad.clone(), hos.human.flat_grad.clone(), loss.detach().clone())
+    finally:
+        hos.two_streams = type(hos).two_streams
+        hos.human.cfg.perturb = 0.0
+        hos.zero_grad()
+    ref = next(v for k, v in res.items() if k[0] is False and k[1] is False)
+    assert float(ref[2].abs().max()) > 0 and float(ref[1].abs().max()) > 0
+    for k, v in res.items():
+        assert torch.equal(v[0], ref[0]), k                                           # forward: same kernels, same inputs
+        for a, r, name in ((v[1], ref[1], "background"), (v[2], ref[2], "human")):
+            # fp32 atomics (volume-gradient scatter, slab halves) make the last bits of some gradients order dependent
+            assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()), (k, name, float((a - r).abs().max()), float(r.abs().max()))
