@@ -4,7 +4,12 @@ ARCH  ?= gfx950
 SRC   := $(wildcard hosnerf_amd/csrc/*.hip)
 OBJ   := $(patsubst hosnerf_amd/csrc/%.hip,build/%.o,$(SRC))
 LIB   := hosnerf_amd/lib/libhosrender.so
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result
+# -packed-fp32-ops (device target feature OFF): no v_pk_{mul,add,fma}_f32 / v_pk_mov_b32 is ever emitted.  Measured on gfx950 /
+# ROCm 7.2 (scripts/stress_victims.py): a wave executing packed-FP32 VALU instructions computes WRONG values in
+# lanes 48-63 when waves of ANOTHER kernel that issue MFMAs are co-resident on the same SIMD (two HIP streams).  Without the
+# packed forms the same kernels are bit-stable under any concurrency; the step time is unchanged (the VALU work here is not
+# what bounds any kernel).  tests/test_isa_hazards_cpu.py checks the built ISA for stragglers.
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result
 
 all: $(LIB)
 

@@ -176,11 +176,7 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
         for (int it = t; it < SB * tail; it += 256) {
             const int s = it / tail, c = it % tail;
             if (p0 + s >= P) break;
-#ifdef HOS_ENC_DEBUG      // diagnostic build: the per-sample moments of phase 1 instead of the state embedding
-            X[(size_t)(p0 + s) * ldx + NIPE + c] = c < 3 ? s_mean[s][c] : (c < 12 ? s_cov[s][c - 3] : (c < 33 ? s_lm[s][c - 12] : (c < 54 ? s_lv[s][c - 33] : 0.f)));
-#else
             X[(size_t)(p0 + s) * ldx + NIPE + c] = (c < NEMB) ? s_embed[c] : 0.f;
-#endif
         }
     } else {
         for (int it = t; it < SB * (tail / 2); it += 256) {

@@ -23,7 +23,12 @@ from .mipnerf360 import MipNeRF360
 # background branch is a few dozen large MFMA-bound GEMM launches, the human branch ~250 launches of which many are latency- or
 # occupancy-bound (26-joint prologue, the volume decoder's 128-workgroup layers, slab reductions, resampling-sized kernels).
 # Issued on ONE stream the small ones leave most of the 256 CUs idle; on two streams they run under the other branch's GEMMs.
-TWO_STREAMS = os.environ.get("HOS_TWO_STREAMS", "0") == "1"      # off until the concurrency issue below is closed
+# What it took: (1) the join at the end of the backward pass is queued from inside it and names the caller's
+# stream explicitly (final callbacks run on the engine's worker thread); (2) human outputs consumed on the main stream are
+# record_stream'ed; (3) scratch buffers are keyed by stream (ops._stream_key); (4) the library is built without packed-FP32
+# VALU instructions: with them the IPE encoder computed wrong values in lanes 48-63 whenever MFMA waves of the other branch were
+# co-resident on its SIMD (Makefile, scripts/stress_victims.py).  HOS_TWO_STREAMS=0 restores the one-stream order.
+TWO_STREAMS = os.environ.get("HOS_TWO_STREAMS", "1") != "0"
 
 
 class _JoinAfterBackward(torch.autograd.Function):

@@ -8,7 +8,11 @@ from hosnerf_amd.hosnerf import HOSNeRF
 from hosnerf_amd.human_nerf import default_cfg
 from hosnerf_amd.train import batch_to_device, prepare_patch_targets, stage3_losses
 
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "liblds_canary.so"))
+_so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "liblds_canary.so")
+if not os.path.exists(_so):
+    import subprocess
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", _so, _so.replace("liblds_canary.so", "lds_canary.hip")], check=True)
+lib = ctypes.CDLL(_so)
 lib.lds_canary_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda")
 ops.set_gemm_mode(ops.GEMM_PLANES)

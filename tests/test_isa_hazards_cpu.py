@@ -1,4 +1,7 @@
-"""Build-time check (no GPU): no instruction of the kernels that read LDS through inline-asm `ds_read` + counted `s_waitcnt`
+"""Build-time checks of the generated ISA (no GPU).
+(1) no packed-FP32 VALU instruction in any kernel (Makefile: -packed-fp32-ops; scripts/check_packed_fp32.py) -- measured on gfx950:
+such instructions go wrong in lanes 48-63 when MFMA waves of another kernel share the SIMD (two streams);
+(2) no instruction of the kernels that read LDS through inline-asm `ds_read` + counted `s_waitcnt`
 touches a fragment register that such a read is still filling (scripts/scan_inflight_reads.py; the bug class behind the
 intermittent garbage of `chain128_kernel` found in round 2)."""
 import os
@@ -28,3 +31,14 @@ def test_planes_gemm_main_loops_never_touch_an_inflight_fragment():
     assert len(rep) == 8, list(rep)
     for k, found in rep.items():
         assert not found, (k, found[:4])
+
+
+def test_no_packed_fp32_instruction_in_any_kernel():
+    """The two-stream step (HOSNeRF.two_streams) lets kernels of the two branches share CUs.  v_pk_{mul,add,fma}_f32 / v_pk_mov_b32
+    in a wave that shares its SIMD with MFMA-issuing waves of another kernel gave wrong results in lanes 48-63 (28 of 30 runs
+    of the IPE encoder next to chain128_kernel; 0 of 30 without the packed forms; scripts/stress_victims.py)."""
+    import check_packed_fp32 as C
+    rep = C.scan()
+    assert len(rep) >= 18
+    assert all(p == 0 for p, _ in rep.values()), {k: v for k, v in rep.items() if v[0]}
+    assert sum(s for _, s in rep.values()) > 10000          # the scalar forms are there: the scan looked at real ISA
