@@ -458,18 +458,28 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     info = {"launch": launch, "final_loss": float(loss.detach()), "f_cyc": wl.f_cyc() if f_cyc is None else f_cyc}
+    if getattr(getattr(wl, "hos", None), "two_streams", False):
+        info["launch"] += "; background branch and human branch on two streams inside the graph"
     if h2d is not None:
         info["h2d_bytes_per_step"] = h2d_bytes
     table = None
     if want_events and rank == 0:
         # per-kernel HIP-event timing cannot be recorded inside a captured graph: time the same steps eagerly right after
         # the timed region (same kernels, same shapes; rocprofv3 --stats of this command agrees)
+        # ... in the ONE-stream order: a (start, stop) event pair around a launch measures that kernel only if nothing of the
+        # other branch shares the GPU with it (the timed step runs the two branches on two streams)
+        hos = getattr(wl, "hos", None)
+        two = getattr(hos, "two_streams", False)
+        if hos is not None:
+            hos.two_streams = False
         prof = ops.KernelEvents()
         ops.set_kernel_events(prof)
         for i in range(min(args.steps, 3)):
             wl.fwd_bwd(args.warmup + args.steps + i)       # rank-local: no collective outside the timed region
         torch.cuda.synchronize()
         ops.set_kernel_events(None)
+        if hos is not None:
+            hos.two_streams = two
         table = prof.summary()
     return dt, info, table
 
@@ -712,9 +722,10 @@ def main():
             out["h2d_bytes_per_step"] = prim["h2d_bytes_per_step"]
         roof = roofline_of(table, args.gemm)
         if roof is not None:
-            src = ("HIP events around each GEMM launch in an EAGER post-pass of 3 forward+backward passes right after the timed "
-                   "region (same kernels and shapes as the replayed graph, which cannot host per-launch events); the rocprofv3 "
-                   "--kernel-trace --stats summary of the replayed graph is under profiles/")
+            src = ("HIP events around each GEMM launch in an EAGER, ONE-STREAM post-pass of 3 forward+backward passes right after the "
+                   "timed region (same kernels and shapes as the replayed graph, which cannot host per-launch events and runs the "
+                   "two branches concurrently on two streams); the rocprofv3 --kernel-trace --stats summary of the replayed graph "
+                   "is under profiles/")
             roof["measured"] = "eager post-pass"
             out["roofline"] = roof
             out["kernels"] = table[:16]

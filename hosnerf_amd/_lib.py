@@ -28,6 +28,7 @@ PROTOTYPES = {
     "hos_device_count": [],
     "hos_error_string": [_I],
     "hos_set_gemm_mode": [_I],
+    "hos_set_thread_gemm_mode": [_I],
     "hos_get_gemm_mode": [],
     "hos_set_range_flag": [_P],
     "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P, _P],

@@ -259,7 +259,12 @@ inline int zero2d(float* p, long ld, int rows, int cols, hipStream_t s) {
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int g_gemm_mode = HOS_GEMM_BF16X3;
+// Arithmetic mode: a process DEFAULT (set once at start-up) and a per-THREAD override (-1 = follow the default).  The override
+// is what scoped switches use (ops.gemm_mode: "this module's GEMMs in exact fp32"), so two host threads -- e.g. the caller and
+// the autograd engine's worker, or two modules pinned to different modes -- never see each other's setting.
+int g_default_mode = HOS_GEMM_BF16X3;
+thread_local int t_mode = -1;
+#define g_gemm_mode (t_mode >= 0 ? t_mode : g_default_mode)
 unsigned int* g_range_flag = nullptr;      // caller-owned device word (hos_set_range_flag); NULL: no range reporting
 
 }  // namespace
@@ -269,7 +274,12 @@ extern "C" int hos_set_range_flag(unsigned int* flag) { g_range_flag = flag; ret
 
 extern "C" int hos_set_gemm_mode(int mode) {
     if (mode != HOS_GEMM_FP32 && mode != HOS_GEMM_BF16X3) return HOS_E_ARG;
-    g_gemm_mode = mode;
+    g_default_mode = mode;
+    return HOS_OK;
+}
+extern "C" int hos_set_thread_gemm_mode(int mode) {
+    if (mode != -1 && mode != HOS_GEMM_FP32 && mode != HOS_GEMM_BF16X3) return HOS_E_ARG;
+    t_mode = mode;
     return HOS_OK;
 }
 extern "C" int hos_get_gemm_mode(void) { return g_gemm_mode; }

@@ -680,11 +680,13 @@ class _NonRigidFn(torch.autograd.Function):
         x = x.contiguous()
         xyz, saved = net._nonrigid_fwd(specs, x, cond, band_w, save=True, rows_dev=rows_dev)
         ctx.net, ctx.specs, ctx.saved, ctx.x, ctx.band_w, ctx.rows_dev = net, specs, saved, x, band_w, rows_dev
+        ctx.mode = ops.get_gemm_mode()           # the backward pass (another host thread) runs in the arithmetic of this forward
         return xyz
 
     @staticmethod
     def backward(ctx, g):
-        g_x = ctx.net._nonrigid_bwd(ctx.specs, ctx.saved, ctx.x, ctx.band_w, g.contiguous(), rows_dev=ctx.rows_dev)
+        with ops.gemm_mode(ctx.mode):
+            g_x = ctx.net._nonrigid_bwd(ctx.specs, ctx.saved, ctx.x, ctx.band_w, g.contiguous(), rows_dev=ctx.rows_dev)
         ctx.saved = None
         return None, None, None, g_x, None, None, None
 
@@ -695,10 +697,12 @@ class _CanonicalFn(torch.autograd.Function):
         cnl = cnl.contiguous()
         raw, saved = net._canonical_fwd(cnl, state, save=True)
         ctx.net, ctx.saved, ctx.cnl, ctx.raw, ctx.state = net, saved, cnl, raw, state
+        ctx.mode = ops.get_gemm_mode()
         return raw
 
     @staticmethod
     def backward(ctx, g):
-        g_cnl = ctx.net._canonical_bwd(ctx.saved, ctx.cnl, ctx.raw, g.contiguous(), ctx.state)
+        with ops.gemm_mode(ctx.mode):
+            g_cnl = ctx.net._canonical_bwd(ctx.saved, ctx.cnl, ctx.raw, g.contiguous(), ctx.state)
         ctx.saved = ctx.raw = None                       # break the output -> grad_fn -> ctx -> output cycle right away
         return None, None, g_cnl, None

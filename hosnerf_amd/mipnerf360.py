@@ -509,6 +509,7 @@ class _MLPFn(torch.autograd.Function):
     def forward(ctx, token, mlp: MipNeRF360MLP, X, viewdirs, B, S, state):
         density, rgb, saved = mlp._forward_impl(X, viewdirs, B, S, save=True)
         ctx.mlp, ctx.saved, ctx.state = mlp, saved, state
+        ctx.mode = ops.get_gemm_mode()           # the backward pass (another host thread) runs in the arithmetic of this forward
         ctx.density, ctx.rgb = density, rgb
         if rgb is None:
             rgb = torch.zeros(0, device=density.device)
@@ -518,7 +519,8 @@ class _MLPFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_density, g_rgb):
         mlp = ctx.mlp
-        mlp._backward_impl(ctx.saved, ctx.density, ctx.rgb, g_density, None if ctx.rgb is None else g_rgb, ctx.state)
+        with ops.gemm_mode(ctx.mode):
+            mlp._backward_impl(ctx.saved, ctx.density, ctx.rgb, g_density, None if ctx.rgb is None else g_rgb, ctx.state)
         ctx.saved = ctx.density = ctx.rgb = None        # break the output -> grad_fn -> ctx -> output cycle right away
         return None, None, None, None, None, None, None
 

@@ -6,6 +6,7 @@ current torch stream.  Tensors are fp32, contiguous, on the HIP device.
 from __future__ import annotations
 
 import os
+import threading
 
 import math
 from typing import Optional, Tuple
@@ -72,21 +73,30 @@ def _timed(key, flops, launch):
 
 # ------------------------------------------------------------------------------------------ GEMMs
 GEMM_FP32, GEMM_BF16X3, GEMM_PLANES = 0, 1, 2
-_planes_mode = True          # default: planes trunks + split GEMMs elsewhere (the library's own default is GEMM_BF16X3)
+_default_mode = GEMM_PLANES  # process default: planes trunks + split GEMMs elsewhere (the library's own default is GEMM_BF16X3)
+_tls = threading.local()     # .mode: this thread's override (None / absent = follow the default), see `gemm_mode`
 
 
 def set_gemm_mode(mode: int):
-    """0 = exact fp32 MFMA; 1 = split precision (fp16 / bf16 hi-lo, 3 MFMAs per product) on fp32 operands;
-    2 = the same arithmetic, but the wide MLP trunks keep their activations as pre-split 16-bit planes
-    (hos_linearp_*: LDS-DMA staging, no conversion work in the K loop); every other GEMM runs as in mode 1.
-    Process-wide."""
-    global _planes_mode
-    _planes_mode = int(mode) == GEMM_PLANES
-    _lib.check(_lib.load().hos_set_gemm_mode(GEMM_BF16X3 if _planes_mode else int(mode)), "hos_set_gemm_mode")
+    """The process DEFAULT (set once at start-up): 0 = exact fp32 MFMA; 1 = split precision (fp16 / bf16 hi-lo, 3 MFMAs per
+    product) on fp32 operands; 2 = the same arithmetic, but the wide MLP trunks keep their activations as pre-split 16-bit
+    planes (hos_linearp_*: LDS-DMA staging, no conversion work in the K loop); every other GEMM runs as in mode 1.
+    Scoped switches go through the per-thread override (`gemm_mode`), not through this."""
+    global _default_mode
+    _default_mode = int(mode)
+    _lib.check(_lib.load().hos_set_gemm_mode(GEMM_BF16X3 if _default_mode == GEMM_PLANES else _default_mode), "hos_set_gemm_mode")
+
+
+def _set_thread_mode(mode: Optional[int]):
+    _tls.mode = mode
+    _lib.check(_lib.load().hos_set_thread_gemm_mode(-1 if mode is None else (GEMM_BF16X3 if mode == GEMM_PLANES else int(mode))),
+               "hos_set_thread_gemm_mode")
 
 
 def get_gemm_mode() -> int:
-    return GEMM_PLANES if _planes_mode else int(_lib.load().hos_get_gemm_mode())
+    """The mode the calling thread's next GEMM launches in (its override if one is active, the process default otherwise)."""
+    m = getattr(_tls, "mode", None)
+    return _default_mode if m is None else m
 
 
 def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.Tensor], N: int,
@@ -358,18 +368,20 @@ def guarded_forward(module, device, run):
 
 
 class gemm_mode:
-    """Context manager: run the enclosed GEMM launches in another arithmetic mode (the mode is read when a kernel is
-    launched, so this also works while a graph is being captured)."""
+    """Context manager: run the GEMM launches THIS THREAD makes inside the block in another arithmetic mode (the mode is read
+    when a kernel is launched, so this also works while a graph is being captured).  A per-thread override in the library
+    (hos_set_thread_gemm_mode) and here: other host threads -- the autograd engine's worker, another module pinned to another
+    mode -- keep theirs."""
 
     def __init__(self, mode: int):
         self.mode = mode
 
     def __enter__(self):
-        self.prev = get_gemm_mode()
-        set_gemm_mode(self.mode)
+        self.prev = getattr(_tls, "mode", None)
+        _set_thread_mode(self.mode)
 
     def __exit__(self, *exc):
-        set_gemm_mode(self.prev)
+        _set_thread_mode(self.prev)
         return False
 
 

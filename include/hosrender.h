@@ -46,14 +46,22 @@ const char* hos_error_string(int code);
  * All reduction dimensions must be multiples of 32 (buffers are zero-padded by the host side).
  * ------------------------------------------------------------------------------------------ */
 
-/* Arithmetic mode of the three linear entry points (process-wide):
+/* Arithmetic mode of the three linear entry points on fp32 operands (hos_linear_fwd / _dgrad / _wgrad):
  *   HOS_GEMM_FP32   v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain (peak 157 TFLOP/s)
- *   HOS_GEMM_BF16X3 (default) bf16 hi/lo split of both operands, 3 bf16 MFMAs per product, fp32 accumulate:
- *                   fp32-grade results (2.9e-5 RGB L-inf) at 1/3 of the bf16 matrix rate (peak 833 TFLOP/s).
- * Layers with N <= 32 always use the fp32 kernel. */
+ *   HOS_GEMM_BF16X3 (library default) 16-bit hi/lo split of both operands on the fly -- fp16 pairs on the forward side (22
+ *                   mantissa bits), bf16 pairs for gradients (8-bit exponent) -- 3 MFMAs per product, fp32 accumulate:
+ *                   fp32-grade results (2.9e-5 RGB L-inf) at 1/3 of the 16-bit matrix rate (peak 833 TFLOP/s).
+ * (The host side's own default is a third mode built on the same arithmetic: wide MLP trunks keep their activations as
+ *  pre-split 16-bit planes and go through hos_linearp_*; see the planes section below.)
+ * Layers with N <= 32 always use the fp32 kernel.
+ * hos_set_gemm_mode        the process DEFAULT (set once at start-up);
+ * hos_set_thread_gemm_mode an override for the CALLING THREAD only (-1 = follow the default): scoped switches ("this module
+ *                          in exact fp32") use it, so host threads / modules pinned to different modes do not interfere;
+ * hos_get_gemm_mode        the mode the calling thread's next launch will use. */
 #define HOS_GEMM_MODE_FP32 0
 #define HOS_GEMM_MODE_BF16X3 1
 int hos_set_gemm_mode(int mode);
+int hos_set_thread_gemm_mode(int mode);
 int hos_get_gemm_mode(void);
 
 /* Range guard of the split modes.  Forward activations travel as fp16 (hi, lo) pairs: exact to 2^-22 for |x| <= 65504; hi

@@ -142,3 +142,39 @@ def test_checkpoint_round_trip_and_stage3_warm_start(tmp_path):
     missing, unexpected = load_checkpoint(lit2, str(tmp_path / "last.ckpt"), strict=True)
     assert not missing and not unexpected
     assert torch.equal(lit2.human.flat_param, lit.human.flat_param) and torch.equal(lit2.model.flat_param, lit.model.flat_param)
+
+
+def test_gemm_mode_is_a_process_default_plus_a_per_thread_override():
+    """the arithmetic mode must not be process-global state behind a context manager.  `hos_set_gemm_mode` is the
+    process default, `hos_set_thread_gemm_mode` / `ops.gemm_mode` an override of the CALLING thread only (no kernel is launched)."""
+    import threading
+    from hosnerf_amd import _lib, ops
+    lib = _lib.load()
+    ops.set_gemm_mode(ops.GEMM_PLANES)
+    assert ops.get_gemm_mode() == ops.GEMM_PLANES and lib.hos_get_gemm_mode() == ops.GEMM_BF16X3
+    seen = {}
+
+    def other():
+        seen["before"] = (ops.get_gemm_mode(), lib.hos_get_gemm_mode())
+        with ops.gemm_mode(ops.GEMM_BF16X3):
+            seen["inside_other"] = (ops.get_gemm_mode(), lib.hos_get_gemm_mode())
+            ready.set()
+            go.wait(5)
+        seen["after"] = (ops.get_gemm_mode(), lib.hos_get_gemm_mode())
+
+    ready, go = threading.Event(), threading.Event()
+    with ops.gemm_mode(ops.GEMM_FP32):
+        assert ops.get_gemm_mode() == ops.GEMM_FP32 and lib.hos_get_gemm_mode() == ops.GEMM_FP32
+        t = threading.Thread(target=other)
+        t.start()
+        assert ready.wait(5)
+        assert ops.get_gemm_mode() == ops.GEMM_FP32 and lib.hos_get_gemm_mode() == ops.GEMM_FP32      # the other thread's switch is invisible here
+        with ops.gemm_mode(ops.GEMM_BF16X3):                                                              # nesting restores the enclosing override
+            assert lib.hos_get_gemm_mode() == ops.GEMM_BF16X3
+        assert lib.hos_get_gemm_mode() == ops.GEMM_FP32
+        go.set()
+        t.join()
+    assert seen["before"] == (ops.GEMM_PLANES, ops.GEMM_BF16X3)           # this thread's fp32 override was invisible there
+    assert seen["inside_other"] == (ops.GEMM_BF16X3, ops.GEMM_BF16X3) and seen["after"] == (ops.GEMM_PLANES, ops.GEMM_BF16X3)
+    assert ops.get_gemm_mode() == ops.GEMM_PLANES and lib.hos_get_gemm_mode() == ops.GEMM_BF16X3
+    assert lib.hos_set_thread_gemm_mode(7) != 0
