@@ -500,11 +500,11 @@ def roofline_of(table, gemm):
         return None
     dom = max(table, key=lambda r: r["total_ms"])
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_gemmp_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_pmc_gemmp_traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        if tj.get("source_hash") == source_hash("hosnerf_amd/csrc/hos_gemmp.hip", "hosnerf_amd/csrc/hos_gemm_common.h"):
+        if tj.get("source_hash") == source_hash("hosnerf_amd/csrc/hos_gemmp.hip", "hosnerf_amd/csrc/hos_gemm_common.h", "Makefile"):
             traffic = tj.get("kernels", {}).get(dom["kernel"], {}).get("hbm_bytes_per_launch")
     peak = FP32_MFMA_PEAK_TFLOPS if gemm == "fp32" else SPLIT_MFMA_PEAK_TFLOPS
     return {"bound": "mfma", "achieved": dom["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": dom["tflops"] / peak,

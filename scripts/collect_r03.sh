@@ -1,0 +1,19 @@
+#!/bin/bash
+# Everything profiles/r03_* is made from, in one GPU call (~10 min): scripts/collect_r03.sh
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err
+for r in 512 1024 2048 4096; do
+  python bench.py --primary stage3 --only-primary --rays $r --steps 20 --warmup 3 --no-kernel-events 2>/dev/null | tail -1
+done > gpurun_out/r03_strong_scaling_sweep.jsonl
+HOS_TWO_STREAMS=0 python bench.py --primary stage3 --only-primary --rays 512 --steps 20 --warmup 3 --no-kernel-events 2>/dev/null | tail -1 > gpurun_out/r03_one_stream_512.json
+HOS_TWO_STREAMS=0 python bench.py --primary stage3 --only-primary --rays 4096 --steps 20 --warmup 3 --no-kernel-events 2>/dev/null | tail -1 > gpurun_out/r03_one_stream_4096.json
+bash scripts/prof_step.sh 4096 r03_stage3
+bash scripts/prof_step.sh 512 r03_stage3_512rays
+PRIMARY=stage2 bash scripts/prof_step.sh 2048 r03_stage2
+PRIMARY=stage1 bash scripts/prof_step.sh 1024 r03_stage1
+bash scripts/pmc_gemmp_step.sh > gpurun_out/pmc_gemmp.log 2>&1
+bash scripts/pmc_step_traffic.sh stage2 > gpurun_out/pmc_stage2.log 2>&1
+bash scripts/pmc_step_traffic.sh stage3 > gpurun_out/pmc_stage3.log 2>&1
+ls gpurun_out/pmc_gemmp/*.json gpurun_out/pmc_step_stage2/traffic.json gpurun_out/pmc_step_stage3/traffic.json
+tail -c 400 gpurun_out/bench_r03.json
