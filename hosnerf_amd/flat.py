@@ -49,6 +49,9 @@ class FlatStore:
         self.param: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
         self._bindings: List[Tuple[nn.Parameter, Region, Tuple[slice, ...], Tuple[int, ...]]] = []
+        # spans [(offset, numel)] no kernel of a training step reads or writes (see human_nerf.Network: the reference-shaped
+        # first deconvolution weight, of which a compact copy is the live one): zero_grad, the norm and Adam skip them
+        self.inactive: List[Tuple[int, int]] = []
 
     def alloc(self, rows: int, cols: int, rows_pad: Optional[int] = None, ld: Optional[int] = None) -> Region:
         r = Region(rows, cols, rows_pad, ld)
@@ -81,9 +84,24 @@ class FlatStore:
         self.grad = self.grad.to(device)
         self.rebind()
 
+    def active_spans(self) -> List[Tuple[int, int]]:
+        """[(offset, numel)] of the flat buffers a training step touches (everything minus `inactive`)."""
+        spans, pos = [], 0
+        for off, n in sorted(self.inactive):
+            if off > pos:
+                spans.append((pos, off - pos))
+            pos = max(pos, off + n)
+        if pos < self.size:
+            spans.append((pos, self.size - pos))
+        return spans
+
     def zero_grad(self):
         self.ensure_bound()
-        self.grad.zero_()
+        if not self.inactive:
+            self.grad.zero_()
+        else:
+            for off, n in self.active_spans():
+                self.grad[off:off + n].zero_()
 
     def ensure_bound(self):
         """Every parameter's `.grad` must alias the flat gradient buffer: the HIP weight-gradient kernels write into
@@ -105,6 +123,7 @@ class FlatStore:
     def adopt(self, other: "FlatStore") -> int:
         """Append another store's regions to this one (before materialisation); returns the base offset."""
         base = self.size
+        self.inactive.extend((o + base, n) for o, n in other.inactive)
         for r in other.regions:
             r.offset += base
             self.regions.append(r)

@@ -92,7 +92,12 @@ CNL_LDE = 128     # [fourier(63) | state(64) | 0]
 CNL_CAT = 384     # skip-concat row [fourier+state (127) | h (256) | 0]
 
 
+def _round64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
 class Network(FlatModule):
+    COMPACT_FIRST_DECONV = os.environ.get("HOS_COMPACT_DECONV", "1") != "0"
     gemm_mode = None      # None: the process default (ops.set_gemm_mode); ops.GEMM_* pins the arithmetic of this module's GEMMs
 
     def __init__(self, cfg, stage: int = 3):
@@ -129,8 +134,20 @@ class Network(FlatModule):
                 ci = co
         chans.append((ci, K + 1))
         self._deconv_chans = chans
+        self._w0c = None
         for n, (a, b) in enumerate(chans):
             pl[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"] = plain((a, b, 4, 4, 4))
+            if n == 0 and self.COMPACT_FIRST_DECONV:
+                # The first ConvTranspose3d(4, 2, 1) sees ONE input voxel and produces 2^3: output voxel o = 2 * 0 + k - 1 only
+                # exists for k in {1, 2} per axis, so 8 of the kernel's 64 taps can ever contribute -- 7/8 of this layer's
+                # 33.5 M weights (29.4 M of the network's 64.7 M parameters) never influence the output and never receive a
+                # gradient (in the reference neither: Adam leaves them at their initial values).  The reference-shaped parameter
+                # stays in the flat buffer for `state_dict` compatibility but is INACTIVE (no kernel, no zeroing, no norm, no
+                # Adam touches it); the live taps are this compact [Cin, 8 * Cout] copy (tap-major, so x @ Wc IS the
+                # channel-last 2^3 x Cout output), synchronised with the parameter on load / save (`_compact_*`).
+                full = pl[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"][0]
+                st.inactive.append((full.offset, _round64(full.numel)))
+                self._w0c = st.alloc(a, 8 * b)
             pl[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"] = plain((b,))
         pw, pe = cfg.pose_decoder.mlp_width, cfg.pose_decoder.embedding_size
         for name, shp in (("block_mlps.0", (pw, pe)), ("block_mlps.2", (pw, pw)), ("block_mlps.4", (pw, pw)),
@@ -200,6 +217,10 @@ class Network(FlatModule):
         self.reset_parameters()
         self._token = torch.zeros(1, requires_grad=True)
         self._chain_bufs = {}
+        if self._w0c is not None:
+            self._compact_from_full()
+            self.register_load_state_dict_post_hook(lambda module, incompatible: module._compact_from_full())
+            self.register_state_dict_pre_hook(lambda module, prefix, keep_vars: module._compact_to_full())
 
     # ------------------------------------------------------------------ init (U:181-308 initseq rules)
     @torch.no_grad()
@@ -246,6 +267,44 @@ class Network(FlatModule):
         for e in self.human_stateembeds:
             e.normal_()
 
+    # ------------------------------------------------------------------ compact first deconvolution layer
+    _LIVE_TAPS = [(od + 1) * 16 + (oh + 1) * 4 + (ow + 1) for od in range(2) for oh in range(2) for ow in range(2)]
+
+    def _first_deconv(self, grad: bool = False):
+        """(full [Cin, Cout, 64] view of the reference-shaped parameter, compact [Cin, 8, Cout] view) of weights or gradients."""
+        flat = self.store.grad if grad else self.store.param
+        fullp = self._plain["mweight_vol_decoder.decoder.block_conv.0.weight"]
+        full = (fullp.grad if grad else fullp.detach())
+        a, b = fullp.shape[0], fullp.shape[1]
+        return full.view(a, b, 64), self._w0c.view(flat).view(a, 8, b)
+
+    @torch.no_grad()
+    def _compact_from_full(self):
+        """Parameter -> live copy (after `load_state_dict`, `reset_parameters` or any direct write to the parameter)."""
+        if self._w0c is None:
+            return
+        full, comp = self._first_deconv()
+        idx = torch.tensor(self._LIVE_TAPS, device=full.device)
+        comp.copy_(full.index_select(2, idx).permute(0, 2, 1))
+
+    @torch.no_grad()
+    def _compact_to_full(self, grads: bool = False):
+        """Live copy -> parameter (before `state_dict()`; `grads=True`: also the gradient, for code that reads `p.grad` of
+        every named parameter -- `scatter_compact_grads`)."""
+        if self._w0c is None:
+            return
+        for g in ((False, True) if grads else (False,)):
+            full, comp = self._first_deconv(grad=g)
+            idx = torch.tensor(self._LIVE_TAPS, device=full.device)
+            if g:
+                full.zero_()
+            full.index_copy_(2, idx, comp.permute(0, 2, 1).contiguous())
+
+    def scatter_compact_grads(self):
+        """Make `p.grad` of `mweight_vol_decoder.decoder.block_conv.0.weight` reflect the live taps' gradient (it is not kept
+        current during training: nothing in a step reads it).  For inspection / tests that walk `named_parameters()`."""
+        self._compact_to_full(grads=True)
+
     def _after_flat_move(self):
         self._token = torch.zeros(1, device=self.store.param.device, requires_grad=True)
 
@@ -286,8 +345,12 @@ class Network(FlatModule):
         n_conv = len(self._deconv_chans)
         D = 1
         for n in range(n_conv):                  # ConvTranspose3d(4, 2, 1) as GEMM + gather, channel-last (hos_deconv.hip)
-            h = ops.deconv3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
-                             P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], D, n < n_conv - 1)
+            if n == 0 and self._w0c is not None:
+                wc, gwc = self._w0c.view(self.store.param), self._w0c.view(self.store.grad)
+                h = ops.deconv3d_first(h, wc, gwc, P["mweight_vol_decoder.decoder.block_conv.0.bias"], n < n_conv - 1)
+            else:
+                h = ops.deconv3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
+                                 P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], D, n < n_conv - 1)
             D *= 2
         h = h.t().reshape(1, -1, D, D, D)        # [V^3, K+1] -> [1, K+1, V, V, V]
         return F.softmax(h + torch.log(priors[None]), dim=1)[0].contiguous()

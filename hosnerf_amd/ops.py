@@ -446,6 +446,52 @@ def deconv3d(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, D: int, 
     return _Deconv3d.apply(x, weight, bias, D, leaky)
 
 
+class _Deconv3dFirst(torch.autograd.Function):
+    """ConvTranspose3d(4, 2, 1) on ONE input voxel: only the 2 x 2 x 2 centre taps of the kernel reach the 2^3 output, so the
+    layer is x [1, Cin] @ Wc [Cin, 8 * Cout] with the live taps stored tap-major (human_nerf.Network._w0c): the product, viewed
+    as [8, Cout], IS the channel-last output.  `wc` / `gwc` are views of the flat parameter / gradient buffers (the weight
+    gradient is accumulated in place, like every other HIP weight gradient); exact fp32 MFMA like the other decoder layers."""
+
+    @staticmethod
+    def forward(ctx, x, wc, gwc, bias, leaky):
+        Cin, N8 = wc.shape
+        Cout = N8 // 8
+        x = x.contiguous()
+        ycol = torch.empty(1, N8, device=x.device)
+        with gemm_mode(GEMM_FP32):
+            linear_dgrad(x, wc, Cin, N8, ycol)
+        out = ycol.view(8, Cout) + bias.detach()
+        if leaky:
+            out = torch.nn.functional.leaky_relu(out, 0.2)
+        ctx.save_for_backward(x, bias, out)
+        ctx.wc, ctx.gwc, ctx.leaky = wc, gwc, leaky
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, out = ctx.saved_tensors
+        wc, gwc = ctx.wc, ctx.gwc
+        Cin, N8 = wc.shape
+        dpre = torch.where(out > 0, g, 0.2 * g) if ctx.leaky else g
+        dpre = dpre.contiguous()
+        if bias.grad is not None and bias.grad.is_contiguous():
+            bias.grad.add_(dpre.sum(0))
+            db = None
+        else:
+            db = dpre.sum(0)
+        dycol = dpre.view(1, N8)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(1, Cin, device=g.device)
+            call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(wc), wc.stride(0), ptr(dx), dx.stride(0), 1, Cin, N8)
+        call("hos_outer_accum", ptr(x), x.stride(0), ptr(dycol), dycol.stride(0), ptr(gwc), gwc.stride(0), 1, Cin, N8)
+        return dx, None, None, db, None
+
+
+def deconv3d_first(x: torch.Tensor, wc: torch.Tensor, gwc: torch.Tensor, bias: torch.Tensor, leaky: bool) -> torch.Tensor:
+    return _Deconv3dFirst.apply(x, wc, gwc, bias, leaky)
+
+
 # ------------------------------------------------------------------------------------------ rays
 _U_CACHE = {}
 

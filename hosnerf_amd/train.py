@@ -98,8 +98,31 @@ class GradClip:
             self._buf = torch.zeros(1, device=dev)
         self._buf.zero_()
         for o in opts:
-            ops.sumsq(o.module.flat_grad, self._buf)
+            g = o.module.flat_grad
+            for off, n in o.module.store.active_spans():          # the whole buffer unless the module has inactive spans
+                ops.sumsq(g[off:off + n], self._buf)
         return self._buf
+
+
+def _minus_inactive(lr_ranges, module: FlatModule):
+    """Learning-rate ranges with the store's inactive spans cut out (parameters whose gradient is identically zero by
+    construction: Adam leaves them where they are, so they are neither read nor written)."""
+    inactive = sorted(getattr(module.store, "inactive", []))
+    if not inactive:
+        return lr_ranges
+    ranges = lr_ranges or [(0, module.flat_param.numel(), 1.0)]
+    out = []
+    for off, n, mult in ranges:
+        pos, end = off, off + n
+        for io, inn in inactive:
+            if io + inn <= pos or io >= end:
+                continue
+            if io > pos:
+                out.append((pos, io - pos, mult))
+            pos = max(pos, io + inn)
+        if pos < end:
+            out.append((pos, end - pos, mult))
+    return out
 
 
 class FusedAdam:
@@ -113,7 +136,7 @@ class FusedAdam:
         `clip`: a GradClip SHARED with the other FusedAdams of the same step (stage 3: one global norm over both modules,
         applied by `step_all`); `max_grad_norm` alone gives this optimiser its own."""
         self.module = module
-        self.lr_ranges = lr_ranges
+        self.lr_ranges = _minus_inactive(lr_ranges, module)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.clip = clip if clip is not None else GradClip(max_grad_norm)
         self.group = process_group

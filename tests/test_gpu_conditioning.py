@@ -50,6 +50,7 @@ def test_hip_gradients_as_accurate_as_the_fp32_reference_graph():
     net = net.to(dev)
     out = net(**batch_to_device(b, dev), t_rand=t_rand.to(dev))
     _loss(out).backward()
+    net.scatter_compact_grads()
     hip = {k: v.grad.double().cpu() for k, v in net.named_parameters() if k in NAMES}
     # forward, mask weighted (what the composite consumes): fp32-grade against fp64
     got = (out["human_rgb"] * out["pts_mask"][..., None]).detach().double().cpu()

@@ -106,6 +106,7 @@ def test_prologue_backward_vs_fp64_autograd(dev, net):
     loss = sum((o * c.to(dev)).sum() for o, c in zip(outs, cot))
     assert abs(float(loss.detach()) - float(loss64.detach())) < 1e-4 * max(1.0, abs(float(loss64.detach())))
     loss.backward()
+    net.scatter_compact_grads()
     params = dict(net.named_parameters())
     for name, p64 in sd64.items():
         got, want = params[name].grad.detach().double().cpu(), p64.grad

@@ -174,6 +174,7 @@ def test_stage2_vs_torch_rocm():
     assert abs(float(total) - float(tot_o)) < 1e-5 * abs(float(tot_o)), errs
     for k in ("mse", "flow", "cycle"):
         assert abs(errs[k][0] - errs[k][1]) < 1e-3 * abs(errs[k][1]) + 1e-9, errs
+    net.scatter_compact_grads()
     hip_grads = {k: v.grad for k, v in net.named_parameters()}
     worst = 0.0
     for name in ("cnl_mlp.pts_linears.2.weight", "cnl_mlp.pts_linears.10.weight", "cnl_mlp.output_linear.0.weight",

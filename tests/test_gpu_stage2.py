@@ -113,6 +113,7 @@ def test_stage2_step_vs_oracle(dev, net2):
     for k in ("mse", "flow", "cycle"):
         e_ref = abs(outs["f32"][2][k] - parts64[k])
         assert abs(float(parts[k]) - parts64[k]) < 3.0 * e_ref + 1e-5 * max(1e-3, abs(parts64[k])), (k, float(parts[k]), parts64[k])
+    net2.scatter_compact_grads()           # the live taps of the first deconvolution layer -> its reference-shaped p.grad
     params = dict(net2.named_parameters())
     seen, report = 0, {}
     for n, t in grads["f64"].items():
