@@ -752,6 +752,7 @@ class _Raw2Outputs(torch.autograd.Function):
         ctx.save_for_backward(rgbsigma, z_vals, rays_d, mask, bgcolor)
         ctx.last_dist = float(last_dist)
         ctx.mark_non_differentiable(acc, depth)
+        ctx.set_materialize_grads(False)       # no zero tensors for the cotangents nobody feeds (acc, depth: one fill launch each)
         return rgb, acc, w, depth
 
     @staticmethod
@@ -760,7 +761,7 @@ class _Raw2Outputs(torch.autograd.Function):
         B, S = z_vals.shape
         g_rs = torch.empty_like(rgbsigma)
         g_mask = torch.empty(B, S, device=z_vals.device) if mask is not None else None
-        g_rgb = g_rgb.contiguous()     # locals keep the (possibly materialised) cotangents alive until the launch is enqueued
+        g_rgb = torch.zeros_like(rgbsigma[:, 0, :3]) if g_rgb is None else g_rgb.contiguous()     # locals keep the cotangents alive until the launch is enqueued
         g_w = None if g_w is None else g_w.contiguous()
         call("hos_raw2outputs_bwd", ptr(g_rgb), ptr(g_w), ptr(rgbsigma), 4,
              ptr(rgbsigma) + 12, 4, ptr(z_vals), ptr(rays_d), ptr(mask), ptr(bgcolor), ctx.last_dist, B, S,
@@ -792,6 +793,7 @@ class _MergeComposite(torch.autograd.Function):
         ctx.save_for_backward(bkg_rgb, bkg_density, human_rgbsigma, pts_mask, bkg_tdist, pts, rays_o, rays_d, A, tiny_flag)
         ctx.thre = float(thre_fg)
         ctx.mark_non_differentiable(idx_fg, order, zh)
+        ctx.set_materialize_grads(False)       # idx_fg / order / zh carry no gradient: no zero tensors for them (3 fills per step)
         return rgb, hw, idx_fg, order, zh
 
     @staticmethod
@@ -803,7 +805,7 @@ class _MergeComposite(torch.autograd.Function):
         g_bden = torch.empty_like(bkg_density)
         g_h = torch.empty_like(human)
         g_m = torch.empty_like(mask)
-        g_rgb = g_rgb.contiguous()
+        g_rgb = torch.zeros(B, 3, device=mask.device) if g_rgb is None else g_rgb.contiguous()
         g_hw = None if g_hw is None else g_hw.contiguous()
         call("hos_merge_composite_bwd", ptr(g_rgb), ptr(g_hw),
              ptr(tdist), ptr(bkg_rgb), ptr(bkg_density), ptr(human), ptr(pts), ptr(mask), ptr(ro), ptr(rd), ptr(A),
@@ -922,10 +924,13 @@ class _CompactRows(torch.autograd.Function):
              ptr(b_sel), ptr(_compact_workspace(dev), torch.int32))
         ctx.save_for_backward(sel, count)
         ctx.mark_non_differentiable(b_sel, sel, count)
+        ctx.set_materialize_grads(False)       # b_sel [P,3] / sel / count carry no gradient: no zero tensors for them
         return a_sel, b_sel, sel, count
 
     @staticmethod
     def backward(ctx, g_a, *_):
+        if g_a is None:
+            return None, None, None, None
         sel, count = ctx.saved_tensors
         P = sel.numel()
         g = torch.empty(P, 3, device=sel.device)
@@ -968,10 +973,13 @@ class _TrainLosses(torch.autograd.Function):
         ctx.cfg = (float(mse_count), float(w_mse), float(w_flow), float(w_cycle))
         parts = out.detach().clone()
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return out[0], parts
 
     @staticmethod
     def backward(ctx, g_total, _g_parts):
+        if g_total is None:
+            return (None,) * 16
         rgb, target, pts_prev, weights, ray_grid, fg, cam, Kin, observe, deform, n_cyc_dev, out = ctx.saved_tensors
         mse_count, w_mse, w_flow, w_cycle = ctx.cfg
         B = rgb.shape[0]
@@ -1050,6 +1058,7 @@ class _SampleWarp(torch.autograd.Function):
         ctx.save_for_backward(vol, R, T, pts, bmin, bscale, x_skel, mask)
         ctx.K = K
         ctx.mark_non_differentiable(z, pts)
+        ctx.set_materialize_grads(False)       # z [B,N] / pts [B,N,3] carry no gradient: no zero tensors for them (2 fills per step)
         return z, pts, x_skel, mask
 
     @staticmethod
