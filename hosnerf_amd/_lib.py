@@ -85,6 +85,8 @@ PROTOTYPES = {
     "hos_mlp_chain_weight_bytes": [],
     "hos_mlp_chain_aux_floats": [],
     "hos_mlp_chain_pack": [_P, _P, _P, _P, _P, _P],
+    "hos_mlp_chain_pack_fold": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "hos_mlp_chain_unfold_grad": [_P, _P, _P, _I, _I, _P, _I, _P, _P],
     "hos_mlp_chain128_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _P],
     "hos_mlp_chain256_weight_bytes": [],
     "hos_mlp_chain256_aux_floats": [],

@@ -35,13 +35,18 @@ constexpr int KSMAX = 12;           // k-steps of 16: 8 (K = 128), 12 for the sk
 constexpr int CBUF = KSMAX * 2 * 1024;      // one out-block of fragments: k-steps x (hi, lo) x 1 KB
 constexpr int SKIP_LAYER = 4;
 
-__host__ __device__ constexpr int ks_of(int l) { return l == SKIP_LAYER ? 12 : 8; }
-__host__ __device__ constexpr int layer_off(int l) {      // bytes, chain planes of layer l
+// FOLD: the 75 pose-condition columns of the first layer's input are the same for every sample point of a call, so they enter
+// as a per-call bias (b0 + W0[:, :75] . cond, formed by the pack kernel) and the first layer's reduction is the 36 hann features
+// alone: 4 k-steps instead of 8, operand rows PE [P, 64] instead of E [P, 128] -- and since PE is also the skip layer's
+// re-concatenated input, ONE 256-byte row read serves both (768 B per row without the fold).
+__host__ __device__ constexpr int ks_of(int l, bool fold = false) { return l == SKIP_LAYER ? 12 : ((fold && l == 0) ? 4 : 8); }
+__host__ __device__ constexpr int layer_off(int l, bool fold = false) {      // bytes, chain planes of layer l
     int o = 0;
-    for (int i = 0; i < l; ++i) o += 4 * ks_of(i) * 2048;
+    for (int i = 0; i < l; ++i) o += 4 * ks_of(i, fold) * 2048;
     return o;
 }
 constexpr int WC_BYTES = layer_off(NL);
+constexpr int W0H_LD = 64;          // fp32 copy of the hann columns of W0 [128, 64] for the folded first layer's backward pass
 
 struct ChainArgs {
     const float* E; int lde;        // [P, >=128]  first-layer rows [cond | hann | 0]
@@ -86,6 +91,7 @@ __device__ __forceinline__ void load_split8(const float* p, h8& hi, h8& lo) {
 
 #define CH_RD128(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 
+template <bool FOLD>
 __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const wbuf = smem;                                              // 2 x CBUF weight fragments
@@ -104,14 +110,15 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
     const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
     // one 1 KB request of this wave for round q of a chunk (a chunk = ks / 2 rounds of 4 KB)
     auto issue_round = [&](int l, int ob, int parity, int q) {
-        const int ks = l == SKIP_LAYER ? 12 : 8;
-        const int lo = l <= SKIP_LAYER ? l * 4 * 8 * 2048 : (SKIP_LAYER * 4 * 8 + 4 * 12) * 2048 + (l - SKIP_LAYER - 1) * 4 * 8 * 2048;
+        const int ks = ks_of(l, FOLD);
+        // byte offset of layer l's planes: 8 k-steps per earlier layer, +4 behind the skip layer, -4 behind a folded layer 0
+        const int lo = (l * 8 + (l > SKIP_LAYER ? 4 : 0) - ((FOLD && l > 0) ? 4 : 0)) * 4 * 2048;
 #ifndef HOS_CHAIN_NO_DMA        // timing experiments only (results invalid)
         dma16(reinterpret_cast<const char*>(a.Wc) + lo + ob * ks * 2048 + voff + q * 4096, wbuf + parity * CBUF + wave * 1024 + q * 4096);
 #endif
     };
     auto issue_chunk = [&](int l, int ob, int parity) {
-        const int rounds = (l == SKIP_LAYER ? 12 : 8) / 2;
+        const int rounds = ks_of(l, FOLD) / 2;
         for (int q = 0; q < rounds; ++q) issue_round(l, ob, parity, q);
     };
     issue_chunk(0, 0, 0);
@@ -123,7 +130,16 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
         const long lrow = row < P ? row : P - 1;                       // clamped for loads; never stored
         const bool tile_full = (tile + 1) * CROWS <= P;
         h8 bh[KSMAX], bl[KSMAX];
-        {
+        if constexpr (FOLD) {
+            // the hann features: operand of layer 0 AND of the skip layer -- loaded once per tile, kept in slots 8..11
+            const float* pe = a.PE + (size_t)lrow * a.ldpe + 4 * hh;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) load_split8(pe + 16 * s, bh[8 + s], bl[8 + s]);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { bh[s][c] = (_Float16)0.f; bl[s][c] = (_Float16)0.f; }
+        } else {
             const float* e = a.E + (size_t)lrow * a.lde + 4 * hh;
 #pragma unroll
             for (int s = 0; s < 8; ++s) load_split8(e + 16 * s, bh[s], bl[s]);
@@ -136,8 +152,8 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
         int parity = 0;
 #pragma unroll 1
         for (int l = 0; l < NL; ++l) {
-            const int ks = l == SKIP_LAYER ? 12 : 8;
-            if (l == SKIP_LAYER) {
+            const int ks = ks_of(l, FOLD);
+            if (!FOLD && l == SKIP_LAYER) {
                 const float* pe = a.PE + (size_t)lrow * a.ldpe + 4 * hh;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) load_split8(pe + 16 * s, bh[8 + s], bl[8 + s]);
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                 // k-step: back-to-back requests stall the issuing wave, and an in-order wave that waits issues no MFMA
                 int nl = l, nob = ob + 1;
                 if (nob == 4) { nob = 0; nl = l + 1 == NL ? 0 : l + 1; }
-                const int nrounds = (nl == SKIP_LAYER ? 12 : 8) / 2;
+                const int nrounds = ks_of(nl, FOLD) / 2;
                 const int npar = parity ^ 1;
                 const int parity_buf = parity;
                 parity ^= 1;
@@ -173,8 +189,6 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                 // two register sets alternate by k-step parity: a register that an asm read is still filling must not be
                 // copied (the compiler believes the asm statement has completed)
                 h8 fh[2], fl[2];
-                CH_RD128(fh[0], la, 0);
-                CH_RD128(fl[0], la, 1024);
                 // NO fragment read may be in flight across a RUN-TIME branch: at a control-flow merge hipcc is free to copy a
                 // register (v_mov) that it believes the asm statement has already written -- while the LDS is still filling
                 // it.  The original loop decided `ks == 12` inside k-step 7 with the reads of step 8 / the last reads of step 7
@@ -182,6 +196,26 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                 // (garbage in some rows of one wave, layer 5: found by a 600-step soak with NaN-poisoned allocations).  Steps
                 // 0..7 are now straight-line code that ends with everything landed, and the four extra steps of the skip layer
                 // are a second straight-line group inside ONE branch.
+                if (FOLD && l == 0) {
+                    // folded first layer: the four k-steps of the hann features (operand slots 8..11), same discipline
+                    CH_RD128(fh[0], la, 0);
+                    CH_RD128(fl[0], la, 1024);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if (s < 3) {
+                            CH_RD128(fh[(s + 1) & 1], la, (2 * s + 2) * 1024);
+                            CH_RD128(fl[(s + 1) & 1], la, (2 * s + 3) * 1024);
+                            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[s & 1]), "+v"(fl[s & 1]));
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[0]), "+v"(fl[0]), "+v"(fh[1]), "+v"(fl[1]));
+                        }
+                        acc[ob] = mfma3(fh[s & 1], fl[s & 1], bh[8 + s], bl[8 + s], acc[ob]);
+                        if ((s & 1) == 0) issue_round(nl, nob, npar, s >> 1);
+                    }
+                    if (nrounds == 4) { issue_round(nl, nob, npar, 2); issue_round(nl, nob, npar, 3); }     // (0, 3) -> layer 1
+                } else {
+                CH_RD128(fh[0], la, 0);
+                CH_RD128(fl[0], la, 1024);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     if (s < 7) {
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(CT, 2) void chain128_kernel(ChainArgs a) {
                     }
                 }
                 if (ks == 8 && nrounds == 6) { issue_round(nl, nob, npar, 4); issue_round(nl, nob, npar, 5); }
-
+                }
             }
             // ---- epilogue of layer l: bias, ReLU, one store for the backward pass, next layer's B fragments in place
             // lane-dependent part (4 * half) folded into the bases: every access below is base + immediate
@@ -287,27 +321,44 @@ struct PackArgs {
     const float* b[NL];
     const float* W6; int ldw6; const float* b6;
     uint16_t* Wc; float* aux;
+    // FOLD only: the condition vector [ncond] shared by all rows of the coming launches, the number of feature columns behind
+    // it in W0, and the aligned fp32 copy [128, W0H_LD] of those columns (operand of the first layer's backward pass)
+    const float* cond; int ncond; int nfeat; float* w0h;
 };
 
+template <bool FOLD>
 __global__ __launch_bounds__(256) void chain_pack_kernel(PackArgs p) {
     const int l = blockIdx.y;
     if (l == NL) {                                   // biases and the last layer
         for (int i = blockIdx.x * 256 + threadIdx.x; i < AUX_FLOATS; i += gridDim.x * 256) {
             float v = 0.f;
-            if (i < NL * CW) v = p.b[i / CW][i % CW];
+            if (i < NL * CW) {
+                v = p.b[i / CW][i % CW];
+                if (FOLD && i < CW) {                // b0 + W0[:, :ncond] . cond, summed in column order in fp32
+                    const float* w = p.W[0] + (size_t)i * p.ldw[0];
+                    for (int c = 0; c < p.ncond; ++c) v = fmaf(w[c], p.cond[c], v);
+                }
+            }
             else if (i < NL * CW + 3 * CW) { const int j = i - NL * CW; v = p.W6[(j / CW) * p.ldw6 + j % CW]; }
             else if (i < NL * CW + 3 * CW + 3) v = p.b6[i - NL * CW - 3 * CW];
             p.aux[i] = v;
         }
         return;
     }
-    const int ks = ks_of(l);
+    const int ks = ks_of(l, FOLD);
     const int total = 4 * ks * 64 * 8;               // (ob, s, lane, c): one thread writes hi and lo
-    uint16_t* dst = p.Wc + layer_off(l) / 2;
+    uint16_t* dst = p.Wc + layer_off(l, FOLD) / 2;
+    if (FOLD && l == 0)
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < CW * W0H_LD; e += gridDim.x * 256) {
+            const int n = e / W0H_LD, k = e % W0H_LD;
+            p.w0h[e] = k < p.nfeat ? p.W[0][(size_t)n * p.ldw[0] + p.ncond + k] : 0.f;
+        }
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int c = e & 7, lane = (e >> 3) & 63, s = (e >> 9) % ks, ob = (e >> 9) / ks;
         const int n = 32 * ob + (lane & 31), k = 16 * s + 8 * (c >> 2) + 4 * (lane >> 5) + (c & 3);
-        const float w = p.W[l][(size_t)n * p.ldw[l] + k];
+        float w;
+        if (FOLD && l == 0) w = k < p.nfeat ? p.W[0][(size_t)n * p.ldw[0] + p.ncond + k] : 0.f;
+        else w = p.W[l][(size_t)n * p.ldw[l] + k];
         _Float16 hi, lo;
         split_to(w, hi, lo);
         const size_t o = (((size_t)(ob * ks + s) * 2) * 64 + lane) * 8 + c;
@@ -534,27 +585,66 @@ __global__ __launch_bounds__(256) void chain2_pack_kernel(Pack2Args p) {
 extern "C" long long hos_mlp_chain_weight_bytes(void) { return WC_BYTES; }
 extern "C" long long hos_mlp_chain_aux_floats(void) { return AUX_FLOATS; }
 
-extern "C" int hos_mlp_chain_pack(const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
-                                  float* aux, hos_stream_t stream) {
+static int chain_pack_args(PackArgs& p, const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
+                           float* aux, int k0) {
     if (!weights7 || !ldw7 || !biases7 || !chain_planes || !aux) return HOS_E_ARG;
-    PackArgs p{};
     for (int l = 0; l < NL; ++l) {
-        if (!weights7[l] || !biases7[l] || ldw7[l] < 16 * ks_of(l)) return HOS_E_ARG;
+        if (!weights7[l] || !biases7[l] || ldw7[l] < (l == 0 ? k0 : 16 * ks_of(l))) return HOS_E_ARG;
         p.W[l] = weights7[l]; p.ldw[l] = ldw7[l]; p.b[l] = biases7[l];
     }
     if (!weights7[NL] || !biases7[NL] || ldw7[NL] < CW) return HOS_E_ARG;
     p.W6 = weights7[NL]; p.ldw6 = ldw7[NL]; p.b6 = biases7[NL];
     p.Wc = static_cast<uint16_t*>(chain_planes); p.aux = aux;
-    hipLaunchKernelGGL(chain_pack_kernel, dim3(24, NL + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return 0;
+}
+
+extern "C" int hos_mlp_chain_pack(const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
+                                  float* aux, hos_stream_t stream) {
+    PackArgs p{};
+    if (int rc = chain_pack_args(p, weights7, ldw7, biases7, chain_planes, aux, 16 * ks_of(0))) return rc;
+    hipLaunchKernelGGL(chain_pack_kernel<false>, dim3(24, NL + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
     return hos_launch_status();
 }
 
+extern "C" int hos_mlp_chain_pack_fold(const float* const* weights7, const int* ldw7, const float* const* biases7, const float* cond,
+                                       int ncond, int nfeat, void* chain_planes, float* aux, float* w0h, hos_stream_t stream) {
+    if (!cond || !w0h || ncond <= 0 || nfeat <= 0) return HOS_E_ARG;
+    if (nfeat > W0H_LD) return HOS_E_SHAPE;
+    if ((uintptr_t)w0h & 15u) return HOS_E_ALIGN;
+    PackArgs p{};
+    if (int rc = chain_pack_args(p, weights7, ldw7, biases7, chain_planes, aux, ncond + nfeat)) return rc;
+    p.cond = cond; p.ncond = ncond; p.nfeat = nfeat; p.w0h = w0h;
+    hipLaunchKernelGGL(chain_pack_kernel<true>, dim3(24, NL + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    return hos_launch_status();
+}
+
+template <bool FOLD>
+static int chain128_launch(const ChainArgs& a, hipStream_t stream) {
+    // HOS_CHAIN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 26000 -> two workgroups own a CU's whole LDS and no
+    // other kernel's workgroup can become co-resident on it
+    static const size_t pad = getenv("HOS_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("HOS_CHAIN_LDS_PAD")) : 0;
+    const size_t smem = SMEM_BYTES + pad;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain128_kernel<FOLD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long ntiles = (a.P + CROWS - 1) / CROWS;
+    static int max_grid = 0;
+    if (max_grid == 0) { const char* e = getenv("HOS_CHAIN_GRID"); max_grid = e ? atoi(e) : 512; if (max_grid <= 0) max_grid = 512; }
+    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    hipLaunchKernelGGL(chain128_kernel<FOLD>, dim3(grid), dim3(CT), smem, stream, a);
+    return hos_launch_status();
+}
+
+// E == NULL selects the folded form: planes / aux from hos_mlp_chain_pack_fold, PE is the only per-row operand.
 extern "C" int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, int ldpe, const float* x, const void* chain_planes,
                                     const float* aux, float* const* acts6, int ldact, float* xyz, int64_t P,
                                     const int32_t* rows_dev, hos_stream_t stream) {
-    if (!E || !PE || !x || !chain_planes || !aux || !acts6 || !xyz || P <= 0) return HOS_E_ARG;
-    if (lde < 128 || ldpe < 64 || ldact < 128) return HOS_E_SHAPE;
-    if ((lde & 3) || (ldpe & 3) || (ldact & 3) || (((uintptr_t)E | (uintptr_t)PE | (uintptr_t)chain_planes) & 15u)) return HOS_E_ALIGN;
+    if (!PE || !x || !chain_planes || !aux || !acts6 || !xyz || P <= 0) return HOS_E_ARG;
+    if ((E && lde < 128) || ldpe < 64 || ldact < 128) return HOS_E_SHAPE;
+    if ((E && (lde & 3)) || (ldpe & 3) || (ldact & 3) || (((uintptr_t)E | (uintptr_t)PE | (uintptr_t)chain_planes) & 15u)) return HOS_E_ALIGN;
     ChainArgs a{};
     a.E = E; a.lde = lde; a.PE = PE; a.ldpe = ldpe; a.x = x; a.Wc = static_cast<const uint16_t*>(chain_planes); a.aux = aux;
     for (int l = 0; l < NL; ++l) {
@@ -562,21 +652,29 @@ extern "C" int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, in
         a.acts[l] = acts6[l];
     }
     a.ldact = ldact; a.xyz = xyz; a.P = P; a.p_dev = rows_dev; a.range_flag = hos_range_flag_ptr();
-    // HOS_CHAIN_LDS_PAD (diagnostic): extra dynamic LDS per workgroup, e.g. 26000 -> two workgroups own a CU's whole LDS and no
-    // other kernel's workgroup can become co-resident on it
-    static const size_t pad = getenv("HOS_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("HOS_CHAIN_LDS_PAD")) : 0;
-    const size_t smem = SMEM_BYTES + pad;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
+    return E ? chain128_launch<false>(a, static_cast<hipStream_t>(stream)) : chain128_launch<true>(a, static_cast<hipStream_t>(stream));
+}
+
+// Gradients of a folded first layer back into the reference-shaped W0 / b0 (called after the slab reductions have landed):
+//   gW0[n, ncond + k] += gw0h[n, k] (k < nfeat);   gW0[n, c] += db[n] * cond[c] (c < ncond);   gb0[n] += db[n]
+// -- every row of the launch saw the same condition vector, so its weight gradient is the outer product with the bias gradient.
+__global__ __launch_bounds__(256) void chain_unfold_kernel(const float* __restrict__ gw0h, const float* __restrict__ db,
+                                                           const float* __restrict__ cond, int ncond, int nfeat,
+                                                           float* __restrict__ gW0, int ldw, float* __restrict__ gb0) {
+    const int K = ncond + nfeat;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < CW * (K + 1); e += gridDim.x * 256) {
+        const int n = e / (K + 1), c = e % (K + 1);
+        if (c == K) gb0[n] += db[n];
+        else if (c < ncond) gW0[(size_t)n * ldw + c] += db[n] * cond[c];
+        else gW0[(size_t)n * ldw + c] += gw0h[n * W0H_LD + (c - ncond)];
     }
-    const long ntiles = (P + CROWS - 1) / CROWS;
-    static int max_grid = 0;
-    if (max_grid == 0) { const char* e = getenv("HOS_CHAIN_GRID"); max_grid = e ? atoi(e) : 512; if (max_grid <= 0) max_grid = 512; }
-    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    hipLaunchKernelGGL(chain128_kernel, dim3(grid), dim3(CT), smem, static_cast<hipStream_t>(stream), a);
+}
+
+extern "C" int hos_mlp_chain_unfold_grad(const float* gw0h, const float* db, const float* cond, int ncond, int nfeat,
+                                         float* gW0, int ldw, float* gb0, hos_stream_t stream) {
+    if (!gw0h || !db || !cond || !gW0 || !gb0 || ncond <= 0 || nfeat <= 0) return HOS_E_ARG;
+    if (nfeat > W0H_LD || ldw < ncond + nfeat) return HOS_E_SHAPE;
+    hipLaunchKernelGGL(chain_unfold_kernel, dim3(56), dim3(256), 0, static_cast<hipStream_t>(stream), gw0h, db, cond, ncond, nfeat, gW0, ldw, gb0);
     return hos_launch_status();
 }
 

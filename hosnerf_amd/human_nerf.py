@@ -424,10 +424,27 @@ class Network(FlatModule):
         `rows_dev` (int32 [1] on the device): only that many leading rows are live (fixed-capacity cycle set)."""
         Pn = x.shape[0]
         dev = x.device
-        E = torch.empty(Pn, NR_LDE, device=dev)
         PE = torch.empty(Pn, NR_LDPE, device=dev)
+        chain = ops.MLP_CHAIN and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32
+        if chain and ops.MLP_CHAIN_FOLD:
+            # The condition code is one vector per FRAME (mlp_offset.py:55 expands it over the points): W0[:, :75] . cond is a
+            # bias of this launch, the first layer reduces over the 36 hann features only, and the [P, 128] first-layer rows are
+            # never built -- PE serves layer 0 and the skip layer (hos_chain.hip, FOLD).
+            cond = cond.reshape(-1).contiguous()
+            ops.embed_hannw(x, band_w, None, PE, rows_dev=rows_dev)
+            key = id(specs)
+            bufs = self._chain_bufs.get(key)
+            if bufs is None or bufs[0].device != dev or len(bufs) < 3:
+                bufs = self._chain_bufs[key] = ops.mlp_chain_buffers(dev) + (torch.empty(128, 64, device=dev),)
+            ws = [self._w(L) for L in specs]
+            ops.mlp_chain_pack_fold([w for w, _ in ws], [b_ for _, b_ in ws], cond, 6 * band_w.numel(), bufs[0], bufs[1], bufs[2])
+            acts = [torch.empty(Pn, 128, device=dev) for _ in range(6)]
+            xyz = torch.empty(Pn, 3, device=dev)
+            ops.mlp_chain128_fwd(None, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=rows_dev)
+            return xyz, ((None, PE, acts, (bufs[2], cond)) if save else None)
+        E = torch.empty(Pn, NR_LDE, device=dev)
         ops.embed_hannw(x, band_w, cond.reshape(-1), E, PE, rows_dev=rows_dev)
-        if ops.MLP_CHAIN and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32:
+        if chain:
             # the whole MLP in one launch, activations on chip across the layers (hos_chain.hip)
             key = id(specs)
             bufs = self._chain_bufs.get(key)
@@ -438,7 +455,7 @@ class Network(FlatModule):
             acts = [torch.empty(Pn, 128, device=dev) for _ in range(6)]
             xyz = torch.empty(Pn, 3, device=dev)
             ops.mlp_chain128_fwd(E, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=rows_dev)
-            return xyz, ((E, PE, acts) if save else None)
+            return xyz, ((E, PE, acts, None) if save else None)
         acts = []
         h = E
         for i in range(6):
@@ -454,7 +471,7 @@ class Network(FlatModule):
         Wt, bt = self._w(specs[6])
         xyz = torch.empty(Pn, 3, device=dev)
         ops.linear_fwd(h, 128, Wt, bt, 3, xyz, ops.EPI_RESIDUAL, aux=x, rows_dev=rows_dev)
-        return xyz, ((E, PE, acts) if save else None)
+        return xyz, ((E, PE, acts, None) if save else None)
 
     def _canonical_fwd(self, cnl: torch.Tensor, state: int, save: bool):
         """mlp_rgb_sigma.py:49-58 + N:539-540: [P,4] = (sigmoid rgb, relu sigma)."""
@@ -505,13 +522,16 @@ class Network(FlatModule):
         """Parameter gradients into the flat buffer; returns d loss / d x  ([P,3]).  Every layer is 128 wide, so each
         layer's (wgrad, dgrad) pair is one fused pass over (dZ, X) (ops.linear_bwd_fused); HOS_FUSED_BWD=0 selects the
         two-GEMM form."""
-        E, PE, acts = saved
+        E, PE, acts, fold = saved
         Pn, dev = x.shape[0], x.device
         fused = ops.FUSED_THIN_BWD
 
-        def layer_bwd(dz, X, spec, N, K, out, relu_mask, w_col0=0, bias=True):
-            Wt, _ = self._w(spec)
-            gW, gb = self._w(spec, grad=True)
+        def layer_bwd(dz, X, spec, N, K, out, relu_mask, w_col0=0, bias=True, override=None):
+            if override is not None:
+                Wt, gW, gb = override
+            else:
+                Wt, _ = self._w(spec)
+                gW, gb = self._w(spec, grad=True)
             if fused:
                 ops.linear_bwd_fused(dz, X, Wt, gW, gb if bias else None, N, K, out, relu_mask, w_col0=w_col0, rows_dev=rows_dev)
             else:
@@ -521,6 +541,11 @@ class Network(FlatModule):
 
         dz6 = torch.empty(Pn, 32, device=dev)
         ops.slice_pad(g_xyz, 0, 3, dz6, rows_dev=rows_dev)           # [P,3] -> zero-padded [P,32] operand rows, one launch
+        if fold is not None:
+            # gradient buffers of the folded first layer: [128, 64] for the hann columns of W0 + [128] for the folded bias
+            gfold = ops.fold_grad_workspace(dev)
+            gfold.zero_()
+            gw0h, db0 = gfold[:128 * 64].view(128, 64), gfold[128 * 64:]
         with ops.deferred_bwd_reduce():          # the seven slab reductions of this chain as one launch at the end
             dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
             dPE = dE = None
@@ -528,12 +553,19 @@ class Network(FlatModule):
                 if i == 4:
                     dPE = layer_bwd(dz, PE, specs[4], 128, NR_LDPE, torch.empty(Pn, NR_LDPE, device=dev), False, w_col0=128, bias=False)
                     dz = layer_bwd(dz, acts[3], specs[4], 128, 128, torch.empty(Pn, 128, device=dev), True)
+                elif i == 0 and fold is not None:
+                    dE = layer_bwd(dz, PE, specs[0], 128, NR_LDPE, torch.empty(Pn, NR_LDPE, device=dev), False, override=(fold[0], gw0h, db0))
                 elif i == 0:
                     dE = layer_bwd(dz, E, specs[0], 128, NR_LDE, torch.empty(Pn, NR_LDE, device=dev), False)
                 else:
                     dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
         g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
-        ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True, rows_dev=rows_dev)
+        if fold is not None:
+            gW0, gb0 = self._w(specs[0], grad=True)
+            ops.mlp_chain_unfold_grad(gw0h, db0, fold[1], 6 * band_w.numel(), gW0, gb0)
+            ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 0, dPE, 0, g_x, True, rows_dev=rows_dev)
+        else:
+            ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True, rows_dev=rows_dev)
         return g_x
 
     def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):

@@ -267,6 +267,18 @@ WGRAD_WS_MIN = int(os.environ.get("HOS_WGRAD_WS_MIN", "0"))  # ... for gradients
 # ------------------------------------------------------------------------------------------ fused MLP chain (hos_chain.hip)
 MLP_CHAIN = os.environ.get("HOS_MLP_CHAIN", "1") != "0"
 MLP_CHAIN_MIN_ROWS = int(os.environ.get("HOS_MLP_CHAIN_MIN_ROWS", "4096"))
+# the non-rigid chain with the per-frame condition code folded into the first layer's bias (hos_chain.hip, FOLD)
+MLP_CHAIN_FOLD = os.environ.get("HOS_CHAIN_FOLD", "1") != "0"
+_FOLD_WS = {}
+
+
+def fold_grad_workspace(device) -> torch.Tensor:
+    """[128 * 64 + 128] floats per (device, stream): gradient buffers of a folded first layer between its backward launch and
+    hos_mlp_chain_unfold_grad (both enqueued by the same chain backward, so stream order is the only synchronisation needed)."""
+    key = _stream_key(device)
+    if key not in _FOLD_WS:
+        _FOLD_WS[key] = torch.empty(128 * 64 + 128, device=device)
+    return _FOLD_WS[key]
 # the canonical (8 x 256) MLP as a chain launch too: correct (tests/test_gpu_chain.py) but measured no faster than its eight thin
 # launches (1.53 vs 1.51 ms per 262 144 rows: 320 operand + accumulator registers per lane leave one wave per SIMD and one
 # accumulator chain, so the MFMAs run at ~60 % and nothing hides the epilogues) -- off by default
@@ -287,12 +299,28 @@ def mlp_chain_pack(weights, biases, planes, aux):
     call("hos_mlp_chain_pack", _ptr_array(list(weights)), ldw, _ptr_array(list(biases)), ptr(planes, torch.int16), ptr(aux))
 
 
+def mlp_chain_pack_fold(weights, biases, cond, nfeat, planes, aux, w0h):
+    """As mlp_chain_pack with the condition code `cond` (the same in every row of the coming launches) folded into the first
+    layer's bias; `w0h` [128, 64] receives the aligned fp32 copy of W0's feature columns (the backward pass's operand)."""
+    import ctypes
+    ldw = (ctypes.c_int * 7)(*[int(w.stride(0)) for w in weights])
+    call("hos_mlp_chain_pack_fold", _ptr_array(list(weights)), ldw, _ptr_array(list(biases)), ptr(cond), cond.numel(), nfeat,
+         ptr(planes, torch.int16), ptr(aux), ptr(w0h))
+
+
+def mlp_chain_unfold_grad(gw0h, db, cond, nfeat, gW0, gb0):
+    """The folded first layer's gradients back into the reference-shaped ones: gW0[:, C:] += gw0h, gW0[:, :C] += db (x) cond, gb0 += db."""
+    call("hos_mlp_chain_unfold_grad", ptr(gw0h), ptr(db), ptr(cond), cond.numel(), nfeat, ptr(gW0), gW0.stride(0), ptr(gb0))
+
+
 def mlp_chain128_fwd(E, PE, x, planes, aux, acts, xyz, rows_dev=None):
-    """xyz = x + MLP(E | PE) with the six hidden activations written once into `acts` (mlp_offset.py:54-70 in one launch)."""
+    """xyz = x + MLP(E | PE) with the six hidden activations written once into `acts` (mlp_offset.py:54-70 in one launch).
+    E = None: the folded form (planes / aux from mlp_chain_pack_fold), PE is the only per-row operand."""
     P = x.shape[0]
-    _timed(f"mlp_chain128[M={P}]", 2.0 * P * 101120, lambda: call(
-        "hos_mlp_chain128_fwd", ptr(E), E.stride(0), ptr(PE), PE.stride(0), ptr(x), ptr(planes, torch.int16), ptr(aux), _ptr_array(list(acts)),
-        acts[0].stride(0), ptr(xyz), P, ptr(rows_dev, torch.int32)))
+    flop = 101120 if E is not None else 101120 - 128 * 64
+    _timed(f"mlp_chain128{'' if E is not None else 'f'}[M={P}]", 2.0 * P * flop, lambda: call(
+        "hos_mlp_chain128_fwd", ptr(E), 0 if E is None else E.stride(0), ptr(PE), PE.stride(0), ptr(x), ptr(planes, torch.int16), ptr(aux),
+        _ptr_array(list(acts)), acts[0].stride(0), ptr(xyz), P, ptr(rows_dev, torch.int32)))
 
 
 def mlp_chain256_buffers(device):

@@ -473,11 +473,23 @@ int hos_motion_basis_bwd(const float* g_R_bwd, const float* g_T_bwd, const float
  *                         step the MFMA A fragments, reduction index permuted to the accumulator layout) and aux
  *                         (hos_mlp_chain_aux_floats() floats: biases + the last layer).  Once per optimiser step.
  *   hos_mlp_chain128_fwd  E [P, lde >= 128] first-layer rows, PE [P, ldpe >= 64] hann features, x [P,3]; acts6: HOST array of the
- *                         6 output buffers; xyz [P,3].  rows_dev as for hos_linear_fwd. */
+ *                         6 output buffers; xyz [P,3].  rows_dev as for hos_linear_fwd.
+ * Folded form (E == NULL): the condition code (mlp_offset.py:55 -- the pose vector, one per FRAME) is the same in every row of a
+ * launch, so W0[:, :ncond] . cond enters as a bias and the first layer reduces over the hann features alone:
+ *   hos_mlp_chain_pack_fold    as hos_mlp_chain_pack (layer 0: ld >= ncond + nfeat) + cond [ncond] on the device, nfeat <= 64 ->
+ *                              planes / aux of the folded chain and w0h [128, 64] = fp32 copy of W0[:, ncond : ncond + nfeat]
+ *                              (16-byte aligned rows: the W operand of the first layer's hos_linear_bwd_fused, X = PE)
+ *   hos_mlp_chain128_fwd       with E == NULL: PE is read once per row and serves layer 0 and the skip layer
+ *   hos_mlp_chain_unfold_grad  after the backward pass: gW0[:, ncond:] += gw0h, gW0[:, :ncond] += db (x) cond, gb0 += db, where
+ *                              gw0h [128, 64] / db [128] are the (zeroed) gradient buffers the folded first layer accumulated into */
 long long hos_mlp_chain_weight_bytes(void);
 long long hos_mlp_chain_aux_floats(void);
 int hos_mlp_chain_pack(const float* const* weights7, const int* ldw7, const float* const* biases7, void* chain_planes,
                        float* aux, hos_stream_t stream);
+int hos_mlp_chain_pack_fold(const float* const* weights7, const int* ldw7, const float* const* biases7, const float* cond,
+                            int ncond, int nfeat, void* chain_planes, float* aux, float* w0h, hos_stream_t stream);
+int hos_mlp_chain_unfold_grad(const float* gw0h, const float* db, const float* cond, int ncond, int nfeat,
+                              float* gW0, int ldw, float* gb0, hos_stream_t stream);
 int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, int ldpe, const float* x, const void* chain_planes,
                          const float* aux, float* const* acts6, int ldact, float* xyz, int64_t P,
                          const int32_t* rows_dev, hos_stream_t stream);

@@ -35,13 +35,23 @@ def _inputs(P, seed=0):
     return x, cond, band
 
 
+@pytest.fixture(params=[True, False], ids=["fold", "rows"])
+def fold(request):
+    """Both forms of the chain: the condition code folded into the first layer's bias (default), and as columns of every row."""
+    prev = ops.MLP_CHAIN_FOLD
+    ops.MLP_CHAIN_FOLD = request.param
+    yield request.param
+    ops.MLP_CHAIN_FOLD = prev
+
+
 def _both(net, specs, x, cond, band, rows_dev=None):
     prev_c, prev_m = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS
     try:
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = True, 1
-        xyz_c, (E, PE, acts_c) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
+        xyz_c, (Ec, _, acts_c, fold_c) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
+        assert (Ec is None) == ops.MLP_CHAIN_FOLD and (fold_c is not None) == ops.MLP_CHAIN_FOLD
         ops.MLP_CHAIN = False
-        xyz_l, (_, _, acts_l) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
+        xyz_l, (E, PE, acts_l, _) = net._nonrigid_fwd(specs, x, cond, band, save=True, rows_dev=rows_dev)
     finally:
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = prev_c, prev_m
     return xyz_c, acts_c, xyz_l, acts_l, E, PE
@@ -61,7 +71,7 @@ def _ref64(net, specs, E, PE, x):
 
 
 @pytest.mark.parametrize("P", [1, 31, 128, 129, 1000, 4096 + 77, 65536])
-def test_chain_matches_layers_and_fp64(net, P):
+def test_chain_matches_layers_and_fp64(net, P, fold):
     for which, specs in (("nr", net._nr), ("nrf", net._nrf)):
         x, cond, band = _inputs(P, seed=P)
         with torch.no_grad():
@@ -75,7 +85,7 @@ def test_chain_matches_layers_and_fp64(net, P):
         assert float((xyz_c - xyz_l).abs().max()) < 1e-6
 
 
-def test_chain_respects_the_device_row_count(net):
+def test_chain_respects_the_device_row_count(net, fold):
     P, n = 5000, 1234
     x, cond, band = _inputs(P, seed=3)
     cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
@@ -89,16 +99,20 @@ def test_chain_respects_the_device_row_count(net):
             ops.embed_hannw(x, band, cond, E, PE)
             bufs = ops.mlp_chain_buffers(DEV)
             ws = [net._w(L) for L in net._nr]
-            ops.mlp_chain_pack([w for w, _ in ws], [b for _, b in ws], bufs[0], bufs[1])
             acts = [torch.full((P, 128), 7.0, device=DEV) for _ in range(6)]
-            ops.mlp_chain128_fwd(E, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=cnt)
+            if fold:
+                ops.mlp_chain_pack_fold([w for w, _ in ws], [b for _, b in ws], cond, 36, bufs[0], bufs[1], torch.empty(128, 64, device=DEV))
+                ops.mlp_chain128_fwd(None, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=cnt)
+            else:
+                ops.mlp_chain_pack([w for w, _ in ws], [b for _, b in ws], bufs[0], bufs[1])
+                ops.mlp_chain128_fwd(E, PE, x, bufs[0], bufs[1], acts, xyz, rows_dev=cnt)
         finally:
             ops.MLP_CHAIN_MIN_ROWS = prev
     assert torch.equal(xyz[:n], full[0][:n]) and bool((xyz[n:] == 7.0).all())
     assert torch.equal(acts[5][:n], full[1][5][:n]) and bool((acts[5][n:] == 7.0).all())
 
 
-def test_chain_vs_reference_fixture(net):
+def test_chain_vs_reference_fixture(net, fold):
     """The reference's NonRigidMotionMLP on its own hann embedding (tests/golden/human_parts.npz: nonrigid_xyz)."""
     hp = np.load(os.path.join(HERE, "golden", "human_parts.npz"))
     b = synth.human_batch(8, seed=3)
@@ -114,6 +128,63 @@ def test_chain_vs_reference_fixture(net):
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = prev_c, prev_m
     assert float((xyz.cpu() - torch.from_numpy(hp["nonrigid_xyz"])).abs().max()) < 2e-6
     assert float((xyzf.cpu() - torch.from_numpy(hp["nonrigid_fwd_xyz"])).abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("P,n_live", [(4096 + 77, None), (20000, 7777)])
+def test_folded_chain_backward_equals_the_row_form(net, P, n_live):
+    """`_NonRigidFn` through both forms of the chain: d loss / d x and EVERY parameter gradient of the MLP.  The folded first
+    layer gets its weight gradient in two parts (hann columns from the GEMM over PE, condition columns as bias-gradient (x)
+    cond) -- against the row form, where all 111 columns come out of one GEMM over E, and against float64 autograd."""
+    from hosnerf_amd.human_nerf import _NonRigidFn
+    x, cond, band = _inputs(P, seed=11)
+    g = torch.randn(P, 3, generator=torch.Generator().manual_seed(5)).to(DEV)
+    rows_dev = None if n_live is None else torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    n = P if n_live is None else n_live
+    if n_live is not None:
+        g[n:] = 0
+    res = {}
+    prev = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD
+    try:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS = True, 1
+        for f in (True, False):
+            ops.MLP_CHAIN_FOLD = f
+            net.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            xyz = _NonRigidFn.apply(torch.zeros((), device=DEV, requires_grad=True), net, "nr", xx, cond, band, rows_dev)
+            xyz.backward(g)
+            res[f] = (xyz.detach()[:n].clone(), xx.grad[:n].clone(),
+                      {k: v.grad.detach().clone() for k, v in net.named_parameters() if k.startswith("non_rigid_mlp.")})
+    finally:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD = prev
+        net.zero_grad()
+    # float64 autograd of the same MLP on the live rows
+    sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in net.named_parameters() if k.startswith("non_rigid_mlp.")}
+    x64 = x[:n].double().clone().requires_grad_(True)
+    freqs = 2.0 ** torch.arange(6, dtype=torch.float64, device=DEV)
+    ang = x64[:, None, :] * freqs[None, :, None]
+    pe = (torch.cat([torch.sin(ang), torch.cos(ang)], -1) * band.double()[None, :, None]).reshape(n, 36)
+    names = sorted({k.rsplit(".", 1)[0] for k in sd}, key=lambda s_: int(s_.split(".")[-1]))
+    h = torch.cat([cond.double()[None].expand(n, -1), pe], 1)
+    for i, nm in enumerate(names):
+        if i == 4:
+            h = torch.cat([h, pe], 1)
+        h = h @ sd[nm + ".weight"].T + sd[nm + ".bias"]
+        if i < len(names) - 1:
+            h = torch.relu(h)
+    (x64 + h).backward(g[:n].double())
+    assert float((res[True][0] - res[False][0]).abs().max()) < 1e-6
+    gx_scale = float(x64.grad.abs().max())
+    assert torch.equal(res[True][1], res[False][1])          # same masks, same weights, same kernels behind the first layer
+    # against float64: all rows but the few where an fp32 pre-activation within rounding of 0 takes the other ReLU branch
+    row_err = (res[True][1].double() - x64.grad).abs().max(1).values
+    assert int((row_err > 2e-5 * gx_scale).sum()) <= 3 and float(row_err.max()) < 2e-2 * gx_scale, (int((row_err > 2e-5 * gx_scale).sum()), float(row_err.max()))
+    assert len(res[True][2]) == 14
+    for k, t in sd.items():
+        ref = t.grad
+        scale = float(ref.abs().max()) + 1e-30
+        e_fold = float((res[True][2][k].double() - ref).abs().max()) / scale
+        e_rows = float((res[False][2][k].double() - ref).abs().max()) / scale
+        assert e_fold < max(3.0 * e_rows, 1e-4), (k, e_fold, e_rows)
 
 
 # ------------------------------------------------------------------------------------------------ canonical MLP (8 x 256)
