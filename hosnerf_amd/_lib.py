@@ -37,6 +37,8 @@ PROTOTYPES = {
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "hos_thin_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _P],
+    "hos_canonical_fold_pack": [_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "hos_canonical_fold_unfold": [_P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "hos_mlp_bwd_defer": [_I],
     "hos_mlp_bwd_flush": [_P],
     "hos_mlp_bwd_ws_floats": [_I, _I, _I, _I],

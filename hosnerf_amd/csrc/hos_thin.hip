@@ -305,20 +305,98 @@ int launch_thin(const ThinArgs& a, hipStream_t stream) {
     return hos_launch_status();
 }
 
+// ---- The canonical MLP with its per-call state embedding folded into biases (mlp_rgb_sigma.py:49-58: the input row is
+// [fourier nf | state ne], the skip layer's [fourier nf | state ne | h nh]; the state embedding is ONE vector per call).
+//   pack:   W0f [n0, nfp] = W0[:, :nf] | 0,   b0f = b0 + W0[:, nf:nf+ne] . embed
+//           W5f [n0, nfp + nh] = W5[:, :nf] | 0 | W5[:, nf+ne:],   b5f = b5 + W5[:, nf:nf+ne] . embed        (nfp = nf rounded up to 4)
+//   unfold: the gradients of the folded layers back into the reference-shaped ones, the state columns as db (x) embed, and
+//           d embed += W0[:, nf:nf+ne]^T db0 + W5[:, nf:nf+ne]^T db5 (fixed-order fp32 sums)
+struct CnlFold {
+    const float* W0; int ld0; const float* b0; const float* W5; int ld5; const float* b5;
+    const float* embed; int n0, nf, ne, nh, nfp;
+    float* W0f; float* b0f; float* W5f; float* b5f;                   // pack outputs / unfold: gradient INPUTS (gW0f, db0, gW5f, db5)
+    float* gW0; float* gb0; float* gW5; float* gb5; float* g_embed;   // unfold outputs (+=)
+};
+
+__global__ __launch_bounds__(256) void cnl_fold_pack_kernel(const CnlFold a) {
+    const int n = blockIdx.x, t = threadIdx.x;
+    const float* w0 = a.W0 + (size_t)n * a.ld0;
+    const float* w5 = a.W5 + (size_t)n * a.ld5;
+    for (int k = t; k < a.nfp; k += 256) a.W0f[(size_t)n * a.nfp + k] = k < a.nf ? w0[k] : 0.f;
+    const int k5 = a.nfp + a.nh;
+    for (int k = t; k < k5; k += 256) a.W5f[(size_t)n * k5 + k] = k < a.nf ? w5[k] : (k < a.nfp ? 0.f : w5[a.nf + a.ne + (k - a.nfp)]);
+    if (t < 2) {
+        const float* w = (t ? w5 : w0) + a.nf;
+        float v = t ? a.b5[n] : a.b0[n];
+        for (int c = 0; c < a.ne; ++c) v = fmaf(w[c], a.embed[c], v);
+        (t ? a.b5f : a.b0f)[n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void cnl_fold_unfold_kernel(const CnlFold a) {
+    const int t = threadIdx.x;
+    if ((int)blockIdx.x == a.n0) {                 // d embed: one thread per state column, sums over the output rows in order
+        if (t < a.ne) {
+            float s = 0.f;
+            for (int n = 0; n < a.n0; ++n) s = fmaf(a.W0[(size_t)n * a.ld0 + a.nf + t], a.b0f[n], s);
+            for (int n = 0; n < a.n0; ++n) s = fmaf(a.W5[(size_t)n * a.ld5 + a.nf + t], a.b5f[n], s);
+            a.g_embed[t] += s;
+        }
+        return;
+    }
+    const int n = blockIdx.x;
+    const float d0 = a.b0f[n], d5 = a.b5f[n];
+    float* g0 = a.gW0 + (size_t)n * a.ld0;
+    float* g5 = a.gW5 + (size_t)n * a.ld5;
+    const int k5 = a.nfp + a.nh;
+    for (int k = t; k < a.nf + a.ne; k += 256) {
+        g0[k] += k < a.nf ? a.W0f[(size_t)n * a.nfp + k] : d0 * a.embed[k - a.nf];
+        g5[k] += k < a.nf ? a.W5f[(size_t)n * k5 + k] : d5 * a.embed[k - a.nf];
+    }
+    for (int j = t; j < a.nh; j += 256) g5[a.nf + a.ne + j] += a.W5f[(size_t)n * k5 + a.nfp + j];
+    if (t == 0) { a.gb0[n] += d0; a.gb5[n] += d5; }
+}
+
 }  // namespace
 
-// Y[M, N] = epi(X[M, :K] . W[:N, :K]^T + bias), N <= 256, K <= 256 (K % 4 == 0), epilogue HOS_EPI_NONE or HOS_EPI_RELU.
+extern "C" int hos_canonical_fold_pack(const float* W0, int ld0, const float* b0, const float* W5, int ld5, const float* b5,
+                                       const float* embed, int n_out, int nf, int ne, int nh,
+                                       float* W0f, float* b0f, float* W5f, float* b5f, hos_stream_t stream) {
+    if (!W0 || !b0 || !W5 || !b5 || !embed || !W0f || !b0f || !W5f || !b5f) return HOS_E_ARG;
+    if (n_out <= 0 || nf <= 0 || ne <= 0 || nh <= 0 || ld0 < nf + ne || ld5 < nf + ne + nh) return HOS_E_SHAPE;
+    CnlFold a{W0, ld0, b0, W5, ld5, b5, embed, n_out, nf, ne, nh, (nf + 3) & ~3, W0f, b0f, W5f, b5f, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(cnl_fold_pack_kernel, dim3(n_out), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hos_launch_status();
+}
+
+extern "C" int hos_canonical_fold_unfold(const float* gW0f, const float* db0, const float* gW5f, const float* db5,
+                                         const float* W0, int ld0, const float* W5, int ld5, const float* embed,
+                                         int n_out, int nf, int ne, int nh,
+                                         float* gW0, float* gb0, float* gW5, float* gb5, float* g_embed, hos_stream_t stream) {
+    if (!gW0f || !db0 || !gW5f || !db5 || !W0 || !W5 || !embed || !gW0 || !gb0 || !gW5 || !gb5 || !g_embed) return HOS_E_ARG;
+    if (n_out <= 0 || nf <= 0 || ne <= 0 || ne > 256 || nh <= 0 || ld0 < nf + ne || ld5 < nf + ne + nh) return HOS_E_SHAPE;
+    CnlFold a{W0, ld0, nullptr, W5, ld5, nullptr, embed, n_out, nf, ne, nh, (nf + 3) & ~3,
+              const_cast<float*>(gW0f), const_cast<float*>(db0), const_cast<float*>(gW5f), const_cast<float*>(db5), gW0, gb0, gW5, gb5, g_embed};
+    hipLaunchKernelGGL(cnl_fold_unfold_kernel, dim3(n_out + 1), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hos_launch_status();
+}
+
+// Y[M, N] = epi(X[M, :K] . W[:N, :K]^T + bias), N <= 256, K <= 320 (K % 4 == 0), epilogue HOS_EPI_NONE or HOS_EPI_RELU.
 // relu_bits (optional, 2 * 512 * ceil(M / 32) bytes): one bit per output element = "came out > 0", in the order the backward
 // kernel (hos_thin_linear_dgrad, mask_bits) consumes it; a waves's 32 columns that lie at or beyond N are not written.
 extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const float* bias, float* Y, int ldy,
                                    int M, int N, int K, int epilogue, void* relu_bits, hos_stream_t stream) {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
-    if (N > 256 || K > 256 || (epilogue != HOS_EPI_NONE && epilogue != HOS_EPI_RELU)) return HOS_E_SHAPE;
+    if (N > 256 || K > 320 || (epilogue != HOS_EPI_NONE && epilogue != HOS_EPI_RELU)) return HOS_E_SHAPE;
     if ((ldx & 3) || (ldw & 3) || (K & 3) || (((uintptr_t)X | (uintptr_t)W) & 15u)) return HOS_E_ALIGN;
     if (relu_bits && ((uintptr_t)relu_bits & 1u)) return HOS_E_ALIGN;
     ThinArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, epilogue, nullptr, 0, hos_range_flag_ptr(), static_cast<uint16_t*>(relu_bits)};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return K <= 128 ? launch_thin<8, false>(a, s) : launch_thin<16, false>(a, s);
+    // reduction steps held in registers: 4 (the folded canonical input layer, 64 columns), 8, 16, 20 (the folded skip layer:
+    // [fourier 64 | h 256]; 250 VGPRs -- 24 steps for the reference-shaped 384-wide concat row do not fit two waves per SIMD)
+    if (K <= 64) return launch_thin<4, false>(a, s);
+    if (K <= 128) return launch_thin<8, false>(a, s);
+    return K <= 256 ? launch_thin<16, false>(a, s) : launch_thin<20, false>(a, s);
 }
 
 // dX[M, K] = (dY[M, :Npad] . W[:Npad, :K]) * [mask > 0], K <= 256 output columns, Npad <= 256 (Npad % 4 == 0; rows of W and

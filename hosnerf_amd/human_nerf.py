@@ -90,6 +90,8 @@ NR_LDE = 128      # [cond(75) | hann features(36) | 0]  -> first-layer input row
 NR_LDPE = 64      # hann features alone (36, zero padded) for the skip concat
 CNL_LDE = 128     # [fourier(63) | state(64) | 0]
 CNL_CAT = 384     # skip-concat row [fourier+state (127) | h (256) | 0]
+CNL_NF = 63       # Fourier features of a canonical point (3 + 6 x 10)
+CNL_NFP = 64      # ... padded: the folded forms' input rows [fourier | 0] and concat rows [fourier | 0 | h (256)]
 
 
 def _round64(n: int) -> int:
@@ -477,13 +479,13 @@ class Network(FlatModule):
         """mlp_rgb_sigma.py:49-58 + N:539-540: [P,4] = (sigmoid rgb, relu sigma)."""
         Pn = cnl.shape[0]
         dev = cnl.device
-        E = torch.empty(Pn, CNL_LDE, device=dev)
-        CAT = torch.empty(Pn, CNL_CAT, device=dev)
-        CAT[:, CNL_CAT - 1].zero_()
         embed = self._embeds.view(self.store.param)[state]
-        ops.embed_fourier(cnl, 10, embed, E, CAT)
         if ops.MLP_CHAIN and ops.MLP_CHAIN256 and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32:
             # the whole canonical MLP in one launch, activations on chip across the eight layers (hos_chain.hip)
+            E = torch.empty(Pn, CNL_LDE, device=dev)
+            CAT = torch.empty(Pn, CNL_CAT, device=dev)
+            CAT[:, CNL_CAT - 1].zero_()
+            ops.embed_fourier(cnl, 10, embed, E, CAT)
             bufs = self._chain_bufs.get("cnl")
             if bufs is None or bufs[0].device != dev:
                 bufs = self._chain_bufs["cnl"] = ops.mlp_chain256_buffers(dev)
@@ -492,7 +494,28 @@ class Network(FlatModule):
             acts = [CAT if i == 4 else torch.empty(Pn, 256, device=dev) for i in range(8)]
             raw = torch.empty(Pn, 4, device=dev)
             ops.mlp_chain256_fwd(E, bufs[0], bufs[1], acts, [127 if i == 4 else 0 for i in range(8)], raw)
-            return raw, ((E, acts, [None] * 8) if save else None)
+            return raw, ((E, acts, [None] * 8, None) if save else None)
+        # The state embedding is ONE vector per call (N:177-230 picks it by frame time): its 64 columns of the input layer and of
+        # the skip layer are biases of this call.  Folded form (hos_thin.hip: hos_canonical_fold_*): input rows [fourier 63 | 0],
+        # concat rows [fourier 63 | 0 | h 256] with the h part 16-byte aligned -- 64 / 320 columns instead of 128 / 384, and the
+        # 320-wide skip layer fits the register-resident thin kernel (20 reduction steps) instead of the tiled GEMM.
+        fold = None
+        if ops.CNL_FOLD and ops.thin_dgrad_rows(Pn):
+            fb = self._chain_bufs.get("cnl_fold")
+            if fb is None or fb.device != dev:
+                fb = self._chain_bufs["cnl_fold"] = torch.empty(256 * (2 * CNL_NFP + 256 + 2), device=dev)
+            fw = ops.cnl_fold_views(fb, 256, CNL_NFP, 256)
+            (W0, b0), (W5, b5) = self._w(self._cnl[0]), self._w(self._cnl[5])
+            ops.canonical_fold_pack(W0, b0, W5, b5, embed, 256, CNL_NF, 256, fw)
+            E = torch.empty(Pn, CNL_NFP, device=dev)
+            CAT = torch.empty(Pn, CNL_NFP + 256, device=dev)
+            ops.embed_fourier(cnl, 10, ops.zero1(dev), E, CAT)          # a one-element zero "state" = the pad column of both rows
+            fold = (fw, embed)
+        else:
+            E = torch.empty(Pn, CNL_LDE, device=dev)
+            CAT = torch.empty(Pn, CNL_CAT, device=dev)
+            CAT[:, CNL_CAT - 1].zero_()
+            ops.embed_fourier(cnl, 10, embed, E, CAT)
         acts, bits = [], []
         h = E
         # training: every layer on the thin kernel also writes its ReLU mask as one bit per element (1 KB per 32 rows), which the
@@ -501,21 +524,25 @@ class Network(FlatModule):
         for i in range(8):
             L = self._cnl[i]
             Wt, bt = self._w(L)
-            rb = ops.thin_relu_bits(Pn, dev) if (want_bits and L.Kpad <= 256) else None
-            if i == 4:      # its output feeds the skip concat: write it at column 127 of CAT
-                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, CAT, ops.EPI_RELU, out_col0=127, relu_bits=rb)
+            K = L.Kpad
+            if fold is not None and i in (0, 5):
+                Wt, bt = (fold[0][0], fold[0][1]) if i == 0 else (fold[0][2], fold[0][3])
+                K = Wt.shape[1]
+            rb = ops.thin_relu_bits(Pn, dev) if (want_bits and K <= 320) else None
+            if i == 4:      # its output feeds the skip concat: write it behind the input columns of CAT
+                ops.linear_fwd(h, K, Wt, bt, 256, CAT, ops.EPI_RELU, out_col0=CNL_NFP if fold is not None else 127, relu_bits=rb)
                 acts.append(CAT)
                 h = CAT
             else:
                 out = torch.empty(Pn, 256, device=dev)
-                ops.linear_fwd(h, L.Kpad, Wt, bt, 256, out, ops.EPI_RELU, relu_bits=rb)
+                ops.linear_fwd(h, K, Wt, bt, 256, out, ops.EPI_RELU, relu_bits=rb)
                 acts.append(out)
                 h = out
             bits.append(rb)
         Wt, bt = self._w(self._cnl[8])
         raw = torch.empty(Pn, 4, device=dev)
         ops.linear_fwd(h, 256, Wt, bt, 4, raw, ops.EPI_SIGMOID_RELU4)
-        return raw, ((E, acts, bits) if save else None)
+        return raw, ((E, acts, bits, fold) if save else None)
 
     # ------------------------------------------------------------------ HIP MLP chains (backward)
     def _nonrigid_bwd(self, specs: List[_LayerSpec], saved, x: torch.Tensor, band_w: torch.Tensor, g_xyz: torch.Tensor, rows_dev=None):
@@ -569,7 +596,7 @@ class Network(FlatModule):
         return g_x
 
     def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):
-        E, acts, bits = saved
+        E, acts, bits, fold = saved
         CAT = acts[4]
         Pn, dev = cnl.shape[0], cnl.device
         dz8 = torch.empty(Pn, 32, device=dev)
@@ -581,12 +608,29 @@ class Network(FlatModule):
         ops.linear_dgrad(dz8, Wt, 32, 256, dz, mask_src=acts[7], mask_bits=bits[7])
         dCAT = dE = None
         tmp_b = {}
+        if fold is not None:
+            # gradient buffers of the two folded layers (zeroed: the launches below accumulate), unfolded after the reductions
+            gws = ops.cnl_fold_grad_workspace(dev, 256, CNL_NFP, 256)
+            gws.zero_()
+            gfold = ops.cnl_fold_views(gws, 256, CNL_NFP, 256)
         with ops.deferred_bwd_reduce():          # the slab reductions of the eight 256-wide weight gradients as one launch at the end
             for i in range(7, -1, -1):
                 L = self._cnl[i]
                 Wt, _ = self._w(L)
                 gW, gb = self._w(L, grad=True)
-                if i == 5:
+                if i == 5 and fold is not None:
+                    W5f = fold[0][2]
+                    ops.linear_wgrad(dz, CAT, gfold[2], gfold[3], 256, CNL_NFP + 256)
+                    nxt = torch.empty(Pn, 256, device=dev)
+                    dCAT = torch.empty(Pn, CNL_NFP, device=dev)
+                    ops.linear_dgrad(dz, W5f, 256, CNL_NFP, dCAT, thin=True)
+                    ops.linear_dgrad(dz, W5f, 256, 256, nxt, mask_src=CAT, w_col0=CNL_NFP, mask_col0=CNL_NFP, mask_bits=bits[4])
+                    dz = nxt
+                elif i == 0 and fold is not None:
+                    ops.linear_wgrad(dz, E, gfold[0], gfold[1], 256, CNL_NFP)
+                    dE = torch.empty(Pn, CNL_NFP, device=dev)
+                    ops.linear_dgrad(dz, fold[0][0], 256, CNL_NFP, dE, thin=True)
+                elif i == 5:
                     tmp_b[5] = torch.zeros(L.Npad, device=dev)
                     ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
                     nxt = torch.empty(Pn, 256, device=dev)
@@ -613,13 +657,18 @@ class Network(FlatModule):
                     nxt = torch.empty(Pn, 256, device=dev)
                     ops.linear_dgrad(dz, Wt, 256, 256, nxt, mask_src=inp, mask_bits=bits[i - 1])
                     dz = nxt
-        # state embedding: its 64 columns are constant over samples -> d embed = db @ W[:, 63:127] (layers 0 and 5)
         g_embed = self._embeds.view(self.store.grad)[state]
-        for i in (0, 5):
-            Wt, _ = self._w(self._cnl[i])
-            _, gb = self._w(self._cnl[i], grad=True)
-            gb += tmp_b[i]
-            g_embed.addmv_(Wt[:256, 63:127].t(), tmp_b[i][:256])
+        if fold is not None:
+            (W0, _), (W5, _) = self._w(self._cnl[0]), self._w(self._cnl[5])
+            (gW0, gb0), (gW5, gb5) = self._w(self._cnl[0], grad=True), self._w(self._cnl[5], grad=True)
+            ops.canonical_fold_unfold(gfold, W0, W5, fold[1], 256, CNL_NF, 256, gW0, gb0, gW5, gb5, g_embed)
+        else:
+            # state embedding: its 64 columns are constant over samples -> d embed = db @ W[:, 63:127] (layers 0 and 5)
+            for i in (0, 5):
+                Wt, _ = self._w(self._cnl[i])
+                _, gb = self._w(self._cnl[i], grad=True)
+                gb += tmp_b[i]
+                g_embed.addmv_(Wt[:256, 63:127].t(), tmp_b[i][:256])
         g_cnl = torch.empty(Pn, 3, device=dev)
         ops.embed_bwd(cnl, None, 10, True, dE, 0, dCAT, 0, g_cnl, False)
         return g_cnl

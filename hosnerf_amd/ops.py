@@ -111,7 +111,7 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
     M = A0.shape[0] if M is None else M
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
-    if (THIN_GEMM and rows_dev is None and A1 is None and 128 < N <= 256 and K0 <= 256 and K0 % 4 == 0 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
+    if (THIN_GEMM and rows_dev is None and A1 is None and 128 < N <= 256 and K0 <= 320 and K0 % 4 == 0 and M >= 16384 and epilogue in (EPI_NONE, EPI_RELU)
             and ldc is None and out is not None and _lib.load().hos_get_gemm_mode() == GEMM_BF16X3):
         # many rows through a thin layer: persistent kernel with the weight in registers (hos_thin.hip)
         _timed(f"thin_fwd[M={M},N={N},K={K0}]", 2.0 * M * N * K0, lambda: call(
@@ -125,6 +125,50 @@ def linear_fwd(A0: torch.Tensor, K0: int, W: torch.Tensor, bias: Optional[torch.
         ptr(W), W.stride(0), ptr(bias), ptr(out) + 4 * out_col0, (0 if out is None else out.stride(0)) if ldc is None else ldc,
         M, N, epilogue, ptr(aux), aux_col, float(p0), 0.0, ptr(rows_dev, torch.int32)))
     return out
+
+
+# the canonical MLP with its per-call state embedding folded into the biases of the input layer and the skip layer (hos_thin.hip)
+CNL_FOLD = os.environ.get("HOS_CNL_FOLD", "1") != "0"
+_CNL_FOLD_WS = {}
+_ZERO1 = {}
+
+
+def zero1(device) -> torch.Tensor:
+    """A cached [1] zero on the device (e.g. the pad column of an embedder row passed as a one-element 'state')."""
+    key = str(torch.device(device))
+    if key not in _ZERO1:
+        _ZERO1[key] = torch.zeros(1, device=device)
+    return _ZERO1[key]
+
+
+def canonical_fold_pack(W0, b0, W5, b5, embed, n_out, nf, nh, out):
+    """`out` = (W0f [n_out, nfp], b0f [n_out], W5f [n_out, nfp + nh], b5f [n_out]), see hos_canonical_fold_pack."""
+    call("hos_canonical_fold_pack", ptr(W0), W0.stride(0), ptr(b0), ptr(W5), W5.stride(0), ptr(b5), ptr(embed), n_out, nf, embed.numel(), nh,
+         ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]))
+
+
+def canonical_fold_unfold(grads, W0, W5, embed, n_out, nf, nh, gW0, gb0, gW5, gb5, g_embed):
+    """`grads` = (gW0f, db0, gW5f, db5) accumulated by the backward launches of the folded layers -> += into the reference-shaped
+    gradients and the state embedding's (hos_canonical_fold_unfold)."""
+    call("hos_canonical_fold_unfold", ptr(grads[0]), ptr(grads[1]), ptr(grads[2]), ptr(grads[3]), ptr(W0), W0.stride(0), ptr(W5), W5.stride(0),
+         ptr(embed), n_out, nf, embed.numel(), nh, ptr(gW0), ptr(gb0), ptr(gW5), ptr(gb5), ptr(g_embed))
+
+
+def cnl_fold_views(buf: torch.Tensor, n_out: int, nfp: int, nh: int):
+    """(W [n_out, nfp], b [n_out], W5 [n_out, nfp + nh], b5 [n_out]) as views of one flat buffer (16-byte aligned matrices)."""
+    o1 = n_out * nfp
+    o2 = o1 + n_out
+    o3 = o2 + n_out * (nfp + nh)
+    return buf[:o1].view(n_out, nfp), buf[o1:o2], buf[o2:o3].view(n_out, nfp + nh), buf[o3:o3 + n_out]
+
+
+def cnl_fold_grad_workspace(device, n_out: int, nfp: int, nh: int) -> torch.Tensor:
+    """Gradient buffers of the two folded layers, one per (device, stream): filled by the backward launches, consumed by
+    canonical_fold_unfold on the same stream."""
+    key = _stream_key(device) + (n_out, nfp, nh)
+    if key not in _CNL_FOLD_WS:
+        _CNL_FOLD_WS[key] = torch.empty(n_out * (2 * nfp + nh + 2), device=device)
+    return _CNL_FOLD_WS[key]
 
 
 def thin_dgrad_rows(M: int) -> bool:

@@ -138,7 +138,8 @@ long long hos_mlp_bwd_ws_floats(int M, int N, int K, int fused);
 int hos_linear_wgrad_tr(const float* dY, int lddy, const float* X, int ldx, float* dW, int lddw, float* db,
                         int M, int N, int K, float* ws, int64_t ws_floats, hos_stream_t stream);
 
-/* Thin layers over very many rows with the weight slice of every wave resident in registers (hos_thin.hip): N, K <= 256.
+/* Thin layers over very many rows with the weight slice of every wave resident in registers (hos_thin.hip): N, K <= 256
+ * (forward: K <= 320, the folded skip layer below).
  *   hos_thin_linear_fwd  : Y [M,N] = epi(X[:, :K] . W[:N, :K]^T + bias), epilogue HOS_EPI_NONE / HOS_EPI_RELU (fp16 hi/lo x3)
  *   hos_thin_linear_dgrad: dX [M,K] = (dY[:, :Npad] . W[:Npad, :K]) * [mask > 0]  (bf16 hi/lo x3; mask NULL: none); W and mask
  *                          may start at any column of their matrices (4-byte alignment: the h part of the skip layer's concat row
@@ -152,6 +153,23 @@ int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int ldw, const 
                         int M, int N, int K, int epilogue, void* relu_bits, hos_stream_t stream);
 int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad, const float* mask, int ldmask,
                           const void* mask_bits, float* dX, int lddx, int M, int K, hos_stream_t stream);
+
+/* CanonicalMLP with the state embedding folded into biases.  The reference concatenates ONE state vector per call to every
+ * point's Fourier features (core/nets/human_nerf/network.py:177-230 picks it by frame time and expands it over the points), so its columns of the input
+ * layer W0 [n_out, nf + ne] and of the skip layer W5 [n_out, nf + ne + nh] act as per-call biases:
+ *   hos_canonical_fold_pack    W0f [n_out, nfp] = W0[:, :nf] | 0,  b0f = b0 + W0[:, nf:nf+ne] . embed,
+ *                              W5f [n_out, nfp + nh] = W5[:, :nf] | 0 | W5[:, nf+ne:],  b5f likewise  (nfp = nf rounded up to 4):
+ *                              rows of 64 / 320 instead of 128 / 384 columns, the h part 16-byte aligned
+ *   hos_canonical_fold_unfold  gradients of the folded layers (gW0f, db0, gW5f, db5: accumulated by the usual backward launches)
+ *                              += into the reference-shaped gW0 / gb0 / gW5 / gb5, the state columns as db (x) embed, and
+ *                              g_embed [ne] += W0[:, nf:nf+ne]^T db0 + W5[:, nf:nf+ne]^T db5  (fixed-order fp32 sums) */
+int hos_canonical_fold_pack(const float* W0, int ld0, const float* b0, const float* W5, int ld5, const float* b5,
+                            const float* embed, int n_out, int nf, int ne, int nh,
+                            float* W0f, float* b0f, float* W5f, float* b5f, hos_stream_t stream);
+int hos_canonical_fold_unfold(const float* gW0f, const float* db0, const float* gW5f, const float* db5,
+                              const float* W0, int ld0, const float* W5, int ld5, const float* embed,
+                              int n_out, int nf, int ne, int nh,
+                              float* gW0, float* gb0, float* gW5, float* gb5, float* g_embed, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * "Planes" form of the same three contractions: operands are pre-split 16-bit hi/lo values (fp16 on the forward

@@ -189,14 +189,15 @@ def test_folded_chain_backward_equals_the_row_form(net, P, n_live):
 
 # ------------------------------------------------------------------------------------------------ canonical MLP (8 x 256)
 def _cnl_both(net, cnl, state):
-    prev_c, prev_m, prev_2 = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256
+    prev_c, prev_m, prev_2, prev_f = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256, ops.CNL_FOLD
     try:
         ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = True, 1, True
-        raw_c, (E, acts_c, _) = net._canonical_fwd(cnl, state, save=True)
+        ops.CNL_FOLD = False                     # the row form [fourier | state] on both sides (the folded form: tests below)
+        raw_c, (E, acts_c, _, _) = net._canonical_fwd(cnl, state, save=True)
         ops.MLP_CHAIN = False
-        raw_l, (_, acts_l, _) = net._canonical_fwd(cnl, state, save=True)
+        raw_l, (_, acts_l, _, _) = net._canonical_fwd(cnl, state, save=True)
     finally:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = prev_c, prev_m, prev_2
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256, ops.CNL_FOLD = prev_c, prev_m, prev_2, prev_f
     return raw_c, acts_c, raw_l, acts_l, E
 
 
@@ -244,3 +245,148 @@ def test_canonical_chain_vs_reference_fixture(net):
     want = torch.from_numpy(hp["cnl_raw"])
     want = torch.cat([torch.sigmoid(want[:, :3]), torch.relu(want[:, 3:])], -1)
     assert float((raw.cpu() - want).abs().max()) < 5e-5          # the bound tests/test_gpu_human.py uses for the layer-by-layer path
+
+
+# ------------------------------------------------------------------------------------------------ canonical MLP, folded state embedding
+def _cnl_ref64(net, cnl, state, g=None):
+    """float64 autograd of CanonicalMLP on [fourier(cnl) | state embedding] (mlp_rgb_sigma.py:49-58 + N:539-540)."""
+    sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in net.named_parameters()
+          if k.startswith("cnl_mlp.") or k == f"human_stateembeds.{state}"}
+    x = cnl.double().clone().requires_grad_(True)
+    freqs = 2.0 ** torch.arange(10, dtype=torch.float64, device=DEV)
+    ang = x[:, None, :] * freqs[None, :, None]
+    emb = torch.cat([x, torch.cat([torch.sin(ang), torch.cos(ang)], -1).reshape(x.shape[0], 60),
+                     sd[f"human_stateembeds.{state}"][None].expand(x.shape[0], -1)], 1)
+    names = sorted({k.rsplit(".", 1)[0] for k in sd if k.startswith("cnl_mlp.pts_linears")}, key=lambda s_: int(s_.split(".")[-1]))
+    h = emb
+    for i, nm in enumerate(names):
+        if i == 5:
+            h = torch.cat([emb, h], 1)
+        h = torch.relu(h @ sd[nm + ".weight"].T + sd[nm + ".bias"])
+    out_name = [k for k in sd if k.startswith("cnl_mlp.") and "pts_linears" not in k and k.endswith(".weight")]
+    assert len(out_name) == 1, out_name
+    o = h @ sd[out_name[0]].T + sd[out_name[0][:-6] + "bias"]
+    raw = torch.cat([torch.sigmoid(o[:, :3]), torch.relu(o[:, 3:])], 1)
+    if g is not None:
+        raw.backward(g.double())
+    return raw.detach(), x.grad, sd
+
+
+@pytest.mark.parametrize("P", [16384, 20000 + 13, 65536])
+@pytest.mark.parametrize("state", [0, 1])
+def test_folded_canonical_forward_equals_the_row_form(net, P, state):
+    """The state embedding as a per-call bias of the input layer and the skip layer (64 / 320-column rows, the skip layer on the
+    20-step thin kernel) against the row form ([fourier | state] rows, 384-wide skip layer on the tiled GEMM) and float64."""
+    gen = torch.Generator().manual_seed(P + state)
+    cnl = (torch.rand(P, 3, generator=gen) * 2 - 1).to(DEV)
+    prev = ops.CNL_FOLD
+    try:
+        with torch.no_grad():
+            ops.CNL_FOLD = True
+            raw_f, (E_f, acts_f, bits_f, fold) = net._canonical_fwd(cnl, state, save=True)
+            ops.CNL_FOLD = False
+            raw_r, (E_r, acts_r, bits_r, none) = net._canonical_fwd(cnl, state, save=True)
+    finally:
+        ops.CNL_FOLD = prev
+    assert fold is not None and none is None and E_f.shape[1] == 64 and E_r.shape[1] == 128 and acts_f[4].shape[1] == 320
+    assert torch.equal(E_f[:, :63], E_r[:, :63]) and bool((E_f[:, 63] == 0).all())
+    assert torch.equal(acts_f[4][:, :63], acts_r[4][:, :63]) and bool((acts_f[4][:, 63] == 0).all())
+    assert bits_f[5] is not None and bits_r[5] is None          # the folded skip layer runs on the thin kernel and writes its mask bits
+    ref, _, _ = _cnl_ref64(net, cnl, state)
+    for l in range(8):
+        a_f = acts_f[l][:, 64:] if l == 4 else acts_f[l]
+        a_r = acts_r[l][:, 127:383] if l == 4 else acts_r[l]
+        assert float((a_f - a_r).abs().max()) < 3e-6 * max(1.0, float(a_r.abs().max())), l
+    rs = max(1.0, float(ref.abs().max()))
+    e_f, e_r = float((raw_f.double() - ref).abs().max()), float((raw_r.double() - ref).abs().max())
+    assert e_f < 3e-6 * rs and e_f < 2.0 * e_r + 1e-7 * rs, (e_f, e_r)
+
+
+@pytest.mark.parametrize("state", [0, 1])
+def test_folded_canonical_backward_equals_the_row_form(net, state):
+    """The backward pass of both forms on the SAME saved activations and ReLU masks (the folded form's rows are cut out of the row
+    form's buffers, so no pre-activation within rounding of 0 can take different branches in the two): d loss / d points, every
+    cnl_mlp gradient and the state embedding's.  The folded layers get their weight gradient in parts -- Fourier columns from the
+    GEMM over the 64-column rows, state columns as bias-gradient (x) embedding, h columns from the aligned window."""
+    P = 20000 + 13
+    gen = torch.Generator().manual_seed(77 + state)
+    cnl = (torch.rand(P, 3, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn(P, 4, generator=gen).to(DEV)
+    prev = ops.CNL_FOLD
+    res = {}
+    try:
+        with torch.no_grad():
+            ops.CNL_FOLD = False
+            raw, (E_r, acts_r, bits_r, _) = net._canonical_fwd(cnl, state, save=True)
+            ops.CNL_FOLD = True
+            _, (_, _, _, fold) = net._canonical_fwd(cnl, state, save=True)           # the packed weights of the folded layers
+            z = torch.zeros(P, 1, device=DEV)
+            E_f = torch.cat([E_r[:, :63], z], 1).contiguous()
+            acts_f = list(acts_r)
+            acts_f[4] = torch.cat([E_r[:, :63], z, acts_r[4][:, 127:383]], 1).contiguous()
+            for f, saved in ((False, (E_r, acts_r, bits_r, None)), (True, (E_f, acts_f, bits_r, fold))):
+                net.zero_grad()
+                g_cnl = net._canonical_bwd(saved, cnl, raw, g, state)
+                res[f] = (g_cnl.clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()
+                                          if k.startswith("cnl_mlp.") or k.startswith("human_stateembeds.")})
+    finally:
+        ops.CNL_FOLD = prev
+        net.zero_grad()
+    _, gx64, sd = _cnl_ref64(net, cnl, state, g)
+    gs = float(gx64.abs().max())
+    assert float((res[True][0] - res[False][0]).abs().max()) < 2e-5 * gs
+    row_err = (res[True][0].double() - gx64).abs().max(1).values
+    n_bad = int((row_err > 5e-5 * gs).sum())                    # rows where fp32 and float64 disagree about a ReLU branch
+    assert n_bad <= 16 and float(row_err.max()) < 5e-2 * gs, (n_bad, float(row_err.max()))
+    for k in res[True][1]:                                      # the embeddings of the other states receive nothing
+        if k.startswith("human_stateembeds.") and k != f"human_stateembeds.{state}":
+            assert float(res[True][1][k].abs().max()) == 0.0
+    assert len(sd) == 19
+    for k, t in sd.items():
+        ref = t.grad
+        scale = float(ref.abs().max()) + 1e-30
+        e_fold = float((res[True][1][k].double() - ref).abs().max()) / scale
+        e_rows = float((res[False][1][k].double() - ref).abs().max()) / scale
+        d_fr = float((res[True][1][k] - res[False][1][k]).abs().max()) / scale
+        assert d_fr < 1e-4 and e_fold < 1.5 * e_rows + 1e-4, (k, e_fold, e_rows, d_fr)
+
+
+@pytest.mark.parametrize("state", [0, 1])
+def test_folded_canonical_autograd_end_to_end(net, state):
+    """`_CanonicalFn` through both forms, each on its own forward: the two evaluations round differently, so a sample whose
+    pre-activation lies within rounding of 0 may take the other ReLU branch in one of them (one such row moves a gradient by
+    ~1 / sqrt(P) of its largest element when the upstream gradients are random) -- the bound is that, on top of the row form's
+    own distance from float64; direction cosines stay at 1."""
+    from hosnerf_amd.human_nerf import _CanonicalFn
+    P = 20000 + 13
+    gen = torch.Generator().manual_seed(77 + state)
+    cnl = (torch.rand(P, 3, generator=gen) * 2 - 1).to(DEV)
+    g = torch.randn(P, 4, generator=gen).to(DEV)
+    res = {}
+    prev = ops.CNL_FOLD
+    try:
+        for f in (True, False):
+            ops.CNL_FOLD = f
+            net.zero_grad()
+            xx = cnl.clone().requires_grad_(True)
+            raw = _CanonicalFn.apply(torch.zeros((), device=DEV, requires_grad=True), net, xx, state)
+            raw.backward(g)
+            res[f] = (xx.grad.clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters()
+                                        if k.startswith("cnl_mlp.") or k == f"human_stateembeds.{state}"})
+    finally:
+        ops.CNL_FOLD = prev
+        net.zero_grad()
+    _, gx64, sd = _cnl_ref64(net, cnl, state, g)
+    gs = float(gx64.abs().max())
+    for f in (True, False):
+        row_err = (res[f][0].double() - gx64).abs().max(1).values
+        n_bad = int((row_err > 5e-5 * gs).sum())
+        assert n_bad <= 16 and float(row_err.max()) < 5e-2 * gs, (f, n_bad, float(row_err.max()))
+    for k, t in sd.items():
+        ref = t.grad.reshape(-1)
+        scale = float(ref.abs().max()) + 1e-30
+        a = res[True][1][k].double().reshape(-1)
+        e_fold = float((a - ref).abs().max()) / scale
+        e_rows = float((res[False][1][k].double().reshape(-1) - ref).abs().max()) / scale
+        cos = float((a @ ref) / (a.norm() * ref.norm() + 1e-30))
+        assert cos > 0.99999 and e_fold < 3.0 * e_rows + 3.0 / P ** 0.5, (k, e_fold, e_rows, cos)
