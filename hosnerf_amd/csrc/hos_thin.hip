@@ -14,8 +14,12 @@
 //   roofline: HBM, 8 B (FWD) / 12 B (DGRAD) per row and column.
 // Reference: CanonicalMLP.forward, core/nets/human_nerf/canonical_mlps/mlp_rgb_sigma.py:49-58, and its autograd.
 #include "hos_gemm_common.h"
+#include <cstdlib>
 #include <type_traits>
 
+#ifndef HOS_THIN_PF2_MAXKS
+#define HOS_THIN_PF2_MAXKS 16        // fast forward kernel: two tiles of register prefetch up to this many reduction steps
+#endif
 #ifndef HOS_THIN_R_FWD
 #define HOS_THIN_R_FWD 32          // rows per forward tile (64 measured 3-5 % slower once the epilogue stopped loading the bias)
 #endif
@@ -53,6 +57,20 @@ struct ThinArgs {
 };
 
 constexpr int TH_NT = 512;
+// Row padding of the (hi, lo) planes in LDS.  A fragment read is ds_read_b128 at row (lane & 31), 16-byte piece 2 s + (lane >> 5);
+// gfx950 serves it in four groups of 16 lanes ({0-3, 12-15, 20-27}, ...; MI355X_MICROARCH.md, LDS) over 64 banks.  With a pitch
+// of 16 x (odd) bytes the 16 lanes of a group sit in 16 different 16-byte slots (conflict free); the round-2 padding of 32 B
+// (slot = 2 row mod 16) makes every read a 2-way conflict.  Measured at [262144, 256, 256]: DGRAD 203 -> 201 us (164 -> 160 with
+// mask bits) with 16 B; the forward kernels were FASTER with 32 B (138 vs 149 us: they are bound by MFMA + VALU issue of the
+// SIMD's two waves, not by LDS cycles, and the staging writes of the next tile interleave differently) -- so each keeps its own.
+#ifndef HOS_THIN_PAD_DGRAD
+#define HOS_THIN_PAD_DGRAD 16
+#endif
+#ifndef HOS_THIN_PAD_FWD
+#define HOS_THIN_PAD_FWD 32
+#endif
+constexpr int TH_PAD_FWD = HOS_THIN_PAD_FWD;
+template <bool DGRAD> constexpr int th_pad() { return DGRAD ? HOS_THIN_PAD_DGRAD : HOS_THIN_PAD_FWD; }
 constexpr int TH_MP = 264;     // LDS pitch of a mask row: 256 columns + the 16-byte group a window at an unaligned column spills into
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -64,7 +82,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
     typedef typename V8<E>::q e4;
     constexpr int R = DGRAD ? 32 : HOS_THIN_R_FWD;
     constexpr int KD = KS * 16;
-    constexpr int P = KD * 2 + 32;                       // LDS row pitch of one plane (bytes): +32 B = 8 banks per row
+    constexpr int P = KD * 2 + th_pad<DGRAD>();          // LDS row pitch of one plane (bytes), see th_pad
     constexpr int PLANE = R * P, BUF = 2 * PLANE;        // hi, lo
     constexpr int MSK = DGRAD ? R * TH_MP : 0;           // mask bytes [R][TH_MP] per buffer
     constexpr int AU = R * (KD / 4) / TH_NT;             // float4 units of the A tile per thread
@@ -288,10 +306,198 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 #undef TH_STAMP
 }
 
+// ---- FWD fast path: whole tiles only (M % 32 == 0, K == 16 KS, N == 256, 16-byte aligned rows of C).
+// The generic kernel above is LATENCY-bound (HOS_TH_TRACE: per 32-row tile a wave computes for ~2.9 k cycles and waits ~4.4 k --
+// 2.0 k at the `vmcnt(0)` in front of the staging and 2.4 k at the barrier): every global load and store of its loop is
+// predicated, so the compiler has no lower bound on how many younger operations follow a prefetch and must wait for ALL of
+// them (vmcnt retires in order), i.e. also for the stores just issued and for any deeper prefetch.  One tile of loads plus one
+// tile of stores in flight per CU is ~1/3 of the bandwidth-delay product, hence 3.3-3.8 TB/s.  Here nothing in the loop is
+// conditional: loads are clamped instead of predicated, every tile issues exactly 4 row stores (+1 bit-mask store) per lane,
+// so the compiler's own counter can wait for the prefetched set alone (`vmcnt(N > 0)`) with TWO further tiles and both
+// epilogues' stores still in flight; the barrier is LDS-only (no fence); the quad transpose of the epilogue uses DPP
+// (v_mov_b32_dpp quad_perm) instead of 16 ds_bpermute per tile; the range flag is one atomic per wave at the end.
+__device__ __forceinline__ float dpp_quad_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+}
+
+template <int KS, bool BITS>
+__global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs a) {
+    typedef _Float16 E;
+    typedef typename V8<E>::t e8;
+    typedef typename V8<E>::q e4;
+    constexpr int R = 32;
+    constexpr int KD = KS * 16;
+    constexpr int P = KD * 2 + TH_PAD_FWD;
+    constexpr int PLANE = R * P, BUF = 2 * PLANE;
+    constexpr int AU = R * (KD / 4) / TH_NT;             // float4 units of a tile per thread
+    constexpr bool PF2 = KS <= HOS_THIN_PF2_MAXKS;       // two tiles of register prefetch (20 steps: the registers hold weights)
+    constexpr int PFD = PF2 ? 3 : 2;
+    static_assert(AU >= 1 && R * (KD / 4) % TH_NT == 0, "tile does not divide over 512 threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_th[];
+    char* const buf0 = smem_th;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int col0 = wave * 32;
+
+    e8 bh[KS], bl[KS];
+    {
+        const float* wrow = a.W + (size_t)(col0 + l31) * a.ldw + 8 * lhi;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 u = ld4(wrow + 16 * s), v = ld4(wrow + 16 * s + 4);
+            const float w[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { E h, l; split_pair<E>(w[q], h, l); bh[s][q] = h; bl[s][q] = l; }
+        }
+    }
+    const int q4 = l31 & 3, colb = col0 + (l31 & ~3);
+    const float4 bias4 = a.bias != nullptr ? ld4(a.bias + colb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool relu = a.epi == HOS_EPI_RELU;
+
+    const int ntiles = a.M / R;
+    const int G = gridDim.x;
+    float4 ra[AU], rb[PF2 ? AU : 1];
+    // this thread's float4 units of a tile: unit u = t + 512 i -> (row, 16-byte column group)
+    auto gload = [&](float4 (&r)[AU], int tile) {
+        tile = tile < ntiles ? tile : ntiles - 1;        // clamped, never predicated (a tile past the end is loaded, not staged)
+#ifdef HOS_EXP_SAMEA       // timing experiment: every tile is read from the workgroup's FIRST tile (cache hits; results invalid)
+        tile = blockIdx.x;
+#endif
+        const float* base = a.A + (size_t)tile * R * a.lda;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            r[i] = ld4(base + (size_t)row * a.lda + c4 * 4);
+        }
+    };
+    auto sstore = [&](const float4 (&r)[AU], int b) {
+        char* const hi = buf0 + b * BUF;
+        char* const lo = hi + PLANE;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            e4 h, l;
+            const float xs[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { E hh, ll; split_pair<E>(xs[q], hh, ll); h[q] = hh; l[q] = ll; }
+            *reinterpret_cast<e4*>(hi + row * P + c4 * 8) = h;
+            *reinterpret_cast<e4*>(lo + row * P + c4 * 8) = l;
+        }
+    };
+
+    int tile = blockIdx.x;                               // grid <= ntiles
+    gload(ra, tile);
+    sstore(ra, 0);
+    gload(ra, tile + G);
+    if constexpr (PF2) gload(rb, tile + 2 * G);
+    __syncthreads();
+    bool big = false;
+    // one tile: MFMAs on buffer b; `rcur` (the tile one grid stride ahead) is staged into the other buffer and refilled with the
+    // tile PFD strides ahead; epilogue.  `more`: a further tile follows (compile-time in the loop, so that no load or store of
+    // the steady state sits behind a branch)
+    auto body = [&](float4 (&rcur)[AU], const int tile, const int b, const bool more) {
+        const char* hi = buf0 + b * BUF + l31 * P + lhi * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const e8 ah = *reinterpret_cast<const e8*>(hi + s * 32);
+            const e8 al = *reinterpret_cast<const e8*>(hi + PLANE + s * 32);
+            acc = mfma_e(al, bh[s], acc);
+            acc = mfma_e(ah, bl[s], acc);
+            acc = mfma_e(ah, bh[s], acc);
+        }
+        if (more) sstore(rcur, b ^ 1);                  // the wait for `rcur` sits here: vmcnt(number of younger operations)
+        gload(rcur, tile + PFD * G);
+        // epilogue: bias, ReLU bits, ReLU, 4 x 16-byte stores -- unconditional
+        uint32_t rbits = 0;
+        float* crow = a.C + (size_t)(tile * R + q4 + 4 * lhi) * a.ldc + colb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+            {   // 4x4 transpose inside the quad (as gemm_epilogue_tile): afterwards (v0..v3) = row q4, columns colb .. colb+3
+                const float s0 = (q4 & 1) ? v0 : v1, s1 = (q4 & 1) ? v2 : v3;
+                const float r0 = dpp_quad_xor1(s0), r1 = dpp_quad_xor1(s1);
+                if (q4 & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+                const float t0 = (q4 & 2) ? v0 : v2, t1 = (q4 & 2) ? v1 : v3;
+                const float u0 = dpp_quad_xor2(t0), u1 = dpp_quad_xor2(t1);
+                if (q4 & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+            }
+            float v[4] = {v0 + bias4.x, v1 + bias4.y, v2 + bias4.z, v3 + bias4.w};
+            if constexpr (BITS) {        // four bits per row group, an independent chain each (bit 15 - (4 g + k) = element k of group g)
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m = __builtin_amdgcn_alignbit(m, __float_as_uint(0.f - v[k]), 31);
+                rbits |= m << (12 - 4 * g);
+            }
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            big |= fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT;
+#ifdef HOS_EXP_NOSTORE     // timing experiment: results are written to the workgroup's first tile only (cache hits; results invalid)
+            *reinterpret_cast<float4*>(a.C + (size_t)(blockIdx.x * R + q4 + 4 * lhi + 8 * g) * a.ldc + colb) = make_float4(v[0], v[1], v[2], v[3]);
+#else
+            *reinterpret_cast<float4*>(crow + (size_t)(8 * g) * a.ldc) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
+        }
+        if constexpr (BITS) {
+            // two lanes' 16-bit masks as ONE dword store by the even lane (same bytes in memory: bits[t] | bits[t + 1] << 16)
+            const uint32_t odd = (uint32_t)__builtin_amdgcn_mov_dpp((int)rbits, 0xB1, 0xF, 0xF, true);
+            if ((lane & 1) == 0) reinterpret_cast<uint32_t*>(a.bits)[((size_t)tile * TH_NT + t) >> 1] = (rbits & 0xffffu) | (odd << 16);
+        }
+        // the other buffer is complete (this wave's LDS writes have landed at lgkmcnt(0)), this one is free for the tile after
+        // next; NOT __syncthreads(): its fence is vmcnt(0), i.e. a wait for the loads and stores just issued
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // The first round is peeled and the loop takes whole pairs (one latch, no exit between the halves), so that the loop is
+    // entered with the same pending operations its back edge carries ([loads of one set][stores][loads of the other][stores]):
+    // merged with a state that has nothing pending the compiler's counter keeps only the operations of the current round and
+    // waits for the previous round's prefetch again.
+    int b = 0;
+    if constexpr (PF2) {
+        body(ra, tile, b, tile + G < ntiles);
+        tile += G; b ^= 1;
+        if (tile < ntiles) {
+            body(rb, tile, b, tile + G < ntiles);
+            tile += G; b ^= 1;
+            while (tile + G < ntiles) {
+                body(ra, tile, b, true);
+                body(rb, tile + G, b ^ 1, tile + 2 * G < ntiles);
+                tile += 2 * G;
+            }
+            if (tile < ntiles) body(ra, tile, b, false);
+        }
+    } else {
+        body(ra, tile, b, tile + G < ntiles);
+        tile += G; b ^= 1;
+        for (; tile < ntiles; tile += G, b ^= 1) body(ra, tile, b, tile + G < ntiles);
+    }
+    if (a.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
+}
+
+template <int KS, bool BITS>
+int launch_thin_fast(const ThinArgs& a, hipStream_t stream) {
+    constexpr size_t smem = 2 * 2 * (size_t)32 * (KS * 32 + TH_PAD_FWD);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_fast_kernel<KS, BITS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntiles = a.M / 32;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((thin_fwd_fast_kernel<KS, BITS>), dim3(grid), dim3(TH_NT), smem, stream, a);
+    return hos_launch_status();
+}
+
 template <int KS, bool DGRAD>
 int launch_thin(const ThinArgs& a, hipStream_t stream) {
     constexpr int R = DGRAD ? 32 : HOS_THIN_R_FWD;
-    constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + 32) + (DGRAD ? 2 * (size_t)R * TH_MP : 0);
+    constexpr size_t smem = 2 * 2 * (size_t)R * (KS * 32 + th_pad<DGRAD>()) + (DGRAD ? 2 * (size_t)R * TH_MP : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_gemm_kernel<KS, DGRAD>),
@@ -394,6 +600,20 @@ extern "C" int hos_thin_linear_fwd(const float* X, int ldx, const float* W, int 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // reduction steps held in registers: 4 (the folded canonical input layer, 64 columns), 8, 16, 20 (the folded skip layer:
     // [fourier 64 | h 256]; 250 VGPRs -- 24 steps for the reference-shaped 384-wide concat row do not fit two waves per SIMD)
+    // whole tiles of the shapes the canonical MLP runs (256 outputs; 64 / 256 / 320 inputs): the unpredicated kernel; a ragged
+    // tail of M % 32 rows goes through the generic one (HOS_THIN_FAST=0: everything does)
+    static const bool fast_on = !(getenv("HOS_THIN_FAST") && atoi(getenv("HOS_THIN_FAST")) == 0);
+    if (fast_on && N == 256 && M >= 32 && (K == 64 || K == 256 || K == 320) && !(ldy & 3) && !((uintptr_t)Y & 15u) &&
+        (!bias || !((uintptr_t)bias & 15u)) && !((uintptr_t)relu_bits & 3u)) {
+        ThinArgs f = a;
+        f.M = M & ~31;
+        int rc;
+        if (relu_bits) rc = K == 64 ? launch_thin_fast<4, true>(f, s) : (K == 256 ? launch_thin_fast<16, true>(f, s) : launch_thin_fast<20, true>(f, s));
+        else rc = K == 64 ? launch_thin_fast<4, false>(f, s) : (K == 256 ? launch_thin_fast<16, false>(f, s) : launch_thin_fast<20, false>(f, s));
+        if (rc != 0 || f.M == M) return rc;
+        a.A += (size_t)f.M * ldx; a.C += (size_t)f.M * ldy; a.M = M - f.M;
+        if (a.bits) a.bits += (size_t)(f.M / 32) * TH_NT;
+    }
     if (K <= 64) return launch_thin<4, false>(a, s);
     if (K <= 128) return launch_thin<8, false>(a, s);
     return K <= 256 ? launch_thin<16, false>(a, s) : launch_thin<20, false>(a, s);

@@ -8,7 +8,7 @@ D=build/variants/$NAME; mkdir -p $D
 for f in hosnerf_amd/csrc/*.hip; do
   o=$D/$(basename ${f%.hip}).o
   if [ "$(basename $f)" = "${VARIANT_SRC:-hos_gemmp.hip}" ] || [ ! -f $o ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result "$@" -c $f -o $o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result "$@" -c $f -o $o &
   fi
 done
 wait

@@ -432,15 +432,20 @@ def test_linear_wgrad_tr(dev, M, N, K, wcol0, ldw):
     assert bool((db.cpu()[N:] == 0.25).all())
 
 
-@pytest.mark.parametrize("M,N,K,relu,col0", [(20000, 256, 256, True, 0), (16390, 256, 256, True, 127), (33001, 200, 132, False, 0)])
+@pytest.mark.parametrize("M,N,K,relu,col0", [(20000, 256, 256, True, 0), (16390, 256, 256, True, 127), (33001, 200, 132, False, 0),
+                                             # the unpredicated whole-tile kernel (+ the generic one for a ragged tail): K = 64 / 256 /
+                                             # 320 with 256 outputs at a 16-byte aligned column
+                                             (16384, 256, 64, True, 0), (16421, 256, 64, False, 0), (16421, 256, 256, True, 0),
+                                             (65536 + 31, 256, 256, True, 64), (16384 + 32 * 5, 256, 320, True, 0), (20011, 256, 320, True, 64)])
 def test_thin_linear_fwd(dev, M, N, K, relu, col0):
-    """hos_thin_linear_fwd (the route ops.linear_fwd takes for 128 < K <= 256, N <= 256 and many rows) against fp64;
-    col0 = 127 is the canonical MLP's skip layer writing into the concat buffer at an unaligned column."""
+    """hos_thin_linear_fwd (the route ops.linear_fwd takes for K <= 320, 128 < N <= 256 and many rows) against fp64;
+    col0 = 127 is the row form of the canonical MLP's skip layer writing into the concat buffer at an unaligned column."""
     from hosnerf_amd import ops
     ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
     g = torch.Generator().manual_seed(M + N)
-    X = torch.relu(torch.randn(M, 256, generator=g))
-    W = torch.randn(256, 256, generator=g) / 16
+    KW = max(256, K)
+    X = torch.relu(torch.randn(M, KW, generator=g))
+    W = torch.randn(256, KW, generator=g) / 16
     bias = torch.randn(256, generator=g) * 0.1
     out = torch.full((M, col0 + 256), float("nan"), device=dev)
     ev = ops.KernelEvents()
@@ -487,7 +492,7 @@ def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     assert bool(torch.isnan(out[:, K:]).all())
 
 
-@pytest.mark.parametrize("M,N,col0", [(20000, 256, 0), (16421, 256, 127), (16500, 200, 0)])
+@pytest.mark.parametrize("M,N,col0", [(20000, 256, 0), (16421, 256, 127), (16500, 200, 0), (16421, 256, 0), (16421, 256, 64), (65536, 256, 64)])
 def test_thin_relu_bits_roundtrip(dev, M, N, col0):
     """linear_fwd(relu_bits=...) -> linear_dgrad(mask_bits=...) masks exactly like the fp32 activations do, also when the
     forward output lands at an unaligned column of a wider row (the skip concat) and with a ragged last tile / column count."""
@@ -497,7 +502,7 @@ def test_thin_relu_bits_roundtrip(dev, M, N, col0):
     X = torch.randn(M, 256, generator=g).to(dev)
     W = (torch.randn(256, 256, generator=g) / 16).to(dev)
     b = (torch.randn(256, generator=g) * 0.1).to(dev)
-    ld = 384 if col0 else 256
+    ld = 384 if col0 else 256              # (col0 = 64: the folded concat row, whole tiles on the unpredicated kernel + ragged tail)
     Y = torch.full((M, ld), float("nan"), device=dev)
     bits = ops.thin_relu_bits(M, dev)
     ops.linear_fwd(X, 256, W, b, N, Y, ops.EPI_RELU, out_col0=col0, relu_bits=bits)
