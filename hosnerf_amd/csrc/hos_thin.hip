@@ -478,6 +478,140 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs 
     if (a.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
 }
 
+// ---- DGRAD fast path, same recipe: dX[M, 256] = (dY[M, 256] . W[256, w-window of 256 columns]) * [bit mask], whole tiles only.
+// The ReLU mask comes as the bit mask of the forward launch (or none); 2 bytes per lane travel with each tile's prefetch.
+template <bool MASK>
+__global__ __launch_bounds__(TH_NT, 1) void thin_dgrad_fast_kernel(const ThinArgs a) {
+    typedef __bf16 E;
+    typedef typename V8<E>::t e8;
+    typedef typename V8<E>::q e4;
+    constexpr int KS = 16, R = 32;
+    constexpr int KD = KS * 16;
+    constexpr int P = KD * 2 + th_pad<true>();
+    constexpr int PLANE = R * P, BUF = 2 * PLANE;
+    constexpr int AU = R * (KD / 4) / TH_NT;
+    constexpr int PFD = 3;                               // two tiles of register prefetch
+
+    extern __shared__ __attribute__((aligned(16))) char smem_th[];
+    char* const buf0 = smem_th;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int col0 = wave * 32;
+
+    e8 bh[KS], bl[KS];
+    {   // B[k][n] = W[k][col0 + n]: column gather, once per launch
+        const float* wcol = a.W + (size_t)(8 * lhi) * a.ldw + col0 + l31;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { E h, l; split_pair<E>(wcol[(size_t)(16 * s + q) * a.ldw], h, l); bh[s][q] = h; bl[s][q] = l; }
+    }
+    const int q4 = l31 & 3, colb = col0 + (l31 & ~3);
+    const int ntiles = a.M / R;
+    const int G = gridDim.x;
+    float4 ra[AU], rb[AU];
+    uint32_t ba = 0, bb = 0, bits_staged = 0;
+    auto gload = [&](float4 (&r)[AU], uint32_t& rbits, int tile) {
+        tile = tile < ntiles ? tile : ntiles - 1;        // clamped, never predicated
+        const float* base = a.A + (size_t)tile * R * a.lda;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            r[i] = ld4(base + (size_t)row * a.lda + c4 * 4);
+        }
+        if constexpr (MASK) rbits = a.bits[(size_t)tile * TH_NT + t];
+    };
+    auto sstore = [&](const float4 (&r)[AU], const uint32_t rbits, int b) {
+        char* const hi = buf0 + b * BUF;
+        char* const lo = hi + PLANE;
+#pragma unroll
+        for (int i = 0; i < AU; ++i) {
+            const int u = t + TH_NT * i, row = u / (KD / 4), c4 = u % (KD / 4);
+            e4 h, l;
+            const float xs[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { E hh, ll; split_pair<E>(xs[q], hh, ll); h[q] = hh; l[q] = ll; }
+            *reinterpret_cast<e4*>(hi + row * P + c4 * 8) = h;
+            *reinterpret_cast<e4*>(lo + row * P + c4 * 8) = l;
+        }
+        bits_staged = rbits;
+    };
+
+    int tile = blockIdx.x;
+    gload(ra, ba, tile);
+    sstore(ra, ba, 0);
+    gload(ra, ba, tile + G);
+    gload(rb, bb, tile + 2 * G);
+    __syncthreads();
+    auto body = [&](float4 (&rcur)[AU], uint32_t& bcur, const int tile, const int b, const bool more) {
+        const uint32_t bits_cur = bits_staged;           // this tile's ReLU bits (staged together with its operands)
+        const char* hi = buf0 + b * BUF + l31 * P + lhi * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const e8 ah = *reinterpret_cast<const e8*>(hi + s * 32);
+            const e8 al = *reinterpret_cast<const e8*>(hi + PLANE + s * 32);
+            acc = mfma_e(al, bh[s], acc);
+            acc = mfma_e(ah, bl[s], acc);
+            acc = mfma_e(ah, bh[s], acc);
+        }
+        if (more) sstore(rcur, bcur, b ^ 1);
+        gload(rcur, bcur, tile + PFD * G);
+        float* crow = a.C + (size_t)(tile * R + q4 + 4 * lhi) * a.ldc + colb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+            {   // 4x4 transpose inside the quad: afterwards (v0..v3) = row q4 + 8 g + 4 lhi, columns colb .. colb+3
+                const float s0 = (q4 & 1) ? v0 : v1, s1 = (q4 & 1) ? v2 : v3;
+                const float r0 = dpp_quad_xor1(s0), r1 = dpp_quad_xor1(s1);
+                if (q4 & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
+                const float t0 = (q4 & 2) ? v0 : v2, t1 = (q4 & 2) ? v1 : v3;
+                const float u0 = dpp_quad_xor2(t0), u1 = dpp_quad_xor2(t1);
+                if (q4 & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
+            }
+            float v[4] = {v0, v1, v2, v3};
+            if constexpr (MASK) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)       // bit -> all-ones / zero (v_bfe_i32), AND
+                    v[k] = __uint_as_float(__float_as_uint(v[k]) & (uint32_t)__builtin_amdgcn_sbfe((int)bits_cur, 15 - (4 * g + k), 1));
+            }
+            *reinterpret_cast<float4*>(crow + (size_t)(8 * g) * a.ldc) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    int b = 0;
+    body(ra, ba, tile, b, tile + G < ntiles);
+    tile += G; b ^= 1;
+    if (tile < ntiles) {
+        body(rb, bb, tile, b, tile + G < ntiles);
+        tile += G; b ^= 1;
+        while (tile + G < ntiles) {
+            body(ra, ba, tile, b, true);
+            body(rb, bb, tile + G, b ^ 1, tile + 2 * G < ntiles);
+            tile += 2 * G;
+        }
+        if (tile < ntiles) body(ra, ba, tile, b, false);
+    }
+}
+
+template <bool MASK>
+int launch_thin_dgrad_fast(const ThinArgs& a, hipStream_t stream) {
+    constexpr size_t smem = 2 * 2 * (size_t)32 * (16 * 32 + th_pad<true>());
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_dgrad_fast_kernel<MASK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const int ntiles = a.M / 32;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((thin_dgrad_fast_kernel<MASK>), dim3(grid), dim3(TH_NT), smem, stream, a);
+    return hos_launch_status();
+}
+
 template <int KS, bool BITS>
 int launch_thin_fast(const ThinArgs& a, hipStream_t stream) {
     constexpr size_t smem = 2 * 2 * (size_t)32 * (KS * 32 + TH_PAD_FWD);
@@ -634,5 +768,15 @@ extern "C" int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, 
     ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask_bits ? nullptr : mask, ldmask, nullptr,
                static_cast<uint16_t*>(const_cast<void*>(mask_bits))};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // whole tiles of a full 256 x 256 layer with the bit mask (or no mask): the unpredicated kernel; ragged tail: generic
+    static const bool fast_on = !(getenv("HOS_THIN_FAST") && atoi(getenv("HOS_THIN_FAST")) == 0);
+    if (fast_on && K == 256 && Npad == 256 && M >= 32 && (mask_bits || !mask) && !(lddx & 3) && !((uintptr_t)dX & 15u)) {
+        ThinArgs f = a;
+        f.M = M & ~31;
+        const int rc = mask_bits ? launch_thin_dgrad_fast<true>(f, s) : launch_thin_dgrad_fast<false>(f, s);
+        if (rc != 0 || f.M == M) return rc;
+        a.A += (size_t)f.M * lddy; a.C += (size_t)f.M * lddx; a.M = M - f.M;
+        if (a.bits) a.bits += (size_t)(f.M / 32) * TH_NT;
+    }
     return Npad <= 128 ? launch_thin<8, true>(a, s) : launch_thin<16, true>(a, s);
 }

@@ -24,12 +24,14 @@ fns = {
     "wgrad_tr[256,256,262144]": (lambda: ops.linear_wgrad(dY, X, dW, db, 256, 256), M * 256 * 8),
 }
 res = {}
-for name, (fn, nbytes) in fns.items():
-    for _ in range(2): fn()
-    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(reps): fn()
-    e.record(); torch.cuda.synchronize()
-    us = a.elapsed_time(e) * 1e3 / reps
-    res[name] = {"us": us, "algorithmic_bytes": nbytes, "TB/s": nbytes / us / 1e6}
+for rnd in range(3):            # three rounds, best of: the first launches of a process run at a lower clock (order effects of ~20 %)
+    for name, (fn, nbytes) in fns.items():
+        for _ in range(3): fn()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps): fn()
+        e.record(); torch.cuda.synchronize()
+        us = a.elapsed_time(e) * 1e3 / reps
+        if name not in res or us < res[name]["us"]:
+            res[name] = {"us": us, "algorithmic_bytes": nbytes, "TB/s": nbytes / us / 1e6}
 print(json.dumps(res, indent=1))
