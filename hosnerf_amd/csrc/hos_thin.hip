@@ -498,8 +498,11 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_dgrad_fast_kernel(const ThinArg
     const int l31 = lane & 31, lhi = lane >> 5;
     const int col0 = wave * 32;
 
+    // a.N = 32 x (active waves): 256 output columns (a whole layer) or 64 (the Fourier part of an input row: the other six waves
+    // only stage tiles -- they issue no store, so they run their own copy of the loop with its own static operation counts)
+    const bool active = col0 < a.N;
     e8 bh[KS], bl[KS];
-    {   // B[k][n] = W[k][col0 + n]: column gather, once per launch
+    if (active) {   // B[k][n] = W[k][col0 + n]: column gather, once per launch
         const float* wcol = a.W + (size_t)(8 * lhi) * a.ldw + col0 + l31;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -543,23 +546,27 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_dgrad_fast_kernel(const ThinArg
     gload(ra, ba, tile + G);
     gload(rb, bb, tile + 2 * G);
     __syncthreads();
-    auto body = [&](float4 (&rcur)[AU], uint32_t& bcur, const int tile, const int b, const bool more) {
+    auto body = [&](auto act, float4 (&rcur)[AU], uint32_t& bcur, const int tile, const int b, const bool more) {
+        constexpr bool ACT = decltype(act)::value;
         const uint32_t bits_cur = bits_staged;           // this tile's ReLU bits (staged together with its operands)
         const char* hi = buf0 + b * BUF + l31 * P + lhi * 16;
         f32x16 acc;
+        if constexpr (ACT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const e8 ah = *reinterpret_cast<const e8*>(hi + s * 32);
-            const e8 al = *reinterpret_cast<const e8*>(hi + PLANE + s * 32);
-            acc = mfma_e(al, bh[s], acc);
-            acc = mfma_e(ah, bl[s], acc);
-            acc = mfma_e(ah, bh[s], acc);
+            for (int s = 0; s < KS; ++s) {
+                const e8 ah = *reinterpret_cast<const e8*>(hi + s * 32);
+                const e8 al = *reinterpret_cast<const e8*>(hi + PLANE + s * 32);
+                acc = mfma_e(al, bh[s], acc);
+                acc = mfma_e(ah, bl[s], acc);
+                acc = mfma_e(ah, bh[s], acc);
+            }
         }
         if (more) sstore(rcur, bcur, b ^ 1);
         gload(rcur, bcur, tile + PFD * G);
         float* crow = a.C + (size_t)(tile * R + q4 + 4 * lhi) * a.ldc + colb;
+        if constexpr (ACT)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
@@ -581,19 +588,23 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_dgrad_fast_kernel(const ThinArg
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
-    int b = 0;
-    body(ra, ba, tile, b, tile + G < ntiles);
-    tile += G; b ^= 1;
-    if (tile < ntiles) {
-        body(rb, bb, tile, b, tile + G < ntiles);
+    auto run = [&](auto act) {
+        int b = 0;
+        body(act, ra, ba, tile, b, tile + G < ntiles);
         tile += G; b ^= 1;
-        while (tile + G < ntiles) {
-            body(ra, ba, tile, b, true);
-            body(rb, bb, tile + G, b ^ 1, tile + 2 * G < ntiles);
-            tile += 2 * G;
+        if (tile < ntiles) {
+            body(act, rb, bb, tile, b, tile + G < ntiles);
+            tile += G; b ^= 1;
+            while (tile + G < ntiles) {
+                body(act, ra, ba, tile, b, true);
+                body(act, rb, bb, tile + G, b ^ 1, tile + 2 * G < ntiles);
+                tile += 2 * G;
+            }
+            if (tile < ntiles) body(act, ra, ba, tile, b, false);
         }
-        if (tile < ntiles) body(ra, ba, tile, b, false);
-    }
+    };
+    if (active) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 template <bool MASK>
@@ -768,9 +779,10 @@ extern "C" int hos_thin_linear_dgrad(const float* dY, int lddy, const float* W, 
     ThinArgs a{dY, lddy, W, ldw, nullptr, dX, lddx, M, K, Npad, 0, mask_bits ? nullptr : mask, ldmask, nullptr,
                static_cast<uint16_t*>(const_cast<void*>(mask_bits))};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // whole tiles of a full 256 x 256 layer with the bit mask (or no mask): the unpredicated kernel; ragged tail: generic
+    // whole tiles of a full 256 x 256 layer (or its 64-column Fourier window) with the bit mask or no mask: the unpredicated kernel;
+    // ragged tail: generic
     static const bool fast_on = !(getenv("HOS_THIN_FAST") && atoi(getenv("HOS_THIN_FAST")) == 0);
-    if (fast_on && K == 256 && Npad == 256 && M >= 32 && (mask_bits || !mask) && !(lddx & 3) && !((uintptr_t)dX & 15u)) {
+    if (fast_on && (K == 256 || K == 64) && Npad == 256 && M >= 32 && (mask_bits || !mask) && !(lddx & 3) && !((uintptr_t)dX & 15u)) {
         ThinArgs f = a;
         f.M = M & ~31;
         const int rc = mask_bits ? launch_thin_dgrad_fast<true>(f, s) : launch_thin_dgrad_fast<false>(f, s);

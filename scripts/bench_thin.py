@@ -20,6 +20,7 @@ fns = {
     "thin_fwd+relu_bits[262144,256,256]": (lambda: ops.linear_fwd(X, 256, W, b, 256, Y, ops.EPI_RELU, relu_bits=bits), M * 256 * 8 + M * 32),
     "thin_dgrad[262144,256,256]": (lambda: ops.linear_dgrad(dY, W, 256, 256, dX, mask_src=X), M * 256 * 12),
     "thin_dgrad(mask_bits)[262144,256,256]": (lambda: ops.linear_dgrad(dY, W, 256, 256, dX, mask_bits=bits), M * 256 * 8 + M * 32),
+    "thin_dgrad[262144,64,256]": (lambda: ops.linear_dgrad(dY, W, 256, 64, dX, thin=True), M * (256 + 64) * 4),
     "mlp_bwd_fused[262144,128,128]": (lambda: ops.linear_bwd_fused(dY1, X1, W1, dW1, db1, 128, 128, dX1, True), M * 128 * 12),
     "wgrad_tr[256,256,262144]": (lambda: ops.linear_wgrad(dY, X, dW, db, 256, 256), M * 256 * 8),
 }

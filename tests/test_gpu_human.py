@@ -464,7 +464,10 @@ def test_thin_linear_fwd(dev, M, N, K, relu, col0):
 
 
 @pytest.mark.parametrize("M,Npad,K,masked", [(20000, 256, 256, True), (16400, 256, 256, False), (33001, 160, 200, True),
-                                               (16500, 256, 384, False), (16500, 256, 380, True)])
+                                               (16500, 256, 384, False), (16500, 256, 380, True),
+                                               # the unpredicated whole-tile kernel: a whole layer, and the 64-column window of an input
+                                               # row's Fourier part (two computing waves, six that only stage), + ragged tails
+                                               (65536, 256, 256, False), (16421, 256, 256, False), (16448, 256, 64, False), (20011, 256, 64, False)])
 def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     from hosnerf_amd import ops
     ops.set_gemm_mode(ops.GEMM_PLANES)       # the routes under test are taken in the split-precision modes only
@@ -480,7 +483,7 @@ def test_thin_linear_dgrad(dev, M, Npad, K, masked):
     ev = ops.KernelEvents()
     ops.set_kernel_events(ev)
     try:
-        ops.linear_dgrad(dY.to(dev), W.to(dev), Npad, K, out, mask_src=Xact.to(dev) if masked else None)
+        ops.linear_dgrad(dY.to(dev), W.to(dev), Npad, K, out, mask_src=Xact.to(dev) if masked else None, thin=K <= 128)
     finally:
         ops.set_kernel_events(None)
     assert all(k.startswith("thin_dgrad") for k in ev.records), list(ev.records)
