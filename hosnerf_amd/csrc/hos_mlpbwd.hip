@@ -338,6 +338,144 @@ __global__ __launch_bounds__(MB_NT, 1) void mlp_bwd_kernel(MlpBwdArgs a) {
 #undef MB_STAMP
 }
 
+// ---- WGRAD of a 256-wide layer, whole tiles only (M % 32 == 0, N == 256, K == 32 KT, slab workspace): nothing in the loop is
+// predicated, so the compiler can wait for ONE prefetched register set (`vmcnt(8)`) while the other is still travelling.  The
+// generic kernel above refills its single set after the first barrier of a tile and needs it at the top of the next one: the
+// loads have one compute phase (~1.5 us) to cover an HBM round trip of 2-3 us, and the workgroup waits for the difference on
+// every tile (251 us per launch at M = 524 288 = 4.3 TB/s; half of every tile period is that wait).
+template <int KT>
+__global__ __launch_bounds__(MB_NT, 1) void wgrad_tr_fast_kernel(MlpBwdArgs a) {
+    constexpr int NT = 8, N_ = NT * 32, K_ = KT * 32, R = 32;
+    constexpr int PZ = N_ * 2 + 32, PX = K_ * 2 + 32;
+    constexpr int Z_PLANE = R * PZ, X_PLANE = R * PX;
+    constexpr int ZU = R * (N_ / 4) / MB_NT;                                  // float4 units of dZ per thread and tile (4)
+    constexpr int XT = R * (K_ / 4);                                          // float4 units of X per tile
+    constexpr int XU = (XT + MB_NT - 1) / MB_NT;                              // ... per thread (4; K = 64: 1, threads past XT idle)
+    constexpr bool XALL = XT % MB_NT == 0;
+    constexpr int WT = NT * KT, WPW = WT / 8;                                 // WGRAD tiles, per wave (8 or 2)
+    static_assert(WT % 8 == 0 && 8 % KT == 0, "a wave's WGRAD tiles share kt");
+
+    extern __shared__ __attribute__((aligned(16))) char smem_mb[];
+    char* const Zh = smem_mb;
+    char* const Zl = Zh + Z_PLANE;
+    char* const Xh = Zl + Z_PLANE;
+    char* const Xl = Xh + X_PLANE;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tr_g = lane >> 4, tr_p = lane & 15;
+    const int tr_row = 8 * (tr_g >> 1) + (tr_p >> 2);
+    const int tr_col = 16 * (tr_g & 1) + 4 * (tr_p & 3);
+    const bool xthread = XALL || t < XT;
+
+    const int nrb = a.M / R;
+    const int G = gridDim.x;
+    float4 rzA[ZU], rxA[XU], rzB[ZU], rxB[XU];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gload = [&](float4 (&rz)[ZU], float4 (&rx)[XU], int rb) {
+        rb = rb < nrb ? rb : nrb - 1;                                         // clamped, never predicated
+        const float* zb = a.dZ + (size_t)rb * R * a.lddz;
+        const float* xb = a.X + (size_t)rb * R * a.ldx;
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = t + MB_NT * i, row = u / (N_ / 4), c4 = u % (N_ / 4);
+            rz[i] = ldg4(zb + (size_t)row * a.lddz + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = XALL ? t + MB_NT * i : (t < XT ? t : 0), row = u / (K_ / 4), c4 = u % (K_ / 4);
+            rx[i] = ldg4(xb + (size_t)row * a.ldx + c4 * 4);
+        }
+    };
+    auto sstore = [&](const float4 (&rz)[ZU], const float4 (&rx)[XU]) {
+#pragma unroll
+        for (int i = 0; i < ZU; ++i) {
+            const int u = t + MB_NT * i, row = u / (N_ / 4), c4 = u % (N_ / 4);
+            bsum.x += rz[i].x; bsum.y += rz[i].y; bsum.z += rz[i].z; bsum.w += rz[i].w;   // c4 is the same for every i
+            bf16x4 h, l;
+            split4(rz[i], h, l);
+            *reinterpret_cast<bf16x4*>(Zh + row * PZ + c4 * 8) = h;
+            *reinterpret_cast<bf16x4*>(Zl + row * PZ + c4 * 8) = l;
+        }
+        if (xthread) {
+#pragma unroll
+            for (int i = 0; i < XU; ++i) {
+                const int u = t + MB_NT * i, row = u / (K_ / 4), c4 = u % (K_ / 4);
+                bf16x4 h, l;
+                split4(rx[i], h, l);
+                *reinterpret_cast<bf16x4*>(Xh + row * PX + c4 * 8) = h;
+                *reinterpret_cast<bf16x4*>(Xl + row * PX + c4 * 8) = l;
+            }
+        }
+    };
+    f32x16 accW[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[j][r] = 0.f;
+    auto compute = [&]() {      // dW[N_ x K_] += dZ^T[N_ x 32] . X[32 x K_]: tile (nt, kt) = wave + 8 j; a wave's tiles share kt
+        const int kw = wave % KT;
+        const char* xfrag = Xh + tr_row * PX + (kw * 32 + tr_col) * 2;
+#pragma unroll
+        for (int s = 0; s < R / 16; ++s) {
+            const bf16x8 bh = tr_frag2(xfrag + s * 16 * PX, PX);
+            const bf16x8 bl = tr_frag2(xfrag + X_PLANE + s * 16 * PX, PX);
+#pragma unroll
+            for (int j = 0; j < WPW; ++j) {
+                const int ti = wave + 8 * j;
+                const char* zfrag = Zh + tr_row * PZ + ((ti / KT) * 32 + tr_col) * 2;
+                const bf16x8 ah = tr_frag2(zfrag + s * 16 * PZ, PZ);
+                const bf16x8 al = tr_frag2(zfrag + Z_PLANE + s * 16 * PZ, PZ);
+                accW[j] = mma3(ah, al, bh, bl, accW[j]);
+            }
+        }
+    };
+#define WG_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // one tile: the set is staged (the wait for it: vmcnt(loads of the other set)), refilled with the tile two strides ahead,
+    // multiplied.  Two barriers: the planes are single-buffered (2 x 69 KB would fit, but the second buffer bought nothing once
+    // the loads no longer stall the staging).
+    auto step = [&](float4 (&rz)[ZU], float4 (&rx)[XU], const int rb) {
+        sstore(rz, rx);
+        WG_BAR();
+        gload(rz, rx, rb + 2 * G);
+        compute();
+        WG_BAR();
+    };
+    int rb = blockIdx.x;                                                       // grid <= nrb
+    gload(rzA, rxA, rb);
+    gload(rzB, rxB, rb + G);
+    step(rzA, rxA, rb);
+    rb += G;
+    if (rb < nrb) {
+        step(rzB, rxB, rb);
+        rb += G;
+        while (rb + G < nrb) {
+            step(rzA, rxA, rb);
+            step(rzB, rxB, rb + G);
+            rb += 2 * G;
+        }
+        if (rb < nrb) step(rzA, rxA, rb);
+    }
+#undef WG_BAR
+    // ---- dW / db partials of this workgroup -> its slab (summed by the reduce kernel)
+    GemmArgs ew{};
+    ew.C = a.ws + (size_t)blockIdx.x * (N_ * K_ + N_); ew.ldc = K_; ew.M = N_; ew.N = K_; ew.epi = HOS_EPI_NONE;
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int ti = wave + 8 * j;
+        gemm_epilogue_tile<MODE_FWD>(ew, accW[j], (ti / KT) * 32, (ti % KT) * 32, lane);
+    }
+    if (a.db != nullptr) {
+        float4* red = reinterpret_cast<float4*>(Zh);
+        red[t] = bsum;
+        __syncthreads();
+        constexpr int CG = N_ / 4;                                // column groups; thread t owns group t % CG
+        if (t < CG) {
+            float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = t; k < MB_NT; k += CG) { const float4 v = red[k]; sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w; }
+            *reinterpret_cast<float4*>(a.ws + (size_t)blockIdx.x * (N_ * K_ + N_) + N_ * K_ + t * 4) = sacc;
+        }
+    }
+}
+
 // dW[n][k] += sum over slabs g of ws[g][n][k].  Block (x, y): 256 threads x float4 = 1024 consecutive elements, slabs
 // y, y + sy, ... in rounds of eight 16-byte loads issued before the first add (one memory latency per round), then
 // sy-way fp32 atomics into dW.  sy = 2: device-scope fp32 atomics are the bottleneck, not the loads -- the batched
@@ -469,6 +607,36 @@ int launch_mb(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
     return hos_launch_status();
 }
 
+// the unpredicated WGRAD (whole 32-row tiles, N = 256, K = 32 KT, slabs): returns -1 when the call does not qualify
+template <int KT>
+int launch_wgrad_fast(MlpBwdArgs a, size_t ws_floats, hipStream_t stream) {
+    constexpr int N_ = 256, K_ = KT * 32, R = 32, nk = N_ * K_;
+    constexpr size_t smem = 2 * (size_t)R * (N_ * 2 + 32) + 2 * (size_t)R * (K_ * 2 + 32);
+    static const bool on = !(getenv("HOS_WGRAD_FAST") && atoi(getenv("HOS_WGRAD_FAST")) == 0);
+    const int nrb = a.M / R;
+    const int grid = nrb < 256 ? nrb : 256;
+    if (!on || a.M % R != 0 || a.N != N_ || a.K != K_ || a.m_dev != nullptr || a.ws == nullptr || grid < 32 ||
+        ws_floats < (size_t)grid * (nk + N_) || (((uintptr_t)a.ws) & 15u)) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tr_fast_kernel<KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_tr_fast_kernel<KT>), dim3(grid), dim3(MB_NT), smem, stream, a);
+    if (g_defer) {
+        if (g_batch.count == MB_BATCH) { const int rc = flush_reduce_batch(stream); if (rc != 0) return rc; }
+        ReduceJob& J = g_batch.j[g_batch.count];
+        J = ReduceJob{a.ws, a.dW, a.db, grid, N_, K_, nk, a.lddw, a.N, a.K,
+                      g_batch.count ? g_batch.j[g_batch.count - 1].first_block + hos_cdiv(g_batch.j[g_batch.count - 1].nk + g_batch.j[g_batch.count - 1].n_, 1024) : 0};
+        ++g_batch.count;
+    } else {
+        hipLaunchKernelGGL(mlp_bwd_reduce_kernel, dim3(hos_cdiv(nk + N_, 1024), reduce_split()), dim3(256), 0, stream,
+                           a.ws, grid, N_, K_, nk, a.dW, a.lddw, a.db, a.N, a.K);
+    }
+    return hos_launch_status();
+}
+
 // floats of slab workspace launch_mb<NT, KT, DG> uses for M rows (0: it accumulates with atomics)
 template <int NT, int KT, bool DG>
 int64_t ws_floats_mb(int M) {
@@ -510,6 +678,10 @@ extern "C" int hos_linear_wgrad_tr(const float* dZ, int lddz, const float* X, in
     MlpBwdArgs a{dZ, lddz, X, ldx, nullptr, 0, nullptr, 0, dW, lddw, db, M, N, K, 0, ws, 0};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int kt = hos_cdiv(K, 32);
+    if (N == 256 && (K == 256 || K == 64)) {        // the canonical MLP's layers (and the 64-column Fourier rows of its folded input)
+        const int rc = K == 256 ? launch_wgrad_fast<8>(a, (size_t)ws_floats, s) : launch_wgrad_fast<2>(a, (size_t)ws_floats, s);
+        if (rc >= 0) return rc;
+    }
     if (kt <= 4) return launch_mb<8, 4, false>(a, (size_t)ws_floats, s);
     return launch_mb<8, 8, false>(a, (size_t)ws_floats, s);
 }
