@@ -297,9 +297,9 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
             }
         }
         TH_STAMP();
-        // next buffer complete; this one free for the tile after next.  (__syncthreads() is also a workgroup-scope fence
-        // = vmcnt(0); an LDS-only `s_waitcnt lgkmcnt(0); s_barrier` was measured equal here: the waves wait for the
-        // prefetched tile either way.)
+        // next buffer complete; this one free for the tile after next.  (hipcc compiles __syncthreads() to `s_waitcnt
+        // lgkmcnt(0); s_barrier` on this target: waves of a workgroup share the CU, so the fence does not wait for global
+        // memory operations.  What the waves wait for at this barrier is each other: HOS_TH_TRACE.)
         __syncthreads();
     }
     TH_STAMP();
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 // tile of stores in flight per CU is ~1/3 of the bandwidth-delay product, hence 3.3-3.8 TB/s.  Here nothing in the loop is
 // conditional: loads are clamped instead of predicated, every tile issues exactly 4 row stores (+1 bit-mask store) per lane,
 // so the compiler's own counter can wait for the prefetched set alone (`vmcnt(N > 0)`) with TWO further tiles and both
-// epilogues' stores still in flight; the barrier is LDS-only (no fence); the quad transpose of the epilogue uses DPP
+// epilogues' stores still in flight; the barrier is written out as `s_waitcnt lgkmcnt(0); s_barrier`; the quad transpose of the epilogue uses DPP
 // (v_mov_b32_dpp quad_perm) instead of 16 ds_bpermute per tile; the range flag is one atomic per wave at the end.
 __device__ __forceinline__ float dpp_quad_xor1(float x) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
@@ -449,7 +449,8 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs 
             if ((lane & 1) == 0) reinterpret_cast<uint32_t*>(a.bits)[((size_t)tile * TH_NT + t) >> 1] = (rbits & 0xffffu) | (odd << 16);
         }
         // the other buffer is complete (this wave's LDS writes have landed at lgkmcnt(0)), this one is free for the tile after
-        // next; NOT __syncthreads(): its fence is vmcnt(0), i.e. a wait for the loads and stores just issued
+        // next.  (Written out -- it is what __syncthreads() compiles to here -- so that it can never become a wait for the loads
+        // and stores just issued.)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     // The first round is peeled and the loop takes whole pairs (one latch, no exit between the halves), so that the loop is
