@@ -76,7 +76,7 @@ __device__ __forceinline__ f32x16 mfma3(const h8& ah, const h8& al, const h8& bh
 }
 
 __device__ __forceinline__ void split_to(float x, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    hi = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);        // one v_med3 (fminf(fmaxf()) adds a canonicalising v_max)
     lo = (_Float16)(x - (float)hi);
 }
 

@@ -25,7 +25,7 @@ constexpr float HALF_PI = 1.57079637050628662109375f;   // float32(0.5*pi)
 
 // (hi, lo) split of one value for the interleaved-planes layout of hos_gemmp.hip: fp16 hi saturates at +-65504
 template <typename E> __device__ __forceinline__ float hi_clamp(float x) { return x; }
-template <> __device__ __forceinline__ float hi_clamp<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+template <> __device__ __forceinline__ float hi_clamp<_Float16>(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 template <typename E> __device__ __forceinline__ void split_store(unsigned short* __restrict__ P, size_t o, float x) {
     const E h = (E)hi_clamp<E>(x);
     const E l = (E)(x - (float)h);

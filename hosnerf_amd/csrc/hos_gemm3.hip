@@ -47,7 +47,7 @@ __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cas
 
 template <typename E> __device__ __forceinline__ float hi_src(float x) { return x; }
 // fp16 hi part saturates at +-65504 instead of overflowing to inf; the residual then lands in lo (exact up to 131008)
-template <> __device__ __forceinline__ float hi_src<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+template <> __device__ __forceinline__ float hi_src<_Float16>(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 
 template <typename E>
 __device__ __forceinline__ void split4(const float4& v, typename Vec<E>::x4& hi, typename Vec<E>::x4& lo) {

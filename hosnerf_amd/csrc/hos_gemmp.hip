@@ -89,7 +89,7 @@ struct PArgs {
 
 template <typename E> __device__ __forceinline__ uint16_t to_bits(E v) { return __builtin_bit_cast(uint16_t, v); }
 template <typename E> __device__ __forceinline__ float clampE(float x) { return x; }
-template <> __device__ __forceinline__ float clampE<_Float16>(float x) { return fminf(fmaxf(x, -65504.f), 65504.f); }
+template <> __device__ __forceinline__ float clampE<_Float16>(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 
 // (hi, lo) of x packed as lo16 = hi bits, hi16 = lo bits
 template <typename E>
