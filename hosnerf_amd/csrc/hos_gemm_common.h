@@ -53,6 +53,15 @@ __device__ __forceinline__ bool fwd_epilogue_value(const GemmArgs& a, float& v, 
     return true;
 }
 
+// Exchange inside a quad of lanes (lane ^ 1, lane ^ 2) as v_mov_b32_dpp quad_perm -- a VALU move -- instead of __shfl_xor, which
+// hipcc lowers to ds_bpermute_b32: 16 round trips through the LDS crossbar per 32 x 32 tile in the quad transposes below.
+__device__ __forceinline__ float quad_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+}
+
 // Epilogue of one 32x32 accumulator tile.
 // The MFMA C/D layout gives a lane ONE column and 16 rows, i.e. 4-byte stores (16 store instructions of 2x128 B
 // per tile) -- measured at ~1 TB/s, 45 % of the whole forward GEMM.  Each group of four accumulator registers is
@@ -98,10 +107,10 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
             float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
             {   // 4x4 transpose inside the quad: afterwards (v0..v3) = row q, columns colb .. colb+3
                 const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
-                const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                 if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
-                const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
+                const float u0 = quad_xor2(t0), u1 = quad_xor2(t1);
                 if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
             }
             const int row = row0 + q + 8 * g + 4 * lhi;

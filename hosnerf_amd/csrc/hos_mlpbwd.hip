@@ -78,10 +78,10 @@ __device__ __forceinline__ void dgrad_store(const MlpBwdArgs& a, const f32x16& a
         float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
         {
             const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
-            const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+            const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
             if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
             const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
-            const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
+            const float u0 = quad_xor2(t0), u1 = quad_xor2(t1);
             if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
         }
         const int lrow = q + 8 * g + 4 * lhi;                     // row inside the 32-row tile

@@ -267,10 +267,10 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
                         float v0 = acc[rt][4 * g + 0], v1 = acc[rt][4 * g + 1], v2 = acc[rt][4 * g + 2], v3 = acc[rt][4 * g + 3];
                         {
                             const float s0 = (q & 1) ? v0 : v1, s1 = (q & 1) ? v2 : v3;
-                            const float r0 = __shfl_xor(s0, 1, 64), r1 = __shfl_xor(s1, 1, 64);
+                            const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                             if (q & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                             const float t0 = (q & 2) ? v0 : v2, t1 = (q & 2) ? v1 : v3;
-                            const float u0 = __shfl_xor(t0, 2, 64), u1 = __shfl_xor(t1, 2, 64);
+                            const float u0 = quad_xor2(t0), u1 = quad_xor2(t1);
                             if (q & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
                         }
                         const int lrow = q + 8 * g + 4 * lhi, row = row0 + lrow;
@@ -317,13 +317,6 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_gemm_kernel(const ThinArgs a) {
 // so the compiler's own counter can wait for the prefetched set alone (`vmcnt(N > 0)`) with TWO further tiles and both
 // epilogues' stores still in flight; the barrier is written out as `s_waitcnt lgkmcnt(0); s_barrier`; the quad transpose of the epilogue uses DPP
 // (v_mov_b32_dpp quad_perm) instead of 16 ds_bpermute per tile; the range flag is one atomic per wave at the end.
-__device__ __forceinline__ float dpp_quad_xor1(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
-}
-__device__ __forceinline__ float dpp_quad_xor2(float x) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
-}
-
 template <int KS, bool BITS>
 __global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs a) {
     typedef _Float16 E;
@@ -423,10 +416,10 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs 
             float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
             {   // 4x4 transpose inside the quad (as gemm_epilogue_tile): afterwards (v0..v3) = row q4, columns colb .. colb+3
                 const float s0 = (q4 & 1) ? v0 : v1, s1 = (q4 & 1) ? v2 : v3;
-                const float r0 = dpp_quad_xor1(s0), r1 = dpp_quad_xor1(s1);
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                 if (q4 & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 const float t0 = (q4 & 2) ? v0 : v2, t1 = (q4 & 2) ? v1 : v3;
-                const float u0 = dpp_quad_xor2(t0), u1 = dpp_quad_xor2(t1);
+                const float u0 = quad_xor2(t0), u1 = quad_xor2(t1);
                 if (q4 & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
             }
             float v[4] = {v0 + bias4.x, v1 + bias4.y, v2 + bias4.z, v3 + bias4.w};
@@ -574,10 +567,10 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_dgrad_fast_kernel(const ThinArg
             float v0 = acc[4 * g + 0], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
             {   // 4x4 transpose inside the quad: afterwards (v0..v3) = row q4 + 8 g + 4 lhi, columns colb .. colb+3
                 const float s0 = (q4 & 1) ? v0 : v1, s1 = (q4 & 1) ? v2 : v3;
-                const float r0 = dpp_quad_xor1(s0), r1 = dpp_quad_xor1(s1);
+                const float r0 = quad_xor1(s0), r1 = quad_xor1(s1);
                 if (q4 & 1) { v0 = r0; v2 = r1; } else { v1 = r0; v3 = r1; }
                 const float t0 = (q4 & 2) ? v0 : v2, t1 = (q4 & 2) ? v1 : v3;
-                const float u0 = dpp_quad_xor2(t0), u1 = dpp_quad_xor2(t1);
+                const float u0 = quad_xor2(t0), u1 = quad_xor2(t1);
                 if (q4 & 2) { v0 = u0; v1 = u1; } else { v2 = u0; v3 = u1; }
             }
             float v[4] = {v0, v1, v2, v3};
