@@ -632,7 +632,7 @@ static int chain128_launch(const ChainArgs& a, hipStream_t stream) {
     }
     const long ntiles = (a.P + CROWS - 1) / CROWS;
     static int max_grid = 0;
-    if (max_grid == 0) { const char* e = getenv("HOS_CHAIN_GRID"); max_grid = e ? atoi(e) : 512; if (max_grid <= 0) max_grid = 512; }
+    if (max_grid == 0) { const char* e = getenv("HOS_CHAIN_GRID"); max_grid = e ? atoi(e) : 1024; if (max_grid <= 0) max_grid = 1024; }
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     hipLaunchKernelGGL(chain128_kernel<FOLD>, dim3(grid), dim3(CT), smem, stream, a);
     return hos_launch_status();
