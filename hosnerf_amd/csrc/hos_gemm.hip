@@ -320,7 +320,7 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
 
 // C[M, N] = A[M, K] . W[N, K]^T in exact fp32 MFMA for a SMALL output with a LONG reduction (the input gradient of the volume
 // decoder's transposed convolutions: [M <= 4096, N <= 1024] from K = 1 728 .. 32 768, i.e. 8-64 output tiles): the reduction is
-// split over ~512 workgroups that add their partial tiles into the zeroed C with fp32 atomics.  No bias / epilogue.
+// split over ~256 workgroups that add their partial tiles into the zeroed C with fp32 atomics.  No bias / epilogue.
 extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                                      hos_stream_t stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
@@ -331,9 +331,13 @@ extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, in
     a.M = M; a.N = N; a.Mload = M; a.Nload = N;
     a.nk = K / BK; a.red_limit = 0x7fffffff; a.epi = HOS_EPI_NONE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool few = M <= 32;
+    // 32-row tiles up to 64 rows and ~256 workgroups (round 3, scripts/bench_decoder.py: [64,512] from K = 16 384 39 -> 22 us,
+    // [512,256] 71 -> 63 us, [4096,256] from K = 1 728 57 -> 54 us; 128 or 1024 workgroups are 25-50 % slower)
+    static const int few_max = getenv("HOS_SPLITK_FEW_M") ? atoi(getenv("HOS_SPLITK_FEW_M")) : 64;
+    static const int target = getenv("HOS_SPLITK_TARGET") ? atoi(getenv("HOS_SPLITK_TARGET")) : 256;
+    const bool few = M <= few_max;
     a.tiles_m = hos_cdiv(M, few ? 32 : 128); a.tiles_n = hos_cdiv(N, 128);
-    int splits = hos_cdiv(512, a.tiles_m * a.tiles_n);
+    int splits = hos_cdiv(target, a.tiles_m * a.tiles_n);
     if (splits > a.nk / 4) splits = a.nk / 4 > 0 ? a.nk / 4 : 1;          // >= 4 K tiles per split
     a.kt_per_split = hos_cdiv(a.nk, splits);
     splits = hos_cdiv(a.nk, a.kt_per_split);
@@ -364,8 +368,10 @@ extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int l
     // splits the reduction (atomics into a zeroed output: +1 % on a stage-2 step, but the result is no longer
     // bit-reproducible from call to call, so it is off by default).
     static const bool few_rows_split = getenv("HOS_DGRAD_SPLIT") && atoi(getenv("HOS_DGRAD_SPLIT")) == 1;
-    if (M <= 32 && !accumulate && Xact == nullptr && a.nk >= 8) {
-        a.tiles_m = 1; a.tiles_n = hos_cdiv(K, 128);
+    // (up to 64 rows as two 32-row tiles: the decoder's [64, 512] x [512, 16384] layer 46 -> 20 us against one half-empty 128-row tile)
+    static const int few_rows_max = getenv("HOS_FEWROW_M") ? atoi(getenv("HOS_FEWROW_M")) : 64;
+    if (M <= few_rows_max && !accumulate && Xact == nullptr && a.nk >= 8) {
+        a.tiles_m = hos_cdiv(M, 32); a.tiles_n = hos_cdiv(K, 128);
         int splits = 1;
         if (few_rows_split) {
             splits = a.nk / 4 < 4 ? a.nk / 4 : 4;

@@ -505,7 +505,8 @@ class _Deconv3d(torch.autograd.Function):
             call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(Wm), Wm.stride(0), ptr(dx), dx.stride(0), M, Cin, Cout * 64)
         with gemm_mode(GEMM_FP32):
             gW = weight.grad.view(Cin, Cout * 64) if in_place else torch.zeros(Cin, Cout * 64, device=g.device)
-            if M <= 64:      # a few voxels against 33-134 MB of weights: outer-product stream, not a tiled GEMM
+            if M <= 8:       # a few voxels against 33-134 MB of weights: outer-product stream, not a tiled GEMM (at 64 voxels the
+                             # tiled GEMM wins: 28 vs 67 us, scripts/bench_decoder.py)
                 call("hos_outer_accum", ptr(x), x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW), gW.stride(0), M, Cin, Cout * 64)
             else:
                 linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)

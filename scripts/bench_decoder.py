@@ -48,5 +48,6 @@ for n in range(5):
         else:
             t_dw = timeit(lambda: ops.linear_wgrad(x, dycol, gW, None, Cin, Cout * 64))
         t_dwmm = timeit(lambda: gW.addmm_(x.t(), dycol))
-    print(f"L{n} M={M:5d} Cin={Cin:4d} N={Cout*64:6d} {t_f:9.1f} {t_mm:9.1f} {t_c:8.1f} | {t_dp:7.1f} {t_im:7.1f} {t_dx:7.1f} {t_dxmm:7.1f} {t_dw:7.1f} {t_dwmm:7.1f}")
+        t_dwg = timeit(lambda: ops.linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)) if M <= 64 else t_dw      # the tiled GEMM for few rows too
+    print(f"L{n} M={M:5d} Cin={Cin:4d} N={Cout*64:6d} {t_f:9.1f} {t_mm:9.1f} {t_c:8.1f} | {t_dp:7.1f} {t_im:7.1f} {t_dx:7.1f} {t_dxmm:7.1f} {t_dw:7.1f} {t_dwmm:7.1f}  (tiled wgrad {t_dwg:6.1f})")
     D *= 2
