@@ -37,6 +37,19 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     assert lib.hos_linear_fwd(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0.0, 0, 0) == -1       # HOS_E_ARG
     assert lib.hos_resample(0, 0, 64, 8, 64, 0.0, 1.0, 0, 10.0, 0.0, 0, 0, 0.0, 0.1, 1e6, 0, 0, 0, 0) == -1
+    # the round-3 entry points of the folded thin MLPs: null pointers -> HOS_E_ARG, never a launch
+    assert lib.hos_mlp_chain_pack_fold(0, 0, 0, 0, 75, 36, 0, 0, 0, 0) == -1
+    assert lib.hos_mlp_chain_unfold_grad(0, 0, 0, 75, 36, 0, 128, 0, 0) == -1
+    assert lib.hos_canonical_fold_pack(0, 128, 0, 0, 384, 0, 0, 256, 63, 64, 256, 0, 0, 0, 0, 0) == -1
+    assert lib.hos_canonical_fold_unfold(0, 0, 0, 0, 0, 128, 0, 384, 0, 256, 63, 64, 256, 0, 0, 0, 0, 0, 0) == -1
+    assert lib.hos_mlp_chain128_fwd(0, 0, 0, 64, 0, 0, 0, 0, 128, 0, 1024, 0, 0) == -1          # E == NULL is legal (folded form), PE is not
+    # shape errors are reported before anything is dereferenced: more feature columns than the 64-wide folded first layer holds
+    import ctypes
+    buf = (ctypes.c_float * 4)()
+    ptrs = (ctypes.c_void_p * 7)(*[ctypes.addressof(buf)] * 7)
+    ld = (ctypes.c_int * 7)(*[256] * 7)
+    a = ctypes.addressof(buf)
+    assert lib.hos_mlp_chain_pack_fold(ctypes.addressof(ptrs), ctypes.addressof(ld), ctypes.addressof(ptrs), a, 75, 65, a, a, a, 0) == -3   # HOS_E_SHAPE
 
 
 def test_no_cpu_fallback():
