@@ -49,6 +49,8 @@ PROTOTYPES = {
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],
     "hos_deconv3d_im2col": [_P, _I, _I, _P, _P],
     "hos_deconv3d_dpre": [_P, _P, _L, _I, _F, _I, _P, _P, _P],
+    "hos_gemv_ws_floats": [_I, _I],
+    "hos_gemv_rowvec": [_P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P, _P],
     "hos_outer_accum": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_split_planes": [_P, _I, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_linearp_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
@@ -114,7 +116,7 @@ _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "ho
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
              "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
              "hos_mlp_chain_aux_floats": c_int64, "hos_mlp_chain256_weight_bytes": c_int64,
-             "hos_mlp_chain256_aux_floats": c_int64}
+             "hos_mlp_chain256_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64}
 
 _lib = None
 

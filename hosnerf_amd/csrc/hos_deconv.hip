@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void deconv3d_im2col_kernel(const float* __res
 // 134 / 67 / 33 MB of weights): the gradient is an outer-product stream -- read, add, write every weight once.  A thread owns
 // four consecutive n of KR weight rows; x comes from LDS, dy is re-read once per row block (L2 resident: M x N x 4 bytes).
 // The tiled GEMM spent its time on a 128-row A tile that is 98 % padding here (2.4 TB/s on the 134 MB layer).
-constexpr int OA_KR = 32;
+// (OA_KR rows per thread: 32 for the wide layers; 8 when the grid would otherwise be under one workgroup per CU -- the compact
+// first layer, [1024, 4096], ran on 128 workgroups at 0.9 TB/s)
+template <int OA_KR>
 __global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dy, int lddy,
                                                           float* __restrict__ gW, int ldw, int M, int K, int N) {
     __shared__ float xs[64][OA_KR];
@@ -166,8 +168,57 @@ extern "C" int hos_outer_accum(const float* x, int ldx, const float* dy, int ldd
     if (!x || !dy || !gW || M <= 0 || K <= 0 || N <= 0) return HOS_E_ARG;
     if (M > 64) return HOS_E_SHAPE;
     if ((N & 3) || (lddy & 3) || (ldw & 3) || (((uintptr_t)dy | (uintptr_t)gW) & 15u)) return HOS_E_ALIGN;
-    const dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)((K + OA_KR - 1) / OA_KR));
-    hipLaunchKernelGGL(outer_accum_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, dy, lddy, gW, ldw, M, K, N);
+    const unsigned gx = (unsigned)((N / 4 + 255) / 256);
+    if (gx * (unsigned)((K + 31) / 32) < 256u)
+        hipLaunchKernelGGL(outer_accum_kernel<8>, dim3(gx, (unsigned)((K + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, dy, lddy, gW, ldw, M, K, N);
+    else
+        hipLaunchKernelGGL(outer_accum_kernel<32>, dim3(gx, (unsigned)((K + 31) / 32)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, dy, lddy, gW, ldw, M, K, N);
+    return hos_launch_status();
+}
+
+// y[n] = act(sum_k x[k] W[k][n] + bias[n % bias_mod]) for ONE row x against a long weight stream (the compact first layer of the
+// decoder: [1, 1024] x [1024, 4096], 16.8 MB): two launches with a fixed summation order -- partial[slab][n] over slabs of
+// GV_SLAB weight rows on K / GV_SLAB x N / 1024 workgroups, then the slabs in ascending order.  The 32-row tile of the exact-fp32
+// GEMM ran this shape on N / 128 = 32 workgroups (34 us for 16.8 MB).
+constexpr int GV_SLAB = 16;
+__global__ __launch_bounds__(256) void gemv_partial_kernel(const float* __restrict__ x, const float* __restrict__ W, int ldw, int K, int N,
+                                                           float* __restrict__ partial) {
+    const int n4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int k0 = blockIdx.y * GV_SLAB;
+    if (n4 >= N) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < GV_SLAB; ++i) {
+        const int k = k0 + i;
+        if (k < K) {
+            const float xv = x[k];
+            const float4 w = *reinterpret_cast<const float4*>(W + (size_t)k * ldw + n4);
+            acc.x += xv * w.x; acc.y += xv * w.y; acc.z += xv * w.z; acc.w += xv * w.w;
+        }
+    }
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.y * N + n4) = acc;
+}
+__global__ __launch_bounds__(256) void gemv_finish_kernel(const float* __restrict__ partial, int slabs, int N, const float* __restrict__ bias,
+                                                          int bias_mod, float slope, int leaky, float* __restrict__ y) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int g = 0; g < slabs; ++g) s += partial[(size_t)g * N + n];
+    if (bias) s += bias[n % bias_mod];
+    if (leaky && s < 0.f) s *= slope;
+    y[n] = s;
+}
+
+extern "C" long long hos_gemv_ws_floats(int K, int N) { return (long long)((K + GV_SLAB - 1) / GV_SLAB) * N; }
+
+extern "C" int hos_gemv_rowvec(const float* x, const float* W, int ldw, int K, int N, const float* bias, int bias_mod,
+                               float leaky_slope, int leaky, float* ws, float* y, hos_stream_t stream) {
+    if (!x || !W || !ws || !y || K <= 0 || N <= 0 || (bias && bias_mod <= 0)) return HOS_E_ARG;
+    if ((N & 3) || (ldw & 3) || (((uintptr_t)W | (uintptr_t)ws) & 15u)) return HOS_E_ALIGN;
+    const int slabs = (K + GV_SLAB - 1) / GV_SLAB;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gemv_partial_kernel, dim3((unsigned)((N / 4 + 255) / 256), (unsigned)slabs), dim3(256), 0, s, x, W, ldw, K, N, ws);
+    hipLaunchKernelGGL(gemv_finish_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, ws, slabs, N, bias, bias_mod, leaky_slope, leaky, y);
     return hos_launch_status();
 }
 

@@ -530,12 +530,11 @@ class _Deconv3dFirst(torch.autograd.Function):
         Cin, N8 = wc.shape
         Cout = N8 // 8
         x = x.contiguous()
-        ycol = torch.empty(1, N8, device=x.device)
-        with gemm_mode(GEMM_FP32):
-            linear_dgrad(x, wc, Cin, N8, ycol)
-        out = ycol.view(8, Cout) + bias.detach()
-        if leaky:
-            out = torch.nn.functional.leaky_relu(out, 0.2)
+        # one row against 16.8 MB of weights: the fixed-order two-launch GEMV with bias + LeakyReLU in its second launch
+        # (hos_gemv_rowvec; the 32-row GEMM tile ran this on 32 workgroups: 34 us + two torch launches)
+        out = torch.empty(8, Cout, device=x.device)
+        ws = torch.empty(int(_lib.load().hos_gemv_ws_floats(Cin, N8)), device=x.device)
+        call("hos_gemv_rowvec", ptr(x), ptr(wc), wc.stride(0), Cin, N8, ptr(bias.detach()), Cout, 0.2, int(leaky), ptr(ws), ptr(out))
         ctx.save_for_backward(x, bias, out)
         ctx.wc, ctx.gwc, ctx.leaky = wc, gwc, leaky
         return out

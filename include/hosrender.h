@@ -266,6 +266,13 @@ int hos_deconv3d_dpre(const float* g, const float* out, long long R, int C, floa
  * exact fp32, one read-add-write pass over the weights.  Reference: deconv_vol_decoder.py:34-42 (ConvTranspose3d autograd). */
 int hos_outer_accum(const float* x, int ldx, const float* dy, int lddy, float* gW, int ldw, int M, int K, int N,
                     hos_stream_t stream);
+/* One row against a long weight stream: y [N] = act(x [K] . W [K, ldw][:, :N] + bias[n % bias_mod]) (act: identity or LeakyReLU with
+ * `leaky_slope`), exact fp32 with a fixed summation order (16-row slabs, then the slabs in ascending order); ws: scratch of
+ * hos_gemv_ws_floats(K, N) floats.  The first ConvTranspose3d of the volume decoder sees ONE voxel (network_util.py:21-59,
+ * deconv_vol_decoder.py:34-42): with its 8 live taps stored tap-major, x . Wc viewed as [8, Cout] + bias IS its output. */
+long long hos_gemv_ws_floats(int K, int N);
+int hos_gemv_rowvec(const float* x, const float* W, int ldw, int K, int N, const float* bias, int bias_mod,
+                    float leaky_slope, int leaky, float* ws, float* y, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Background branch, per-ray kernels (one wavefront per ray).

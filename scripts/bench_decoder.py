@@ -51,3 +51,10 @@ for n in range(5):
         t_dwg = timeit(lambda: ops.linear_wgrad(x, dycol, gW, None, Cin, Cout * 64)) if M <= 64 else t_dw      # the tiled GEMM for few rows too
     print(f"L{n} M={M:5d} Cin={Cin:4d} N={Cout*64:6d} {t_f:9.1f} {t_mm:9.1f} {t_c:8.1f} | {t_dp:7.1f} {t_im:7.1f} {t_dx:7.1f} {t_dxmm:7.1f} {t_dw:7.1f} {t_dwmm:7.1f}  (tiled wgrad {t_dwg:6.1f})")
     D *= 2
+
+# the compact first layer as the network runs it: ONE voxel, 8 live taps: [1, 1024] x [1024, 4096]
+x = torch.randn(1, 1024, device=dev); wc = torch.randn(1024, 4096, device=dev) * 0.02; gwc = torch.zeros_like(wc); b = torch.zeros(512, device=dev)
+dy = torch.randn(1, 4096, device=dev)
+t_f = timeit(lambda: ops.deconv3d_first(x, wc, gwc, b, True))
+t_o = timeit(lambda: call("hos_outer_accum", ptr(x), x.stride(0), ptr(dy), dy.stride(0), ptr(gwc), gwc.stride(0), 1, 1024, 4096))
+print(f"compact first layer: forward (gemv + bias + leaky) {t_f:.1f} us, weight gradient (outer) {t_o:.1f} us")
