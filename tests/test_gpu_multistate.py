@@ -38,7 +38,7 @@ def test_background_states(ms, K):
     model = model.to(dev)
     worst = 0.0
     for i, t in enumerate(times):
-        assert select_state(float(t), model.transitions_times) == int(ms[f"k{K}_bkgd_state"][i]), (K, i, t)
+        assert select_state(float(t), model.mlps[2].transitions_times) == int(ms[f"k{K}_bkgd_state"][i]), (K, i, t)
         b = {k: v.to(dev) for k, v in synth.stage1_batch(4, seed=31, time=float(t)).items()}
         with torch.no_grad():
             _, hist = model(b, 1.0, False, False, 0.1, 1e6)
