@@ -111,6 +111,21 @@ PROTOTYPES = {
     "hos_sumsq": [_P, _L, _P, _P],
     "hos_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P, _F, _P],
     "hos_adam_step_dyn": [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P, _F, _P],
+    "hos_rowdot_lrelu_fwd": [_P, _P, _I, _P, _I, _I, _F, _P, _P],
+    "hos_rowdot_lrelu_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
+    "hos_volume_softmax_fwd": [_P, _P, _I, _L, _P, _P],
+    "hos_volume_softmax_bwd": [_P, _P, _I, _L, _P, _P],
+    "hos_volume_channel_last": [_P, _I, _L, _P, _P],
+    "hos_volume_pair_bwd": [_P, _P, _I, _I, _L, _P, _P],
+    "hos_copy_or_zero_n": [_I, _P, _P, _P, _P],
+    "hos_add_n": [_I, _P, _L, _P, _P],
+    "hos_any_abs_below": [_P, _L, _F, _P, _P],
+    "hos_state_embed_grad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "hos_embed_bwd_res": [_P, _P, _I, _I, _P, _I, _I, _P, _I, _I, _L, _P, _P, _P, _P],
+    "hos_head_grad_padded": [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P, _I, _P],
+    "hos_sumsq_blocks": [],
+    "hos_sumsq_partials": [_I, _P, _P, _P, _P],
+    "hos_adam_multi": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _F, _P, _P, _P],
 }
 _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "hos_train_losses_workspace_floats": c_int64,
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,

@@ -371,6 +371,39 @@ extern "C" int hos_distortion_bwd(const float* t, const float* w, int B, int S, 
     return hos_launch_status();
 }
 
+// columns [c0, c1) of every row of a [P, ld] matrix = 0 (the zero padding of an operand row whose live columns other kernels write)
+__global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ a, int ld, int c0, int c1, int P, float* __restrict__ b, int ldb, int b0, int b1) {
+    const int wa = a ? c1 - c0 : 0, wb = b ? b1 - b0 : 0, w = wa + wb;
+    const long total = (long)P * w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / w;
+        const int c = (int)(i - m * w);
+        if (c < wa) a[m * ld + c0 + c] = 0.f; else b[m * ldb + b0 + (c - wa)] = 0.f;
+    }
+}
+
+// hos_head_grad that also writes the ZERO PADDING of its two operand rows -- columns (col_dd, ld_dd) of dz_density's rows and
+// [3, ld_dr) of dz_rgb's -- so that both may be uninitialised storage (the caller's other kernels fill columns [0, col_dd)).
+extern "C" int hos_head_grad_padded(const float* g_density, const float* density, const float* g_rgb, const float* rgb,
+                                    int P, float rgb_padding, float* dz_density, int ld_dd, int col_dd,
+                                    float* dz_rgb, int ld_dr, hos_stream_t stream) {
+    if (P <= 0) return HOS_E_ARG;
+    if (dz_density && !density) return HOS_E_ARG;
+    if (dz_rgb && !rgb) return HOS_E_ARG;
+    int blocks = hos_cdiv(P, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(head_grad_kernel, dim3(blocks), dim3(256), 0, s, g_density, density, g_rgb, rgb, P, rgb_padding, dz_density, ld_dd, col_dd, dz_rgb, ld_dr);
+    const int wa = dz_density ? ld_dd - (col_dd + 1) : 0, wb = dz_rgb ? ld_dr - 3 : 0;
+    if (wa + wb > 0) {
+        long zb = ((long)P * (wa + wb) + 255) / 256;
+        if (zb > 4096) zb = 4096;
+        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)zb), dim3(256), 0, s, wa > 0 ? dz_density : nullptr, ld_dd, col_dd + 1, ld_dd, P,
+                           wb > 0 ? dz_rgb : nullptr, ld_dr, 3, ld_dr);
+    }
+    return hos_launch_status();
+}
+
 extern "C" int hos_head_grad(const float* g_density, const float* density, const float* g_rgb, const float* rgb,
                              int P, float rgb_padding, float* dz_density, int ld_dd, int col_dd,
                              float* dz_rgb, int ld_dr, hos_stream_t stream) {

@@ -842,9 +842,13 @@ __global__ __launch_bounds__(256) void lbs_forward_bwd_kernel(
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ x, const float* __restrict__ band_w, int F,
                                                         int identity, const float* __restrict__ dA, int lda, int colA,
                                                         const float* __restrict__ dB, int ldb, int colB, long P,
-                                                        float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev) {
+                                                        float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev,
+                                                        const float* __restrict__ res) {
+    const long P_full = P;
     if (p_dev) P = min(P, (long)*p_dev);
     const long total = P * 3;
+    if (res != nullptr)
+        for (long it = total + (long)blockIdx.x * blockDim.x + threadIdx.x; it < P_full * 3; it += (long)gridDim.x * blockDim.x) g_x[it] = res[it];
     for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
         const long p = it / 3;
         const int ax = (int)(it % 3);
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
             const float wj = band_w ? band_w[j] : 1.f;
             g += wj * fr * (cosf(a) * feat(base + j * 6 + ax) - sinf(a) * feat(base + j * 6 + 3 + ax));
         }
-        g_x[it] = accumulate ? g_x[it] + g : g;
+        g_x[it] = res != nullptr ? res[it] + g : (accumulate ? g_x[it] + g : g);
     }
 }
 
@@ -873,10 +877,16 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void embed_bwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ band_w, int F,
                                                               int identity, const float* __restrict__ dA, int lda, int colA,
                                                               const float* __restrict__ dB, int ldb, int colB, long P,
-                                                              float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev) {
+                                                              float* __restrict__ g_x, int accumulate, const int* __restrict__ p_dev,
+                                                              const float* __restrict__ res) {
     __shared__ float sG[64][101];
+    const long P_full = P;
     if (p_dev) P = min(P, (long)*p_dev);
     const int t = threadIdx.x, nf = (identity ? 3 : 0) + 6 * F;
+    // `res` (the residual path's cotangent, xyz = x + offset): g_x = res + g, and rows past the device-side row count -- which this
+    // kernel otherwise leaves alone -- receive res alone, so that g_x may be uninitialised storage (no clone of res beforehand)
+    if (res != nullptr)
+        for (long it = P * 3 + (long)blockIdx.x * 256 + t; it < P_full * 3; it += (long)gridDim.x * 256) g_x[it] = res[it];
     for (long row0 = (long)blockIdx.x * 64; row0 < P; row0 += (long)gridDim.x * 64) {
         const int rows = (int)min(64L, P - row0);
         for (int i = t; i < rows * nf; i += 256) {
@@ -901,7 +911,7 @@ __global__ __launch_bounds__(256) void embed_bwd_tiled_kernel(const float* __res
                 sincosf(a, &sn, &cs);
                 g += wj * fr * (cs * sG[r][base + j * 6 + ax] - sn * sG[r][base + j * 6 + 3 + ax]);
             }
-            g_x[it] = accumulate ? g_x[it] + g : g;
+            g_x[it] = res != nullptr ? res[it] + g : (accumulate ? g_x[it] + g : g);
         }
         __syncthreads();
     }
@@ -1008,20 +1018,39 @@ extern "C" int hos_lbs_forward_bwd(const float* cnl_pts, const float* R_fwd, con
     return hos_launch_status();
 }
 
+static int embed_bwd_launch(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
+                            int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
+                            const int32_t* rows_dev, const float* res, hos_stream_t stream);
+
 extern "C" int hos_embed_bwd(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
                              int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
                              const int32_t* rows_dev, hos_stream_t stream) {
+    return embed_bwd_launch(x, band_w, num_freqs, identity, dA, lda, colA, dB, ldb, colB, P, g_x, accumulate, rows_dev, nullptr, stream);
+}
+
+// The same gradient added to a residual cotangent: g_x [P, 3] = res [P, 3] + d(features)/dx (rows past *rows_dev: res alone), so
+// g_x may be uninitialised storage -- the backward of xyz = x + MLP(embed(x)) (mlp_offset.py:66-70) without a clone of `res`.
+extern "C" int hos_embed_bwd_res(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
+                                 int colA, const float* dB, int ldb, int colB, int64_t P, const float* res, float* g_x,
+                                 const int32_t* rows_dev, hos_stream_t stream) {
+    if (!res) return HOS_E_ARG;
+    return embed_bwd_launch(x, band_w, num_freqs, identity, dA, lda, colA, dB, ldb, colB, P, g_x, 0, rows_dev, res, stream);
+}
+
+static int embed_bwd_launch(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda,
+                            int colA, const float* dB, int ldb, int colB, int64_t P, float* g_x, int accumulate,
+                            const int32_t* rows_dev, const float* res, hos_stream_t stream) {
     if (!x || !dA || !g_x || P <= 0) return HOS_E_ARG;
     if (num_freqs < 1 || num_freqs > 16) return HOS_E_SHAPE;
     static const bool tiled = !(getenv("HOS_EMBED_BWD_TILED") && atoi(getenv("HOS_EMBED_BWD_TILED")) == 0);
     if (tiled) {
         const long b = (P + 63) / 64;
         hipLaunchKernelGGL(embed_bwd_tiled_kernel, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                           band_w, num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev);
+                           band_w, num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev, res);
         return hos_launch_status();
     }
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(P * 3)), dim3(256), 0, static_cast<hipStream_t>(stream), x, band_w,
-                       num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev);
+                       num_freqs, identity, dA, lda, colA, dB, ldb, colB, (long)P, g_x, accumulate, rows_dev, res);
     return hos_launch_status();
 }
 

@@ -64,6 +64,80 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+
+// ---- round 4: ONE norm launch + ONE update launch per training step, whatever the number of flat buffers / learning-rate ranges,
+// and the fp16 range guard consumed on the device.
+constexpr int OPT_SPANS = 8;
+constexpr int SUMSQ_BLOCKS = 1024;
+struct SumsqSpans { const float* g[OPT_SPANS]; long start4[OPT_SPANS + 1]; int count; };      // spans in float4 units (n % 4 == 0)
+
+// partial[b] = sum of squares of block b's share of all spans: plain stores in a fixed order (no atomics, nothing to zero first,
+// bit-reproducible); the update kernel adds the SUMSQ_BLOCKS partials itself.
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const SumsqSpans t, float* __restrict__ partial) {
+    float acc = 0.f;
+    const long total4 = t.start4[t.count];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < OPT_SPANS; ++k) if (k < t.count && i >= t.start4[k]) s = k;
+        const float4 v = reinterpret_cast<const float4*>(t.g[s])[i - t.start4[s]];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+struct AdamSpans {
+    float* p[OPT_SPANS]; const float* g[OPT_SPANS]; float* m[OPT_SPANS]; float* v[OPT_SPANS];
+    const float* hyper[OPT_SPANS];                       // device {lr, 1-b1^t, 1/sqrt(1-b2^t)} of the span, or NULL: the host values below
+    float lr[OPT_SPANS], bc1[OPT_SPANS], rsbc2[OPT_SPANS];
+    long start4[OPT_SPANS + 1]; int count;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, float b1, float b2, float eps, float grad_scale,
+                                                         const float* __restrict__ partial, int n_partial, float max_norm,
+                                                         const unsigned int* __restrict__ guard, unsigned int* __restrict__ skipped) {
+    // fp16 range guard: a hidden activation of this step's forward left the exact hi/lo range (the forward epilogues OR the word):
+    // the step must not reach the parameters.  The word stays set until the host re-arms it (train.check_range), `skipped` counts.
+    if (guard != nullptr && *guard != 0u) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && skipped != nullptr) atomicAdd(skipped, 1u);
+        return;
+    }
+    float gs = grad_scale;
+    if (partial != nullptr && max_norm > 0.f) {
+        __shared__ float red[4];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];      // fixed order per thread, fixed tree below
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        const float total = sqrtf(red[0] + red[1] + red[2] + red[3]) * fabsf(grad_scale);
+        gs *= fminf(max_norm / (total + 1e-6f), 1.f);      // torch.nn.utils.clip_grad_norm_
+    }
+    const long total4 = t.start4[t.count];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        int s = 0;
+#pragma unroll
+        for (int k = 1; k < OPT_SPANS; ++k) if (k < t.count && i >= t.start4[k]) s = k;
+        const long j = i - t.start4[s];
+        float lr = t.lr[s], bc1 = t.bc1[s], rsbc2 = t.rsbc2[s];
+        if (t.hyper[s] != nullptr) { lr = t.hyper[s][0]; bc1 = t.hyper[s][1]; rsbc2 = t.hyper[s][2]; }
+        float4* p4 = reinterpret_cast<float4*>(t.p[s]) + j;
+        float4* m4 = reinterpret_cast<float4*>(t.m[s]) + j;
+        float4* v4 = reinterpret_cast<float4*>(t.v[s]) + j;
+        float4 pp = *p4, mm = *m4, vv = *v4;
+        const float4 gg = reinterpret_cast<const float4*>(t.g[s])[j];
+        adam1(pp.x, gg.x * gs, mm.x, vv.x, lr, b1, b2, eps, bc1, rsbc2);
+        adam1(pp.y, gg.y * gs, mm.y, vv.y, lr, b1, b2, eps, bc1, rsbc2);
+        adam1(pp.z, gg.z * gs, mm.z, vv.z, lr, b1, b2, eps, bc1, rsbc2);
+        adam1(pp.w, gg.w * gs, mm.w, vv.w, lr, b1, b2, eps, bc1, rsbc2);
+        *p4 = pp; *m4 = mm; *v4 = vv;
+    }
+}
+
 }  // namespace
 
 extern "C" int hos_sumsq(const float* g, int64_t n, float* sumsq, hos_stream_t stream) {
@@ -101,6 +175,57 @@ extern "C" int hos_adam_step_dyn(float* p, const float* g, float* m, float* v, i
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m, v, n, 0.f,
                        beta1, beta2, eps, 1.f, 1.f, grad_scale, sumsq, max_norm, hyper);
+    return hos_launch_status();
+}
+
+extern "C" int hos_sumsq_blocks(void) { return SUMSQ_BLOCKS; }
+
+// partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 8 spans (every count % 4 == 0, 16-byte aligned): the
+// gradient norm of `Trainer(gradient_clip_val=..., "norm")` (S1/run.py:155, 3rd_.../run.py:188-189) over ALL flat buffers of a step
+// in one launch, deterministic, nothing to zero beforehand.  Consumed by hos_adam_multi.
+extern "C" int hos_sumsq_partials(int n, const float* const* g, const long long* count, float* partial, hos_stream_t stream) {
+    if (n <= 0 || n > OPT_SPANS || !g || !count || !partial) return HOS_E_ARG;
+    SumsqSpans t{};
+    long pos = 0;
+    for (int s = 0; s < n; ++s) {
+        if (!g[s] || count[s] <= 0) return HOS_E_ARG;
+        if ((count[s] & 3) || ((uintptr_t)g[s] & 15u)) return HOS_E_ALIGN;
+        t.g[s] = g[s]; t.start4[s] = pos; pos += (long)(count[s] >> 2);
+    }
+    for (int s = n; s <= OPT_SPANS; ++s) t.start4[s] = pos;
+    t.count = n;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, static_cast<hipStream_t>(stream), t, partial);
+    return hos_launch_status();
+}
+
+// torch.optim.Adam over n <= 8 spans of flat buffers in ONE launch (M1:536-569, optimizer.py:19-60: the reference's per-parameter
+// groups are contiguous ranges here).  Span s: p/g/m/v[s][0 .. count[s]) with count % 4 == 0; its step scalars come from device
+// memory (hyper[s] = {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}, graph replay) or, where hyper[s] is NULL, from lr[s] and `step`.
+// partial (NULL: no clipping): hos_sumsq_partials' output, summed here; coefficient min(max_norm / (sqrt(sum) * |grad_scale| + 1e-6), 1).
+// guard (NULL: off): the range-guard word (hos_set_range_flag); non-zero -> NOTHING is updated and *skipped (NULL ok) is incremented.
+extern "C" int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
+                              const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
+                              const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream) {
+    if (n <= 0 || n > OPT_SPANS || !p || !g || !m || !v || !count) return HOS_E_ARG;
+    AdamSpans t{};
+    long pos = 0;
+    const double bc1 = step >= 1 ? 1.0 - pow((double)beta1, (double)step) : 1.0;
+    const double bc2 = step >= 1 ? 1.0 - pow((double)beta2, (double)step) : 1.0;
+    for (int s = 0; s < n; ++s) {
+        if (!p[s] || !g[s] || !m[s] || !v[s] || count[s] <= 0) return HOS_E_ARG;
+        if ((count[s] & 3) || (((uintptr_t)p[s] | (uintptr_t)g[s] | (uintptr_t)m[s] | (uintptr_t)v[s]) & 15u)) return HOS_E_ALIGN;
+        const float* h = hyper ? hyper[s] : nullptr;
+        if (!h && (!lr || step < 1)) return HOS_E_ARG;
+        t.p[s] = p[s]; t.g[s] = g[s]; t.m[s] = m[s]; t.v[s] = v[s]; t.hyper[s] = h;
+        t.lr[s] = lr ? lr[s] : 0.f; t.bc1[s] = (float)bc1; t.rsbc2[s] = (float)(1.0 / sqrt(bc2));
+        t.start4[s] = pos; pos += (long)(count[s] >> 2);
+    }
+    for (int s = n; s <= OPT_SPANS; ++s) t.start4[s] = pos;
+    t.count = n;
+    long blocks = (pos + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), t, beta1, beta2, eps, grad_scale,
+                       partial, SUMSQ_BLOCKS, max_norm, guard, skipped);
     return hos_launch_status();
 }
 

@@ -97,7 +97,10 @@ class FlatStore:
 
     def zero_grad(self):
         self.ensure_bound()
-        if not self.inactive:
+        if self.grad.is_cuda:
+            from . import ops          # one library launch for all active spans (the CPU plumbing mode keeps torch's fill)
+            ops.copy_or_zero_n([self.grad[off:off + n] for off, n in self.active_spans()])
+        elif not self.inactive:
             self.grad.zero_()
         else:
             for off, n in self.active_spans():

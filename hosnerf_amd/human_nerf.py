@@ -341,9 +341,9 @@ class Network(FlatModule):
     def _motion_weight_volume(self, priors):
         """deconv_vol_decoder.py:34-42 + U:21-59 -> [K+1, V, V, V]."""
         P = self._plain
-        h = F.leaky_relu(F.linear(P["mweight_vol_decoder.const_embedding"][None],
-                                  P["mweight_vol_decoder.decoder.block_mlp.0.weight"],
-                                  P["mweight_vol_decoder.decoder.block_mlp.0.bias"]), 0.2)         # [1, 1024] = 1 voxel, channel-last
+        self.store.ensure_bound()
+        h = ops.decoder_head(P["mweight_vol_decoder.const_embedding"], P["mweight_vol_decoder.decoder.block_mlp.0.weight"],
+                             P["mweight_vol_decoder.decoder.block_mlp.0.bias"])                     # [1, 1024] = 1 voxel, channel-last
         n_conv = len(self._deconv_chans)
         D = 1
         for n in range(n_conv):                  # ConvTranspose3d(4, 2, 1) as GEMM + gather, channel-last (hos_deconv.hip)
@@ -354,8 +354,7 @@ class Network(FlatModule):
                 h = ops.deconv3d(h, P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.weight"],
                                  P[f"mweight_vol_decoder.decoder.block_conv.{2 * n}.bias"], D, n < n_conv - 1)
             D *= 2
-        h = h.t().reshape(1, -1, D, D, D)        # [V^3, K+1] -> [1, K+1, V, V, V]
-        return F.softmax(h + torch.log(priors[None]), dim=1)[0].contiguous()
+        return ops.volume_softmax(h, priors)     # [V^3, K+1] channel-last logits -> [K+1, V, V, V]
 
     # ------------------------------------------------------------------ data-parallel backward of the volume decoder
     # The motion-weight volume decoder (63.4 M of the 64.7 M parameters, 253 MB of gradient) sees no ray: its input is a learned
@@ -570,8 +569,7 @@ class Network(FlatModule):
         ops.slice_pad(g_xyz, 0, 3, dz6, rows_dev=rows_dev)           # [P,3] -> zero-padded [P,32] operand rows, one launch
         if fold is not None:
             # gradient buffers of the folded first layer: [128, 64] for the hann columns of W0 + [128] for the folded bias
-            gfold = ops.fold_grad_workspace(dev)
-            gfold.zero_()
+            gfold = ops.zero_(ops.fold_grad_workspace(dev))
             gw0h, db0 = gfold[:128 * 64].view(128, 64), gfold[128 * 64:]
         with ops.deferred_bwd_reduce():          # the seven slab reductions of this chain as one launch at the end
             dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
@@ -586,14 +584,13 @@ class Network(FlatModule):
                     dE = layer_bwd(dz, E, specs[0], 128, NR_LDE, torch.empty(Pn, NR_LDE, device=dev), False)
                 else:
                     dz = layer_bwd(dz, acts[i - 1], specs[i], 128, 128, torch.empty(Pn, 128, device=dev), True)
-        g_x = g_xyz.contiguous().clone()                                       # residual path of xyz = x + offset
+        # residual path of xyz = x + offset: g_x = g_xyz + d(features)/dx in the embedder's backward launch (no clone)
+        res = g_xyz.contiguous()
         if fold is not None:
             gW0, gb0 = self._w(specs[0], grad=True)
             ops.mlp_chain_unfold_grad(gw0h, db0, fold[1], 6 * band_w.numel(), gW0, gb0)
-            ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 0, dPE, 0, g_x, True, rows_dev=rows_dev)
-        else:
-            ops.embed_bwd(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, g_x, True, rows_dev=rows_dev)
-        return g_x
+            return ops.embed_bwd_res(x, band_w, band_w.numel(), False, dE, 0, dPE, 0, res, rows_dev=rows_dev)
+        return ops.embed_bwd_res(x, band_w, band_w.numel(), False, dE, 75, dPE, 0, res, rows_dev=rows_dev)
 
     def _canonical_bwd(self, saved, cnl: torch.Tensor, raw: torch.Tensor, g_raw: torch.Tensor, state: int):
         E, acts, bits, fold = saved
@@ -610,8 +607,7 @@ class Network(FlatModule):
         tmp_b = {}
         if fold is not None:
             # gradient buffers of the two folded layers (zeroed: the launches below accumulate), unfolded after the reductions
-            gws = ops.cnl_fold_grad_workspace(dev, 256, CNL_NFP, 256)
-            gws.zero_()
+            gws = ops.zero_(ops.cnl_fold_grad_workspace(dev, 256, CNL_NFP, 256))
             gfold = ops.cnl_fold_views(gws, 256, CNL_NFP, 256)
         with ops.deferred_bwd_reduce():          # the slab reductions of the eight 256-wide weight gradients as one launch at the end
             for i in range(7, -1, -1):
@@ -631,7 +627,7 @@ class Network(FlatModule):
                     dE = torch.empty(Pn, CNL_NFP, device=dev)
                     ops.linear_dgrad(dz, fold[0][0], 256, CNL_NFP, dE, thin=True)
                 elif i == 5:
-                    tmp_b[5] = torch.zeros(L.Npad, device=dev)
+                    tmp_b[5] = ops.zeros(L.Npad, dev)
                     ops.linear_wgrad(dz, CAT, gW, tmp_b[5], 256, CNL_CAT)
                     nxt = torch.empty(Pn, 256, device=dev)
                     if ops.thin_dgrad_rows(Pn):
@@ -647,7 +643,7 @@ class Network(FlatModule):
                         ops.slice_mask(dCAT, 127, CAT, 127, 256, nxt)             # h-part of the concat, through layer 4's ReLU
                     dz = nxt
                 elif i == 0:
-                    tmp_b[0] = torch.zeros(L.Npad, device=dev)
+                    tmp_b[0] = ops.zeros(L.Npad, dev)
                     ops.linear_wgrad(dz, E, gW, tmp_b[0], 256, CNL_LDE)
                     dE = torch.empty(Pn, CNL_LDE, device=dev)
                     ops.linear_dgrad(dz, Wt, 256, CNL_LDE, dE)
@@ -691,7 +687,19 @@ class Network(FlatModule):
             return torch.zeros_like(pv) * pv if iter_v < nr_kick else pv          # N:653-656
 
         # prologue for the current (and, for the flow set, the previous) frame in one batch
-        if flow:
+        if flow and dst_Rs.is_cuda and not (dst_Rs.requires_grad or dst_Ts.requires_grad or dst_posevec.requires_grad):
+            # the three stacks as ONE launch into one allocation (the inputs are batch tensors: no gradient flows to them)
+            nR, nT, nP = dst_Rs.numel(), dst_Ts.numel(), dst_posevec.numel()
+            pad4 = lambda n: (2 * n + 3) // 4 * 4
+            buf = torch.empty(pad4(nR) + pad4(nT) + pad4(nP), device=dst_Rs.device)
+            Rs = buf[:2 * nR].view((2,) + tuple(dst_Rs.shape))
+            Ts = buf[pad4(nR):pad4(nR) + 2 * nT].view((2,) + tuple(dst_Ts.shape))
+            pv = buf[pad4(nR) + pad4(nT):pad4(nR) + pad4(nT) + 2 * nP].view(2, nP)
+            c = lambda t_: t_.detach().float().contiguous()
+            ops.copy_or_zero_n([Rs[0], Rs[1], Ts[0], Ts[1], pv[0], pv[1]],
+                               [c(dst_Rs), c(kwargs["dst_Rs_prev"]), c(dst_Ts), c(kwargs["dst_Ts_prev"]), c(dst_posevec).reshape(-1),
+                                c(kwargs["dst_posevec_prev"]).reshape(-1)])
+        elif flow:
             Rs = torch.stack([dst_Rs, kwargs["dst_Rs_prev"]], 0)
             Ts = torch.stack([dst_Ts, kwargs["dst_Ts_prev"]], 0)
             pv = torch.stack([dst_posevec.reshape(-1), kwargs["dst_posevec_prev"].reshape(-1)], 0)
@@ -707,14 +715,14 @@ class Network(FlatModule):
             leaf = vol.detach().requires_grad_(True)
             self._pending_vol = (vol, leaf)
             vol = leaf
-        Rb, Tb, Rf, Tf = (ops.unbind_frames(t_) for t_ in (Rb_, Tb_, Rf_, Tf_))      # per-frame views, one-launch backward
+        Rb, Tb, Rf, Tf = ops.unbind_frames_many(Rb_, Tb_, Rf_, Tf_)      # per-frame views; ONE launch stacks all their cotangents
+        # the volume feeds the backward warp (channel-major) and, as a channel-last copy of its K bone channels, the forward warp
+        vol, vol_cl = ops.volume_pair(vol, K)
         pro = {"flow": flow, "state": select_state(time, self.transitions_times), "R_b": Rb[0], "T_b": Tb[0],
                "R_f": Rf[0], "T_f": Tf[0], "band_w": self._band_weights(iter_v, dst_Rs.device),
-               "cond": cond_of(dst_posevec).contiguous(), "vol": vol}
+               "cond": cond_of(dst_posevec).contiguous(), "vol": vol, "vol_cl": vol_cl}
         if flow:
             pro.update(R_fp=Rf[1], T_fp=Tf[1], cond_prev=cond_of(kwargs["dst_posevec_prev"]).contiguous())
-        # channel-last copy of the K bone channels for the K-channel forward tap
-        pro["vol_cl"] = F.pad(pro["vol"][:K].permute(1, 2, 3, 0), (0, 32 - K)).contiguous()
         return pro
 
     def forward(self, rays, dst_Rs=None, dst_Ts=None, cnl_gtfms=None, motion_weights_priors=None, dst_posevec=None, near=None,
@@ -758,11 +766,16 @@ class Network(FlatModule):
                 z, pts, x_skel, mask = ops.human_sample_warp_ad(vol, R_b, T_b, rays_o[sl], rays_d[sl], near[sl].contiguous(),
                                                                 far[sl].contiguous(), N, bmin, bscale, tr, K)
                 cnl = _NonRigidFn.apply(self._token, self, "nr", x_skel, cond, band_w, None)
-                raw = _CanonicalFn.apply(self._token, self, cnl, state)
+                # the canonical points feed up to three consumers (canonical MLP, flow set, cycle set): their cotangents are
+                # summed by ONE launch instead of one autograd accumulation per extra consumer
+                n_use = 1 + int(flow) + int(with_cycle)
+                cnl_uses = list(ops.fanout(cnl, n_use))
+                raw = _CanonicalFn.apply(self._token, self, cnl_uses.pop(), state)
             else:
                 z, pts, x_skel, mask = ops.human_sample_warp(rays_o[sl], rays_d[sl], near[sl].contiguous(), far[sl].contiguous(),
                                                              N, R_b, T_b, vol, bmin, bscale, tr, K)
                 cnl, _ = self._nonrigid_fwd(self._nr, x_skel, cond, band_w, save=False)
+                cnl_uses = [cnl, cnl, cnl]
                 raw, _ = self._canonical_fwd(cnl, state, save=False)
             b = z.shape[0]
             if self.stage == 2:
@@ -783,14 +796,14 @@ class Network(FlatModule):
                 return self._nonrigid_fwd(self._nrf, d_, cond_, band_w, save=False, rows_dev=rows_dev)[0]
 
             if flow:                                                               # N:474-502
-                ret["deform_pts_prev_final"] = fwd_branch(cnl, R_fp, T_fp, cond_prev).view(b, N, 3)
+                ret["deform_pts_prev_final"] = fwd_branch(cnl_uses.pop(), R_fp, T_fp, cond_prev).view(b, N, 3)
             # N:505-536 (data-dependent size); the frame loops of eval.py never read the cycle outputs and switch them off
             if with_cycle and static_cycle:
                 # fixed-capacity form for captured training steps: the selection is a device-side compaction, the row count
                 # stays in device memory (`cycle_count`), rows past it are zero and receive zero gradients
                 if B > chunk:
                     raise ValueError("static_cycle needs the whole ray batch in one chunk (cfg.chunk >= number of rays)")
-                sel_cnl, observe, _, count = ops.compact_rows(mask, 0.005, cnl, pts)
+                sel_cnl, observe, _, count = ops.compact_rows(mask, 0.005, cnl_uses.pop(), pts)
                 # the kernels stop at `count` rows (the two-GEMM debug path of the backward, HOS_FUSED_BWD=0, has no row
                 # limit and runs over the zero-padded capacity instead)
                 ret["deform_pts_final"] = fwd_branch(sel_cnl, R_f, T_f, cond, rows_dev=count if ops.FUSED_THIN_BWD else None)
@@ -799,7 +812,7 @@ class Network(FlatModule):
             elif with_cycle:
                 sel = torch.nonzero(mask.detach() > 0.005).reshape(-1)
                 if sel.numel() > 0:
-                    ret["deform_pts_final"] = fwd_branch(cnl.index_select(0, sel), R_f, T_f, cond)
+                    ret["deform_pts_final"] = fwd_branch(cnl_uses.pop().index_select(0, sel), R_f, T_f, cond)
                     ret["observe_pts"] = pts.view(-1, 3).index_select(0, sel)
                 else:
                     ret["deform_pts_final"] = pts[0, 0][None]

@@ -264,16 +264,18 @@ class MipNeRF360MLP(FlatModule):
         Hs = self._head
         g_density = None if g_density is None else g_density.contiguous().view(-1)
         if self.disable_rgb:
-            dyh = torch.zeros(P, 32, device=dev)
-            ops.head_grad(g_density, density, None, None, 0.0, dyh, 0, None)
+            dyh = torch.empty(P, 32, device=dev)
+            ops.head_grad_padded(g_density, density, None, None, 0.0, dyh, 0, None)     # writes the zero padding too
         else:
             Xv, hv = saved[2], saved[3]
             bw = self.bottleneck_width
             NC = self.netwidth_condition
             g_rgb = None if g_rgb is None else g_rgb.contiguous().view(-1, 3)
-            dz_rgb = torch.zeros(P, 32, device=dev)
-            dyh = torch.zeros(P, XV_LD, device=dev)
-            ops.head_grad(g_density, density, g_rgb, rgb, self.rgb_padding, dyh, bw, dz_rgb)
+            # operand rows [bottleneck gradient (written by the view layer's dgrad below) | density | 0 ...] and [rgb 3 | 0 ...]:
+            # the padding columns are written by the head-gradient launch, not by a fill of the whole [P, 288] / [P, 32] matrices
+            dz_rgb = torch.empty(P, 32, device=dev)
+            dyh = torch.empty(P, XV_LD, device=dev)
+            ops.head_grad_padded(g_density, density, g_rgb, rgb, self.rgb_padding, dyh, bw, dz_rgb)
             # rgb layer (M:344)
             Wt, _ = self._w(self._rgb)
             gW, gb = self._w(self._rgb, grad=True)
@@ -294,22 +296,21 @@ class MipNeRF360MLP(FlatModule):
         ops.linear_dgrad(dyh, Wt, Hs.Npad, W, dz, mask_src=h_last)
         # trunk, last layer first
         embed_cols = []   # (temporary bias-grad, weight region, first embedding column)
+        tmps = ops.zeros_many([(self._layers[0].Npad,)] * (1 + len(self._skip_consumers)), dev)      # one launch for the bias-gradient temporaries
         for i in range(len(self._layers) - 1, -1, -1):
             L = self._layers[i]
             Wt, _ = self._w(L)
             gW, gb = self._w(L, grad=True)
             inp = acts[i - 1] if i > 0 else X
             if i in self._skip_consumers:
-                tmp = torch.zeros(L.Npad, device=dev)
+                tmp = tmps.pop()
                 ops.linear_wgrad(dz, inp, gW, tmp, W, W)
                 ops.linear_wgrad(dz, X, gW, None, W, X_LD, w_col0=W)
-                gb += tmp
-                embed_cols.append((tmp, Wt, W + POS_FEATS))
+                embed_cols.append((tmp, Wt, W + POS_FEATS, gb))
             elif i == 0:
-                tmp = torch.zeros(L.Npad, device=dev)
+                tmp = tmps.pop()
                 ops.linear_wgrad(dz, X, gW, tmp, W, X_LD)
-                gb += tmp
-                embed_cols.append((tmp, Wt, POS_FEATS))
+                embed_cols.append((tmp, Wt, POS_FEATS, gb))
             else:
                 ops.linear_wgrad(dz, inp, gW, gb, W, W)
             if i > 0:
@@ -319,8 +320,8 @@ class MipNeRF360MLP(FlatModule):
         # state-embedding gradient: the 64 embedding columns of x are constant over samples, so
         # d embed = (sum_p dZ[p,:]) @ W[:, embed cols] = db @ W[:, embed cols]   (M:295-296)
         g_embed = self._embeds.view(self.store.grad)[state]
-        for tmp, Wt, c0 in embed_cols:
-            g_embed += tmp[:W] @ Wt[:W, c0:c0 + EMBED]
+        for tmp, Wt, c0, gb in embed_cols:       # gb += db and g_embed += db @ W[:, embed columns], one launch per layer
+            ops.state_embed_grad(tmp, Wt, c0, W, gb, g_embed)
 
     # ------------------------------------------------------------------ planes path (ops.GEMM_PLANES)
     PLANES_MIN_WIDTH = int(os.environ.get("HOS_PLANES_MIN_WIDTH", "256"))
@@ -423,16 +424,18 @@ class MipNeRF360MLP(FlatModule):
         nl = len(self._layers)
         g_density = None if g_density is None else g_density.contiguous().view(-1)
         if self.disable_rgb:
-            dyh = torch.zeros(P, 32, device=dev)
-            ops.head_grad(g_density, density, None, None, 0.0, dyh, 0, None)
+            dyh = torch.empty(P, 32, device=dev)
+            ops.head_grad_padded(g_density, density, None, None, 0.0, dyh, 0, None)     # writes the zero padding too
         else:
             Xv, hv = saved[2], saved[3]
             bw = self.bottleneck_width
             NC = self.netwidth_condition
             g_rgb = None if g_rgb is None else g_rgb.contiguous().view(-1, 3)
-            dz_rgb = torch.zeros(P, 32, device=dev)
-            dyh = torch.zeros(P, XV_LD, device=dev)
-            ops.head_grad(g_density, density, g_rgb, rgb, self.rgb_padding, dyh, bw, dz_rgb)
+            # operand rows [bottleneck gradient (written by the view layer's dgrad below) | density | 0 ...] and [rgb 3 | 0 ...]:
+            # the padding columns are written by the head-gradient launch, not by a fill of the whole [P, 288] / [P, 32] matrices
+            dz_rgb = torch.empty(P, 32, device=dev)
+            dyh = torch.empty(P, XV_LD, device=dev)
+            ops.head_grad_padded(g_density, density, g_rgb, rgb, self.rgb_padding, dyh, bw, dz_rgb)
             Wt, _ = self._w(self._rgb)
             gW, gb = self._w(self._rgb, grad=True)
             ops.linear_wgrad(dz_rgb, hv, gW, gb, 3, NC)
@@ -449,22 +452,21 @@ class MipNeRF360MLP(FlatModule):
         dz = ops.Planes.empty(P, W, torch.bfloat16, dev)
         ops.linearp_dgrad(dyhP, sv.WT[-1], Hs.Npad, P, W, mask=sv.y16[-1], dX=dz)
         embed_cols = []
+        tmps = ops.zeros_many([(self._layers[0].Npad,)] * (1 + len(self._skip_consumers)), dev)      # one launch for the bias-gradient temporaries
         for i in range(nl - 1, -1, -1):
             L = self._layers[i]
             Wt, _ = self._w(L)
             gW, gb = self._w(L, grad=True)
             inp_b = sv.yb[i - 1] if i > 0 else sv.Xb
             if i in self._skip_consumers:
-                tmp = torch.zeros(L.Npad, device=dev)
+                tmp = tmps.pop()
                 ops.linearp_wgrad(dz, inp_b, gW, tmp, P, W, W)
                 ops.linearp_wgrad(dz, sv.Xb, gW, None, P, W, X_LD, w_col0=W)
-                gb += tmp
-                embed_cols.append((tmp, Wt, W + POS_FEATS))
+                embed_cols.append((tmp, Wt, W + POS_FEATS, gb))
             elif i == 0:
-                tmp = torch.zeros(L.Npad, device=dev)
+                tmp = tmps.pop()
                 ops.linearp_wgrad(dz, sv.Xb, gW, tmp, P, W, X_LD)
-                gb += tmp
-                embed_cols.append((tmp, Wt, POS_FEATS))
+                embed_cols.append((tmp, Wt, POS_FEATS, gb))
             else:
                 ops.linearp_wgrad(dz, inp_b, gW, gb, P, W, W)
             if i > 0:
@@ -472,8 +474,8 @@ class MipNeRF360MLP(FlatModule):
                 ops.linearp_dgrad(dz, sv.WT[i], W, P, W, mask=sv.y16[i - 1], dX=dz_prev)
                 dz = dz_prev
         g_embed = self._embeds.view(self.store.grad)[state]
-        for tmp, Wt, c0 in embed_cols:
-            g_embed += tmp[:W] @ Wt[:W, c0:c0 + EMBED]
+        for tmp, Wt, c0, gb in embed_cols:       # gb += db and g_embed += db @ W[:, embed columns], one launch per layer
+            ops.state_embed_grad(tmp, Wt, c0, W, gb, g_embed)
 
     # ------------------------------------------------------------------ reference-style forward
     def forward(self, gaussians, viewdirs, randomized, is_train, time):
@@ -482,6 +484,14 @@ class MipNeRF360MLP(FlatModule):
         (means, covs) tensors of the reference are never materialised."""
         tdist, rays_o, rays_d, radii = gaussians
         return self.query(tdist, rays_o, rays_d, radii, viewdirs, float(time))
+
+    def _zero_rgb(self, B: int, S: int, dev):
+        """The all-zero colours a proposal MLP reports (M:347-349, `disable_rgb`): a constant, cached per shape (read-only)."""
+        key = (B, S, str(dev))
+        cache = getattr(self, "_zero_rgb_cache", None)
+        if cache is None or cache[0] != key:
+            self._zero_rgb_cache = cache = (key, torch.zeros(B, S, 3, device=dev))
+        return cache[1]
 
     def query(self, tdist, rays_o, rays_d, radii, viewdirs, time: float) -> Dict[str, torch.Tensor]:
         B, S = tdist.shape[0], tdist.shape[1] - 1
@@ -497,7 +507,7 @@ class MipNeRF360MLP(FlatModule):
         else:
             density, rgb, _ = self._forward_impl(X, viewdirs, B, S, save=False)
         density = density.view(B, S)
-        rgb = torch.zeros(B, S, 3, device=density.device) if self.disable_rgb else rgb.view(B, S, 3)
+        rgb = self._zero_rgb(B, S, density.device) if self.disable_rgb else rgb.view(B, S, 3)
         return {"density": density, "rgb": rgb}
 
 
@@ -585,6 +595,15 @@ class MipNeRF360(FlatModule):
 
     gemm_mode = None      # None: the process default (ops.set_gemm_mode); ops.GEMM_* pins the arithmetic of this module's GEMMs
 
+    def _level0(self, B: int, dev):
+        """The level-0 histogram of M:446-448 (constants): cached per (B, device) instead of three fills + a cat per call."""
+        key = (B, str(dev))
+        cache = getattr(self, "_level0_cache", None)
+        if cache is None or cache[0] != key:
+            sd = torch.cat([torch.zeros(B, 1, device=dev), torch.ones(B, 1, device=dev)], dim=-1)
+            self._level0_cache = cache = (key, sd, torch.ones(B, 1, device=dev))
+        return cache[1], cache[2]
+
     def forward(self, batch, train_frac, randomized, is_train, near, far, jitters=None, want_index: bool = False):
         """`self.gemm_mode` (None = the process default, ops.set_gemm_mode) selects the arithmetic of THIS module's GEMMs;
         without autograd the fp16 range guard may set it to exact fp32 (ops.guarded_forward)."""
@@ -602,8 +621,7 @@ class MipNeRF360(FlatModule):
         # the reference branches on `time` in python (M:230) = one host sync per call; pass a python float to avoid it
         time = float(times.reshape(-1)[0]) if isinstance(times, torch.Tensor) else float(times)
 
-        sdist = torch.cat([torch.zeros(B, 1, device=dev), torch.ones(B, 1, device=dev)], dim=-1)
-        weights = torch.ones(B, 1, device=dev)
+        sdist, weights = self._level0(B, dev)                                    # M:446-448: sdist = [0, 1], weights = [1]
         prod = 1
         # M:459-460.  `train_frac` may be a 1-element device tensor: the anneal factor is then evaluated inside the resampling
         # kernel, so a step captured once in a hipGraph keeps annealing as training advances (no host value baked in)

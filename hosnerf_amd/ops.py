@@ -141,6 +141,78 @@ def zero1(device) -> torch.Tensor:
     return _ZERO1[key]
 
 
+def _table(ptrs, ctype=None):
+    import ctypes
+    ctype = ctypes.c_void_p if ctype is None else ctype
+    return (ctype * len(ptrs))(*ptrs)
+
+
+def copy_or_zero_n(dsts, srcs=None):
+    """dsts[i][...] = srcs[i] (None: zeros) for up to 8 contiguous fp32 tensors per launch (hos_copy_or_zero_n): fills of
+    accumulation targets, stacks of small per-frame tensors -- one launch per group instead of one torch launch per tensor."""
+    import ctypes
+    for i0 in range(0, len(dsts), 8):
+        d = dsts[i0:i0 + 8]
+        sr = [None] * len(d) if srcs is None else srcs[i0:i0 + 8]
+        for a, b in zip(d, sr):
+            if b is not None and b.numel() != a.numel():
+                raise _lib.HosLibraryError("copy_or_zero_n: size mismatch")
+        call("hos_copy_or_zero_n", len(d), _table([ptr(t) for t in d]), _table([ptr(t) for t in sr]),
+             _table([t.numel() for t in d], ctypes.c_longlong))
+
+
+def zeros_many(shapes, device, dtype=torch.float32):
+    """Zeroed fp32 tensors of the given shapes out of ONE allocation and ONE library launch (sizes rounded to 16 bytes so every
+    view stays aligned)."""
+    sizes = [(int(np.prod(sh)) + 3) // 4 * 4 for sh in shapes]
+    buf = torch.empty(sum(sizes), device=device, dtype=dtype)
+    copy_or_zero_n([buf])
+    out, o = [], 0
+    for sh, n in zip(shapes, sizes):
+        out.append(buf[o:o + int(np.prod(sh))].view(sh))
+        o += n
+    return out
+
+
+def zeros(shape, device):
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    return zeros_many([shape], device)[0]
+
+
+def zero_(t: torch.Tensor):
+    copy_or_zero_n([t])
+    return t
+
+
+def add_n(ts):
+    """sum of up to 8 same-shaped contiguous fp32 tensors in one launch."""
+    import ctypes
+    out = torch.empty_like(ts[0])
+    call("hos_add_n", len(ts), _table([ptr(t.contiguous()) for t in ts]), ts[0].numel(), ptr(out))
+    return out
+
+
+class _Fanout(torch.autograd.Function):
+    """x -> n aliases of x for n consumers; the backward sums their cotangents in ONE launch (autograd's own accumulation is one
+    add launch per extra consumer)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        return (gs[0] if len(gs) == 1 else add_n(gs)), None
+
+
+def fanout(x: torch.Tensor, n: int):
+    return _Fanout.apply(x, n) if (n > 1 and x.requires_grad and torch.is_grad_enabled()) else (x,) * n
+
+
 def canonical_fold_pack(W0, b0, W5, b5, embed, n_out, nf, nh, out):
     """`out` = (W0f [n_out, nfp], b0f [n_out], W5f [n_out, nfp + nh], b5f [n_out]), see hos_canonical_fold_pack."""
     call("hos_canonical_fold_pack", ptr(W0), W0.stride(0), ptr(b0), ptr(W5), W5.stride(0), ptr(b5), ptr(embed), n_out, nf, embed.numel(), nh,
@@ -417,6 +489,29 @@ def range_events(device, reset: bool = True) -> int:
     return v
 
 
+_RANGE_SKIPS = {}
+
+
+def range_guard_words(device):
+    """(guard word, skipped-steps counter) for hos_adam_multi, or (None, None) when the guard is off.  The word is the library's
+    range flag (registered here if it was not yet): the forward epilogues of a training step OR it, the optimiser launch of the
+    same step reads it.  Never allocates while a graph is being captured (a captured fill would clear the word on every replay)."""
+    if not RANGE_GUARD:
+        return None, None
+    key = str(device)
+    if key not in _RANGE_FLAG or key not in _RANGE_SKIPS:
+        if torch.cuda.is_current_stream_capturing():
+            return None, None
+        arm_range_flag(device)
+        _RANGE_SKIPS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _RANGE_FLAG[key], _RANGE_SKIPS[key]
+
+
+def range_skips(device) -> int:
+    t = _RANGE_SKIPS.get(str(device))
+    return 0 if t is None else int(t.item())
+
+
 def guarded_forward(module, device, run):
     """Run `run()` (a no-grad forward of `module`); if the fp16 range flag fires, switch the module to exact-fp32 MFMA for good
     (`module.gemm_mode = GEMM_FP32`) and run it again.  Costs one 4-byte device read per call; only used without autograd
@@ -488,7 +583,7 @@ class _Deconv3d(torch.autograd.Function):
         g = g.contiguous()
         in_place = weight.grad is not None and weight.grad.is_contiguous()
         db_in_place = in_place and bias.grad is not None and bias.grad.is_contiguous()
-        db = bias.grad if db_in_place else torch.zeros(Cout, device=g.device)
+        db = bias.grad if db_in_place else zeros(Cout, g.device)
         # LeakyReLU backward + bias gradient: one pass (was where / mul / sum / add: 4 torch launches per layer, the [32768, 27]
         # column sum alone 88 us)
         dpre = torch.empty_like(g) if leaky else g
@@ -504,7 +599,7 @@ class _Deconv3d(torch.autograd.Function):
             dx = torch.empty(M, Cin, device=g.device)
             call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(Wm), Wm.stride(0), ptr(dx), dx.stride(0), M, Cin, Cout * 64)
         with gemm_mode(GEMM_FP32):
-            gW = weight.grad.view(Cin, Cout * 64) if in_place else torch.zeros(Cin, Cout * 64, device=g.device)
+            gW = weight.grad.view(Cin, Cout * 64) if in_place else zeros((Cin, Cout * 64), g.device)
             if M <= 8:       # a few voxels against 33-134 MB of weights: outer-product stream, not a tiled GEMM (at 64 voxels the
                              # tiled GEMM wins: 28 vs 67 us, scripts/bench_decoder.py)
                 call("hos_outer_accum", ptr(x), x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW), gW.stride(0), M, Cin, Cout * 64)
@@ -544,13 +639,13 @@ class _Deconv3dFirst(torch.autograd.Function):
         x, bias, out = ctx.saved_tensors
         wc, gwc = ctx.wc, ctx.gwc
         Cin, N8 = wc.shape
-        dpre = torch.where(out > 0, g, 0.2 * g) if ctx.leaky else g
-        dpre = dpre.contiguous()
-        if bias.grad is not None and bias.grad.is_contiguous():
-            bias.grad.add_(dpre.sum(0))
-            db = None
-        else:
-            db = dpre.sum(0)
+        g = g.contiguous()
+        Cout = N8 // 8
+        db_in_place = bias.grad is not None and bias.grad.is_contiguous()
+        db = None if db_in_place else zeros(Cout, g.device)
+        dpre = torch.empty_like(g) if ctx.leaky else g
+        call("hos_deconv3d_dpre", ptr(g), ptr(out), 8, Cout, 0.2, int(ctx.leaky), ptr(dpre) if ctx.leaky else None,
+             ptr(bias.grad if db_in_place else db))
         dycol = dpre.view(1, N8)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -562,6 +657,100 @@ class _Deconv3dFirst(torch.autograd.Function):
 
 def deconv3d_first(x: torch.Tensor, wc: torch.Tensor, gwc: torch.Tensor, bias: torch.Tensor, leaky: bool) -> torch.Tensor:
     return _Deconv3dFirst.apply(x, wc, gwc, bias, leaky)
+
+
+class _DecoderHead(torch.autograd.Function):
+    """h [1, N] = LeakyReLU(0.2)(W [N, K] . e [K] + b): `block_mlp` of the volume decoder on its constant embedding
+    (network_util.py:21-30, deconv_vol_decoder.py:36-37) -- one row-dot launch (was F.linear -> a library GEMM, + leaky_relu);
+    the backward accumulates into the parameters' flat gradients in place when they alias them."""
+
+    @staticmethod
+    def forward(ctx, emb, weight, bias):
+        N, K = weight.shape
+        y = torch.empty(1, N, device=emb.device)
+        call("hos_rowdot_lrelu_fwd", ptr(emb.detach().contiguous()), ptr(weight.detach()), weight.stride(0), ptr(bias.detach()), N, K, 0.2, ptr(y))
+        ctx.save_for_backward(emb, weight, bias, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, weight, bias, y = ctx.saved_tensors
+        N, K = weight.shape
+        g = g.contiguous()
+        ok = lambda p_: p_.grad is not None and p_.grad.is_contiguous()
+        in_place = ok(emb) and ok(weight) and ok(bias)
+        if in_place:
+            gW, gb, gx = weight.grad, bias.grad, emb.grad
+        else:
+            gW, gb, gx = zeros_many([(N, K), (N,), (K,)], g.device)
+        call("hos_rowdot_lrelu_bwd", ptr(g), ptr(y), ptr(emb.detach().contiguous()), ptr(weight.detach()), weight.stride(0), N, K, 0.2,
+             ptr(gW), gW.stride(0), ptr(gb), ptr(gx))
+        return (None, None, None) if in_place else (gx, gW, gb)
+
+
+def decoder_head(emb, weight, bias):
+    return _DecoderHead.apply(emb, weight, bias)
+
+
+class _VolumeSoftmax(torch.autograd.Function):
+    """vol [C, V, V, V] = softmax_c(z [V^3, C] + log prior) (deconv_vol_decoder.py:38-42): one launch each way (was log, add,
+    softmax on a transposed view + their three backward launches and a clone)."""
+
+    @staticmethod
+    def forward(ctx, z, prior):
+        V3, C = z.shape
+        V = round(V3 ** (1.0 / 3.0))
+        z = z.contiguous()
+        vol = torch.empty(C, V, V, V, device=z.device)
+        call("hos_volume_softmax_fwd", ptr(z), ptr(prior.detach().contiguous().float()), C, V3, ptr(vol))
+        ctx.save_for_backward(vol)
+        return vol
+
+    @staticmethod
+    def backward(ctx, g):
+        vol, = ctx.saved_tensors
+        C = vol.shape[0]
+        V3 = vol.numel() // C
+        gz = torch.empty(V3, C, device=vol.device)
+        g = g.contiguous()
+        call("hos_volume_softmax_bwd", ptr(g), ptr(vol), C, V3, ptr(gz))
+        return gz, None
+
+
+def volume_softmax(z, prior):
+    return _VolumeSoftmax.apply(z, prior)
+
+
+class _VolumePair(torch.autograd.Function):
+    """vol [C, V, V, V] -> (vol, vol_cl [V, V, V, 32]): the channel-major volume the backward warp samples per bone and the
+    channel-last copy of its first K bone channels for the forward warp (all bones at one position).  The backward forms the
+    volume's gradient from both consumers in one launch (was slice + permute + pad, their backward and an accumulation add)."""
+
+    @staticmethod
+    def forward(ctx, vol, K):
+        C, V = vol.shape[0], vol.shape[-1]
+        vol = vol.contiguous()
+        cl = torch.empty(V, V, V, 32, device=vol.device)
+        call("hos_volume_channel_last", ptr(vol), K, V * V * V, ptr(cl))
+        ctx.dims = (C, K, V)
+        ctx.set_materialize_grads(False)
+        return vol.view_as(vol), cl
+
+    @staticmethod
+    def backward(ctx, g_vol, g_cl):
+        if g_vol is None and g_cl is None:
+            return None, None
+        C, K, V = ctx.dims
+        ref = g_vol if g_vol is not None else g_cl
+        g = torch.empty(C, V, V, V, device=ref.device)
+        g_vol = None if g_vol is None else g_vol.contiguous()
+        g_cl = None if g_cl is None else g_cl.contiguous()
+        call("hos_volume_pair_bwd", ptr(g_vol), ptr(g_cl), C, K, V * V * V, ptr(g))
+        return g, None
+
+
+def volume_pair(vol, K: int):
+    return _VolumePair.apply(vol, K)
 
 
 # ------------------------------------------------------------------------------------------ rays
@@ -743,6 +932,19 @@ def distortion_loss_per_ray(t, w):
     return _Distortion.apply(t.detach().contiguous(), w.contiguous())
 
 
+def head_grad_padded(g_density, density, g_rgb, rgb, rgb_padding, dz_density, col_dd, dz_rgb):
+    """head_grad that also zeroes the padding columns of its two operand rows (which may be uninitialised storage)."""
+    P = density.numel()
+    call("hos_head_grad_padded", ptr(g_density), ptr(density), ptr(g_rgb), ptr(rgb), P, float(rgb_padding),
+         ptr(dz_density), 0 if dz_density is None else dz_density.stride(0), col_dd,
+         ptr(dz_rgb), 0 if dz_rgb is None else dz_rgb.stride(0))
+
+
+def state_embed_grad(db, W, c0, N, gb, g_embed):
+    """gb[:N] += db[:N] (gb None: skip); g_embed += db[:N] @ W[:N, c0:c0+len(g_embed)] -- one launch (was add_ + mm + add_)."""
+    call("hos_state_embed_grad", ptr(db), ptr(W), W.stride(0), c0, N, g_embed.numel(), ptr(gb), ptr(g_embed))
+
+
 def head_grad(g_density, density, g_rgb, rgb, rgb_padding, dz_density, col_dd, dz_rgb):
     P = density.numel()
     call("hos_head_grad", ptr(g_density), ptr(density), ptr(g_rgb), ptr(rgb), P, float(rgb_padding),
@@ -753,6 +955,27 @@ def head_grad(g_density, density, g_rgb, rgb, rgb_padding, dz_density, col_dd, d
 # ------------------------------------------------------------------------------------------ optimiser
 def sumsq(g: torch.Tensor, out: torch.Tensor):
     call("hos_sumsq", ptr(g), g.numel(), ptr(out))
+
+
+def sumsq_blocks() -> int:
+    return int(_lib.load().hos_sumsq_blocks())
+
+
+def sumsq_partials(spans, partial: torch.Tensor):
+    """partial[:sumsq_blocks()] = per-block sums of squares over all `spans` (<= 8 fp32 tensors, numel % 4 == 0), one launch."""
+    import ctypes
+    call("hos_sumsq_partials", len(spans), _table([ptr(t) for t in spans]), _table([t.numel() for t in spans], ctypes.c_longlong), ptr(partial))
+
+
+def adam_multi(spans, step: int, beta1: float, beta2: float, eps: float, grad_scale: float, partial, max_norm: float, guard=(None, None)):
+    """torch.optim.Adam over up to 8 spans in one launch.  spans: (p, g, m, v, hyper | None, lr) -- hyper: device [3] row
+    {lr, 1-b1^t, 1/sqrt(1-b2^t)} (graph replay), else lr / `step` from the host.  guard: (range word, skipped counter) or Nones."""
+    import ctypes
+    n = len(spans)
+    col = lambda i: _table([ptr(sp[i]) for sp in spans])
+    call("hos_adam_multi", n, col(0), col(1), col(2), col(3), _table([sp[0].numel() for sp in spans], ctypes.c_longlong),
+         col(4), _table([float(sp[5]) for sp in spans], ctypes.c_float), int(step), float(beta1), float(beta2), float(eps),
+         float(grad_scale), ptr(partial), float(max_norm), ptr(guard[0], torch.int32), ptr(guard[1], torch.int32))
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, sumsq_buf=None, max_norm=0.0):
@@ -833,7 +1056,7 @@ class _Raw2Outputs(torch.autograd.Function):
         B, S = z_vals.shape
         g_rs = torch.empty_like(rgbsigma)
         g_mask = torch.empty(B, S, device=z_vals.device) if mask is not None else None
-        g_rgb = torch.zeros_like(rgbsigma[:, 0, :3]) if g_rgb is None else g_rgb.contiguous()     # locals keep the cotangents alive until the launch is enqueued
+        g_rgb = zeros((rgbsigma.shape[0], 3), rgbsigma.device) if g_rgb is None else g_rgb.contiguous()     # locals keep the cotangents alive until the launch is enqueued
         g_w = None if g_w is None else g_w.contiguous()
         call("hos_raw2outputs_bwd", ptr(g_rgb), ptr(g_w), ptr(rgbsigma), 4,
              ptr(rgbsigma) + 12, 4, ptr(z_vals), ptr(rays_d), ptr(mask), ptr(bgcolor), ctx.last_dist, B, S,
@@ -877,7 +1100,7 @@ class _MergeComposite(torch.autograd.Function):
         g_bden = torch.empty_like(bkg_density)
         g_h = torch.empty_like(human)
         g_m = torch.empty_like(mask)
-        g_rgb = torch.zeros(B, 3, device=mask.device) if g_rgb is None else g_rgb.contiguous()
+        g_rgb = zeros((B, 3), mask.device) if g_rgb is None else g_rgb.contiguous()
         g_hw = None if g_hw is None else g_hw.contiguous()
         call("hos_merge_composite_bwd", ptr(g_rgb), ptr(g_hw),
              ptr(tdist), ptr(bkg_rgb), ptr(bkg_density), ptr(human), ptr(pts), ptr(mask), ptr(ro), ptr(rd), ptr(A),
@@ -891,7 +1114,8 @@ def merge_composite(bkg_tdist, bkg_rgb, bkg_density, human_rgbsigma, newsmpl_pts
     total_order [B,Sb+Sh] int32, z_human [B,Sh]).  No host synchronisation: the `any |d| < 1e-5` test of M:1526
     stays on the device."""
     rd = rays_d_bkg.contiguous()
-    tiny = (rd.abs() < 1e-5).any().to(torch.int32).reshape(1)
+    tiny = torch.empty(1, dtype=torch.int32, device=rd.device)
+    call("hos_any_abs_below", ptr(rd), rd.numel(), 1e-5, ptr(tiny, torch.int32))
     return _MergeComposite.apply(bkg_rgb.contiguous(), bkg_density.contiguous(), human_rgbsigma.contiguous(),
                                  pts_mask.contiguous(), bkg_tdist.contiguous(), newsmpl_pts.contiguous(),
                                  rays_o_bkg.contiguous(), rd, newsmpl_to_scale_world.contiguous().float(), tiny, thre_fg)
@@ -927,8 +1151,8 @@ class _PoseRefine(torch.autograd.Function):
     def backward(ctx, gR, gT):
         Rs, posevec, saved = ctx.saved_tensors
         F_, K, width = ctx.dims
-        gR = torch.zeros_like(Rs) if gR is None else gR.contiguous()
-        gT = torch.zeros(F_, K, 3, device=Rs.device) if gT is None else gT.contiguous()
+        gR = zeros(tuple(Rs.shape), Rs.device) if gR is None else gR.contiguous()
+        gT = zeros((F_, K, 3), Rs.device) if gT is None else gT.contiguous()
         ws = torch.empty(F_, int(_lib.load().hos_pose_refine_workspace_floats()), device=Rs.device)
         call("hos_pose_refine_bwd", ptr(gR), ptr(gT), ptr(posevec), ptr(Rs), ptr(saved), _ptr_array(ctx.weights), _ptr_array(ctx.grads),
              F_, K, width, ptr(ws))
@@ -1085,13 +1309,7 @@ def train_losses(rgb, target, mse_const=0.0, mse_count=None, pts_prev=None, weig
 def _zeros_like_many(*ts):
     """Zeroed accumulators shaped like `ts` out of ONE allocation and ONE fill launch (every launch of a replayed step costs
     4-5 us whatever its size; sizes are rounded to 16 bytes so that every view stays aligned)."""
-    sizes = [(t.numel() + 3) // 4 * 4 for t in ts]
-    buf = torch.zeros(sum(sizes), device=ts[0].device, dtype=ts[0].dtype)
-    out, o = [], 0
-    for t, n in zip(ts, sizes):
-        out.append(buf[o:o + t.numel()].view(t.shape))
-        o += n
-    return out
+    return zeros_many([tuple(t.shape) for t in ts], ts[0].device, ts[0].dtype)
 
 
 class _UnbindFrames(torch.autograd.Function):
@@ -1117,6 +1335,55 @@ def unbind_frames(x: torch.Tensor):
     return _UnbindFrames.apply(x)
 
 
+class _UnbindFramesMany(torch.autograd.Function):
+    """(x_0 [F, ...], ..., x_{m-1} [F, ...]) -> the F per-frame views of each, frame-major per tensor.  Backward: ONE launch stacks
+    (or zero-fills) all m x F cotangents into one allocation (per tensor that was a torch.stack + a zero fill per missing frame)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.set_materialize_grads(False)
+        out = []
+        for x in xs:
+            out += [x[f] for f in range(x.shape[0])]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return (None,) * len(ctx.shapes)
+        dev = next(g for g in gs if g is not None).device
+        outs = [torch.empty(sh, device=dev) for sh in ctx.shapes] if len(ctx.shapes) > 8 else None
+        sizes = [int(np.prod(sh)) for sh in ctx.shapes]
+        buf = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), device=dev)
+        outs, o = [], 0
+        for sh, n in zip(ctx.shapes, sizes):
+            outs.append(buf[o:o + n].view(sh))
+            o += (n + 3) // 4 * 4
+        dsts, srcs, k = [], [], 0
+        for x_out in outs:
+            for f in range(x_out.shape[0]):
+                dsts.append(x_out[f])
+                g = gs[k]
+                srcs.append(None if g is None else g.contiguous())
+                k += 1
+        copy_or_zero_n(dsts, srcs)
+        return tuple(outs)
+
+
+def unbind_frames_many(*xs):
+    """Per-frame views of several [F, ...] tensors: returns a list of tuples, one per tensor."""
+    F_ = xs[0].shape[0]
+    if F_ == 1 or not (torch.is_grad_enabled() and any(x.requires_grad for x in xs)):
+        return [tuple(x[f] for f in range(x.shape[0])) for x in xs]
+    flat = _UnbindFramesMany.apply(*xs)
+    out, k = [], 0
+    for x in xs:
+        out.append(tuple(flat[k:k + x.shape[0]]))
+        k += x.shape[0]
+    return out
+
+
 SAMPLE_WARP_BWD_REUSE = os.environ.get("HOS_SAMPLE_WARP_BWD_REUSE", "1") == "1"   # A/B switch: backward reads the forward's x_skel / mask
 
 
@@ -1139,8 +1406,8 @@ class _SampleWarp(torch.autograd.Function):
         K = ctx.K
         P = pts.shape[0] * pts.shape[1]
         g_vol, g_R, g_T = _zeros_like_many(vol, R, T)
-        gx = torch.zeros(P, 3, device=pts.device) if g_xskel is None else g_xskel.contiguous()
-        gm = torch.zeros(P, device=pts.device) if g_mask is None else g_mask.contiguous()
+        gx = zeros((P, 3), pts.device) if g_xskel is None else g_xskel.contiguous()
+        gm = zeros(P, pts.device) if g_mask is None else g_mask.contiguous()
         scratch = torch.empty(P, 2, device=pts.device)
         call("hos_human_sample_warp_bwd", ptr(pts), ptr(R), ptr(T), ptr(vol), vol.shape[-1], ptr(bmin), ptr(bscale), P, K,
              ptr(gx), ptr(gm), ptr(g_vol), ptr(g_R), ptr(g_T), ptr(scratch),
@@ -1179,6 +1446,14 @@ def lbs_forward_ad(cnl, vol_cl, R_f, T_f, bmin, bscale, K: int = 26, rows_dev=No
 def embed_bwd(x, band_w, num_freqs, identity, dA, colA, dB, colB, g_x, accumulate, rows_dev=None):
     call("hos_embed_bwd", ptr(x), ptr(band_w), num_freqs, int(identity), ptr(dA), dA.stride(0), colA,
          ptr(dB), 0 if dB is None else dB.stride(0), colB, x.shape[0], ptr(g_x), int(accumulate), ptr(rows_dev, torch.int32))
+
+
+def embed_bwd_res(x, band_w, num_freqs, identity, dA, colA, dB, colB, res, rows_dev=None):
+    """g_x [P,3] = res + d(features)/dx in one launch (rows past *rows_dev: res alone) -- no clone of the residual cotangent."""
+    g_x = torch.empty(x.shape[0], 3, device=x.device)
+    call("hos_embed_bwd_res", ptr(x), ptr(band_w), num_freqs, int(identity), ptr(dA), dA.stride(0), colA,
+         ptr(dB), 0 if dB is None else dB.stride(0), colB, x.shape[0], ptr(res), ptr(g_x), ptr(rows_dev, torch.int32))
+    return g_x
 
 
 def slice_mask(src, col0, mask_src, mcol0, width, out, rows_dev=None):

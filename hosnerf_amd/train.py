@@ -52,6 +52,8 @@ def allreduce_flat_grad_async(module: FlatModule, group=None, ranges=None) -> li
     the volume decoder's backward under the gradient exchange of the other parameters (bench.py, N > 1)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return []
+    if ranges is None and getattr(module.store, "inactive", None):
+        ranges = module.store.active_spans()
     if ranges is None:
         return [dist.all_reduce(module.flat_grad, group=group, async_op=True)]
     return [dist.all_reduce(module.flat_grad[off:off + n], group=group, async_op=True) for off, n in ranges if n > 0]
@@ -68,6 +70,8 @@ def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
         return 1
     world = dist.get_world_size(group)
     if world > 1:
+        if ranges is None and getattr(module.store, "inactive", None):
+            ranges = module.store.active_spans()      # never-written spans (all zeros) are not worth exchanging
         if ranges is None:
             dist.all_reduce(module.flat_grad, group=group)
         else:
@@ -102,6 +106,23 @@ class GradClip:
             for off, n in o.module.store.active_spans():          # the whole buffer unless the module has inactive spans
                 ops.sumsq(g[off:off + n], self._buf)
         return self._buf
+
+    def partials(self, opts) -> Optional[torch.Tensor]:
+        """Round 4: the same norm as per-block partial sums of ALL participating spans in ONE launch (hos_sumsq_partials: fixed
+        order, no atomics, nothing to zero first); `ops.adam_multi` adds them.  None when clipping is off or a span is unaligned."""
+        if self.max_norm <= 0:
+            return None
+        spans = []
+        for o in opts:
+            g = o.module.flat_grad
+            spans += [g[off:off + n] for off, n in o.module.store.active_spans()]
+        if len(spans) > 8 or any((t.numel() % 4) or (t.data_ptr() % 16) for t in spans):
+            return None
+        dev = spans[0].device
+        if getattr(self, "_partials", None) is None or self._partials.device != dev:
+            self._partials = torch.empty(ops.sumsq_blocks(), device=dev)
+        ops.sumsq_partials(spans, self._partials)
+        return self._partials
 
 
 def _minus_inactive(lr_ranges, module: FlatModule):
@@ -195,6 +216,8 @@ class FusedAdam:
             self.exp_avg, self.exp_avg_sq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device)
             self._hyper = None
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
+        if clip_sumsq is False and _step_multi([self], [lr], dynamic):         # norm + Adam of this module as two launches
+            return
         sumsq = self.clip.sumsq([self]) if clip_sumsq is False else clip_sumsq      # after the exchange: the norm of the SUMMED gradient
         if dynamic:
             p = self.module.flat_param
@@ -222,6 +245,57 @@ class FusedAdam:
         self.step_count = int(sd["step"])
 
 
+MULTI_ADAM = __import__("os").environ.get("HOS_MULTI_ADAM", "1") != "0"     # A/B switch: 0 = one norm / Adam launch per span (round 3)
+
+
+def _step_multi(opts, lrs, dynamic: bool) -> bool:
+    """The whole optimiser step of `opts` (already reduced gradients) as TWO launches: the joint gradient norm of every active span
+    (hos_sumsq_partials) and torch.optim.Adam over every learning-rate range of every module (hos_adam_multi), which also
+    consumes the fp16 range-guard word: a step whose forward left the exact hi/lo range updates nothing (train.range_skips counts).
+    Returns False when the step does not fit that form (CPU tensors, > 8 spans, unaligned ranges, separate clip objects)."""
+    if not MULTI_ADAM or not opts or not opts[0].module.flat_param.is_cuda:
+        return False
+    clip = opts[0].clip
+    if not all(o.clip is clip for o in opts):
+        return False
+    world = opts[0].world_size()
+    spans = []
+    for o, l in zip(opts, lrs):
+        p, g = o.module.flat_param, o.module.flat_grad
+        if o.exp_avg.device != g.device:
+            o.exp_avg, o.exp_avg_sq = o.exp_avg.to(g.device), o.exp_avg_sq.to(g.device)
+            o._hyper = None
+        if dynamic and o._hyper is None:
+            return False
+        l = o.lr if l is None else l
+        for r, (off, n, mult) in enumerate(o.lr_ranges or [(0, p.numel(), 1.0)]):
+            if n % 4 or off % 4:
+                return False
+            spans.append((p[off:off + n], g[off:off + n], o.exp_avg[off:off + n], o.exp_avg_sq[off:off + n],
+                          o._hyper[r] if dynamic else None, float(l) * mult))
+    if len(spans) > 8 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
+        return False
+    partial = clip.partials(opts)
+    if clip.max_norm > 0 and partial is None:
+        return False
+    if not dynamic:
+        for o in opts:
+            o.step_count += 1
+        if any(o.step_count != opts[0].step_count for o in opts):
+            for o in opts:
+                o.step_count -= 1
+            return False
+    dev = spans[0][0].device
+    ops.adam_multi(spans, opts[0].step_count if not dynamic else 0, opts[0].betas[0], opts[0].betas[1], opts[0].eps, 1.0 / world,
+                   partial, clip.max_norm, ops.range_guard_words(dev))
+    return True
+
+
+def range_skips(device) -> int:
+    """Number of optimiser steps the device-side range guard has skipped so far (one 4-byte read: poll it rarely)."""
+    return ops.range_skips(device)
+
+
 def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
     """The optimiser step of a training step that owns several flat modules (stage 3: background + human; the reference has
     ONE torch Adam over both, optimizer.py:19-60, and Lightning clips ONE norm over it): (1) every flat gradient that was
@@ -236,6 +310,8 @@ def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
         if not (r or o.grad_is_reduced):
             allreduce_flat_grad(o.module, o.group)
         o.grad_is_reduced = False
+    if _step_multi(opts, lrs, dynamic):
+        return
     clip = opts[0].clip
     shared = all(o.clip is clip for o in opts)
     for o, l in zip(opts, lrs):
@@ -453,6 +529,8 @@ def check_range(modules, device) -> bool:
     ops.arm_range_flag(device)
     if not ops.range_events(device):
         return False
+    # the optimiser kernel has been skipping every step since the flag fired (hos_adam_multi's guard): nothing saturated reached
+    # the parameters; from here on the modules run in exact fp32 MFMA and the re-armed flag lets the updates through again
     for m in modules:
         m.gemm_mode = ops.GEMM_FP32
     return True

@@ -596,6 +596,53 @@ int hos_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, c
                       float beta1, float beta2, float eps, float grad_scale, const float* sumsq,
                       float max_norm, hos_stream_t stream);
 
+/* ---- round 4: the remaining torch / library launches of a captured training step as library kernels ---------------------- */
+/* Head of the motion-weight volume decoder: y [N] = LeakyReLU(W [N, ldw] . x [K] + b [N]) -- `block_mlp` of ConvDecoder3D on the
+ * learned constant embedding (network_util.py:21-30, deconv_vol_decoder.py:36-37; was F.linear -> a library GEMM + leaky_relu). */
+int hos_rowdot_lrelu_fwd(const float* x, const float* W, int ldw, const float* b, int N, int K, float slope, float* y,
+                         hos_stream_t stream);
+/* its backward: gW [N, ldgw] += d x^T, gb [N] += d (NULL: skip), gx [K] += W^T d (NULL: skip), d = g * (y > 0 ? 1 : slope). */
+int hos_rowdot_lrelu_bwd(const float* g, const float* y, const float* x, const float* W, int ldw, int N, int K, float slope,
+                         float* gW, int ldgw, float* gb, float* gx, hos_stream_t stream);
+/* Tail of the decoder: vol [C, V3] = softmax over c of (z [V3, C] + log prior [C, V3]), C <= 32 (deconv_vol_decoder.py:38-42:
+ * `F.softmax(decoded_weights + torch.log(motion_weights_priors), dim=1)`); backward gz [V3, C] = vol (g - sum_c g vol). */
+int hos_volume_softmax_fwd(const float* z, const float* prior, int C, long long V3, float* vol, hos_stream_t stream);
+int hos_volume_softmax_bwd(const float* g_vol, const float* vol, int C, long long V3, float* gz, hos_stream_t stream);
+/* vol_cl [V3, 32] = the first Kb channels of vol [C, V3], channel-last and zero padded (the forward warp N:357-399 taps all bones at
+ * one position); hos_volume_pair_bwd: g [C, V3] = g_vol (NULL: 0) + the channel-major scatter of g_cl [V3, 32] (NULL: 0). */
+int hos_volume_channel_last(const float* vol, int Kb, long long V3, float* vol_cl, hos_stream_t stream);
+int hos_volume_pair_bwd(const float* g_vol, const float* g_cl, int C, int Kb, long long V3, float* g, hos_stream_t stream);
+/* n <= 8 buffers in one launch: dst[s][0 .. count[s]) = src[s] (src == NULL or src[s] == NULL: zeros).  Fills of accumulation
+ * targets, stacks of per-frame tensors.  The tables are read during the call.  (plumbing; no reference counterpart) */
+int hos_copy_or_zero_n(int n, float* const* dst, const float* const* src, const long long* count, hos_stream_t stream);
+/* out[i] = sum_k src[k][i], n <= 8: the gradient of a tensor that feeds several consumers in one pass. */
+int hos_add_n(int n, const float* const* src, long long count, float* out, hos_stream_t stream);
+/* flag[0] = any |x[i]| < thr (M:1526, the tiny-direction test of the stage-3 re-projection, kept on the device). */
+int hos_any_abs_below(const float* x, long long n, float thr, int32_t* flag, hos_stream_t stream);
+/* gb [N] += db (NULL: skip); g_embed [E <= 64] += db [N] . W [N, ldw][:, c0 : c0 + E]: gradient of the per-call state embedding
+ * through the first / skip layer of a MipNeRF360MLP (M:295-296). */
+int hos_state_embed_grad(const float* db, const float* W, int ldw, int c0, int N, int E, float* gb, float* g_embed, hos_stream_t stream);
+/* hos_embed_bwd added to a residual cotangent: g_x [P, 3] = res + d(features)/dx (rows past *rows_dev: res alone); g_x may be
+ * uninitialised (mlp_offset.py:66-70, xyz = x + offset). */
+int hos_embed_bwd_res(const float* x, const float* band_w, int num_freqs, int identity, const float* dA, int lda, int colA,
+                      const float* dB, int ldb, int colB, int64_t P, const float* res, float* g_x, const int32_t* rows_dev,
+                      hos_stream_t stream);
+/* hos_head_grad that also writes the zero padding of its operand rows: columns (col_dd, ld_dd) of dz_density and [3, ld_dr) of dz_rgb. */
+int hos_head_grad_padded(const float* g_density, const float* density, const float* g_rgb, const float* rgb, int P, float rgb_padding,
+                         float* dz_density, int ld_dd, int col_dd, float* dz_rgb, int ld_dr, hos_stream_t stream);
+/* Gradient norm + Adam of a whole training step in TWO launches, whatever the number of flat buffers / learning-rate ranges.
+ * hos_sumsq_partials: partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 8 spans (count % 4 == 0), fixed order,
+ * nothing to zero first (`Trainer(gradient_clip_val=..., "norm")`, S1/run.py:155, 3rd_.../run.py:188-189).
+ * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 8 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
+ * from device memory hyper[s] (graph replay) or, if NULL, from lr[s] / step; clip coefficient min(max_norm / (sqrt(sum partial) *
+ * |grad_scale| + 1e-6), 1) when partial != NULL; guard (the word of hos_set_range_flag, NULL: off): non-zero -> no parameter is
+ * touched and *skipped is incremented -- a forward whose activations left the exact fp16 hi/lo range never reaches Adam. */
+int hos_sumsq_blocks(void);
+int hos_sumsq_partials(int n, const float* const* g, const long long* count, float* partial, hos_stream_t stream);
+int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
+                   const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
+                   const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
