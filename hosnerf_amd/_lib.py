@@ -92,6 +92,11 @@ PROTOTYPES = {
     "hos_mlp_chain_pack_fold": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "hos_mlp_chain_unfold_grad": [_P, _P, _P, _I, _I, _P, _I, _P, _P],
     "hos_mlp_chain128_fwd": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _P],
+    "hos_mlp_chain_bwd_steps": [_I],
+    "hos_mlp_chain_bwd_image_bytes": [_I, _I],
+    "hos_mlp_chain_bwd_ws_floats": [_I, _I],
+    "hos_mlp_chain_bwd_pack": [_I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "hos_mlp_chain_bwd": [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     "hos_mlp_chain256_weight_bytes": [],
     "hos_mlp_chain256_aux_floats": [],
     "hos_mlp_chain256_pack": [_P, _P, _P, _P, _P, _P],
@@ -131,7 +136,8 @@ _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "ho
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
              "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
              "hos_mlp_chain_aux_floats": c_int64, "hos_mlp_chain256_weight_bytes": c_int64,
-             "hos_mlp_chain256_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64}
+             "hos_mlp_chain256_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64,
+             "hos_mlp_chain_bwd_image_bytes": c_int64, "hos_mlp_chain_bwd_ws_floats": c_int64}
 
 _lib = None
 

@@ -571,6 +571,32 @@ class Network(FlatModule):
             # gradient buffers of the folded first layer: [128, 64] for the hann columns of W0 + [128] for the folded bias
             gfold = ops.zero_(ops.fold_grad_workspace(dev))
             gw0h, db0 = gfold[:128 * 64].view(128, 64), gfold[128 * 64:]
+        if (fold is not None and fused and ops.MLP_CHAIN_BWD and Pn >= ops.MLP_CHAIN_BWD_MIN_ROWS
+                and ops.get_gemm_mode() != ops.GEMM_FP32):
+            # Three group launches (hos_mlpbwd.hip, chain_bwd_kernel): the gradient with respect to a layer's output stays in LDS
+            # between the layers of a group; only the hand-overs (dz4, dz2), the hann-column gradients and the activations move.
+            Wm = [self._w(L)[0] for L in specs]
+            G = [self._w(L, grad=True) for L in specs]
+            im = ops.mlp_chain_bwd_images(id(specs), (0, 1, 2), dev)
+            ops.mlp_chain_bwd_pack([
+                (0, 0, Wm[6], 0, 3, 128, im[0][0]), (0, 1, Wm[5], 0, 128, 128, im[0][1]),
+                (1, 0, Wm[4], 128, 128, NR_LDPE, im[1][0]), (1, 1, Wm[4], 0, 128, 128, im[1][1]), (1, 2, Wm[3], 0, 128, 128, im[1][2]),
+                (2, 0, Wm[2], 0, 128, 128, im[2][0]), (2, 1, Wm[1], 0, 128, 128, im[2][1]), (2, 2, fold[0], 0, 128, NR_LDPE, im[2][2])])
+            dz4 = torch.empty(Pn, 128, device=dev)
+            dz2 = torch.empty(Pn, 128, device=dev)
+            dPE = torch.empty(Pn, NR_LDPE, device=dev)
+            dE = torch.empty(Pn, NR_LDPE, device=dev)
+            with ops.deferred_bwd_reduce():      # the eight slab reductions as one launch at the end
+                ops.mlp_chain_bwd(0, dz6, [acts[5], acts[4]], im[0], [None, dz4], [G[6][0], G[5][0]], [0, 0], [G[6][1], G[5][1]],
+                                  [3, 128], [128, 128], rows_dev=rows_dev)
+                ops.mlp_chain_bwd(1, dz4, [PE, acts[3], acts[2]], im[1], [dPE, None, dz2], [G[4][0], G[4][0], G[3][0]], [128, 0, 0],
+                                  [None, G[4][1], G[3][1]], [128, 128, 128], [NR_LDPE, 128, 128], rows_dev=rows_dev)
+                ops.mlp_chain_bwd(2, dz2, [acts[1], acts[0], PE], im[2], [None, None, dE], [G[2][0], G[1][0], gw0h], [0, 0, 0],
+                                  [G[2][1], G[1][1], db0], [128, 128, 128], [128, 128, NR_LDPE], rows_dev=rows_dev)
+            res = g_xyz.contiguous()
+            gW0, gb0 = self._w(specs[0], grad=True)
+            ops.mlp_chain_unfold_grad(gw0h, db0, fold[1], 6 * band_w.numel(), gW0, gb0)
+            return ops.embed_bwd_res(x, band_w, band_w.numel(), False, dE, 0, dPE, 0, res, rows_dev=rows_dev)
         with ops.deferred_bwd_reduce():          # the seven slab reductions of this chain as one launch at the end
             dz = layer_bwd(dz6, acts[5], specs[6], 3, 128, torch.empty(Pn, 128, device=dev), True)
             dPE = dE = None

@@ -327,7 +327,7 @@ def _stream_key(device):
     return (str(d), torch.cuda.current_stream(d).cuda_stream if d.type == "cuda" else 0)
 
 
-def _bwd_workspace(device, M: int = 0, N: int = 0, K: int = 0, fused: bool = False) -> torch.Tensor:
+def _bwd_workspace(device, M: int = 0, N: int = 0, K: int = 0, fused: bool = False, need: Optional[int] = None) -> torch.Tensor:
     """Per-workgroup dW / db partials of hos_linear_bwd_fused / hos_linear_wgrad_tr: 256 slabs of up to 256 x 256 + 256 floats
     (67 MB) per call, one buffer per device -- launches on a stream are ordered and the reduce kernel that reads a call's slabs
     is enqueued by the same call.  Inside `deferred_bwd_reduce()` the reductions are postponed to one batched launch, so every
@@ -337,7 +337,9 @@ def _bwd_workspace(device, M: int = 0, N: int = 0, K: int = 0, fused: bool = Fal
         if key not in _BWD_WS:
             _BWD_WS[key] = torch.empty(256 * (256 * 256 + 256), device=device)
         return _BWD_WS[key][:256 * (256 * 256 + 256)]
-    need = max((int(_lib.load().hos_mlp_bwd_ws_floats(M, N, K, int(fused))) + 3) // 4 * 4, 4)
+    if need is None:
+        need = int(_lib.load().hos_mlp_bwd_ws_floats(M, N, K, int(fused)))
+    need = max((need + 3) // 4 * 4, 4)
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < max(need, BWD_DEFER_WS_FLOATS):
         _BWD_WS[key] = ws = torch.empty(max(need, BWD_DEFER_WS_FLOATS), device=device)      # (replaces the 67 MB buffer of the immediate mode)
@@ -395,6 +397,56 @@ def fold_grad_workspace(device) -> torch.Tensor:
     if key not in _FOLD_WS:
         _FOLD_WS[key] = torch.empty(128 * 64 + 128, device=device)
     return _FOLD_WS[key]
+# ---- backward of the non-rigid MLP as three group launches, dZ on chip between the layers of a group (hos_mlpbwd.hip, chain_bwd_kernel)
+MLP_CHAIN_BWD = os.environ.get("HOS_CHAIN_BWD", "1") != "0"
+MLP_CHAIN_BWD_MIN_ROWS = int(os.environ.get("HOS_CHAIN_BWD_MIN_ROWS", "16384"))
+_CB_IMAGES = {}
+
+
+def _int_array(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def mlp_chain_bwd_images(key, cfgs, device):
+    """One int16 buffer per (cfg, step) of the groups `cfgs`, cached per (key, device, stream)."""
+    lib = _lib.load()
+    k = (key, tuple(cfgs)) + _stream_key(device)
+    bufs = _CB_IMAGES.get(k)
+    if bufs is None:
+        bufs = _CB_IMAGES[k] = [[torch.empty(int(lib.hos_mlp_chain_bwd_image_bytes(c, s)) // 2, dtype=torch.int16, device=device)
+                                 for s in range(int(lib.hos_mlp_chain_bwd_steps(c)))] for c in cfgs]
+    return bufs
+
+
+def mlp_chain_bwd_pack(jobs):
+    """jobs: [(cfg, step, W [rows, ld] fp32 view, w_col0, N, K, image)], at most 8 per launch."""
+    for i in range(0, len(jobs), 8):
+        js = jobs[i:i + 8]
+        import ctypes
+        Wp = (ctypes.c_void_p * len(js))(*[ptr(j[2]) + 4 * j[3] for j in js])
+        call("hos_mlp_chain_bwd_pack", len(js), _int_array([j[0] for j in js]), _int_array([j[1] for j in js]), Wp,
+             _int_array([j[2].stride(0) for j in js]), _int_array([j[4] for j in js]), _int_array([j[5] for j in js]),
+             (ctypes.c_void_p * len(js))(*[ptr(j[6], torch.int16) for j in js]))
+
+
+def mlp_chain_bwd(cfg, dZ, X, images, dXout, dW, w_col0, db, N, K, rows_dev=None):
+    """One group of layer steps (include/hosrender.h: hos_mlp_chain_bwd).  Per step: X[s] input rows, images[s] packed weight,
+    dXout[s] (tensor for '-> HBM' steps, else None), dW[s] (+ w_col0[s]) / db[s] gradient views, N[s], K[s]."""
+    import ctypes
+    M = dZ.shape[0]
+    S = len(X)
+    need = int(_lib.load().hos_mlp_chain_bwd_ws_floats(cfg, M))
+    ws = _bwd_workspace(dZ.device, need=need)
+    flop = sum(4.0 * M * n * k for n, k in zip(N, K))
+    _timed(f"mlp_chain_bwd{cfg}[M={M}]", flop, lambda: call(
+        "hos_mlp_chain_bwd", cfg, ptr(dZ), dZ.stride(0), M, ptr(rows_dev, torch.int32), _ptr_array(list(X)), _int_array([x.stride(0) for x in X]),
+        (ctypes.c_void_p * S)(*[ptr(im, torch.int16) for im in images]), _ptr_array(list(dXout)),
+        _int_array([0 if o is None else o.stride(0) for o in dXout]),
+        (ctypes.c_void_p * S)(*[ptr(g) + 4 * c for g, c in zip(dW, w_col0)]), _int_array([g.stride(0) for g in dW]),
+        _ptr_array(list(db)), _int_array(N), _int_array(K), ptr(ws), ws.numel()))
+
+
 # the canonical (8 x 256) MLP as a chain launch too: correct (tests/test_gpu_chain.py) but measured no faster than its eight thin
 # launches (1.53 vs 1.51 ms per 262 144 rows: 320 operand + accumulator registers per lane leave one wave per SIMD and one
 # accumulator chain, so the MFMAs run at ~60 % and nothing hides the epilogues) -- off by default

@@ -519,6 +519,28 @@ int hos_mlp_chain128_fwd(const float* E, int lde, const float* PE, int ldpe, con
                          const float* aux, float* const* acts6, int ldact, float* xyz, int64_t P,
                          const int32_t* rows_dev, hos_stream_t stream);
 
+/* Backward of a GROUP of consecutive thin layers of that MLP in one launch (hos_mlpbwd.hip, chain_bwd_kernel): the gradient with
+ * respect to a layer's output stays in LDS between the layers of the group -- it replaces the chain of hos_linear_bwd_fused calls
+ * (autograd of core/nets/human_nerf/non_rigid_motion_mlps/mlp_offset.py:54-70), each of which wrote dX to HBM for the next one.
+ *   cfg 0: {offset head [3 (32) <- 128] -> chain, layer 5 [128 <- 128] -> HBM}
+ *   cfg 1: {skip concat's hann columns [128 <- 64] -> HBM, layer 4 [128 <- 128] -> chain, layer 3 -> HBM}
+ *   cfg 2: {layer 2 -> chain, layer 1 -> chain, folded layer 0 [128 <- 64] -> HBM};  cfg 3: the same with an unfolded layer 0 [128 <- 128]
+ *   cfg 4, 5: the MLP as two groups of four steps (register-pressure experiment)
+ * Per step s (HOST arrays of hos_mlp_chain_bwd_steps(cfg) entries): X[s] [M, ldx[s]] the layer's input rows (ReLU mask where the
+ * step has one), images[s] the weight as packed by hos_mlp_chain_bwd_pack (n <= 8 images per launch: HOST arrays of (cfg, step, W + col0,
+ * ldw, N, K, image)) into hos_mlp_chain_bwd_image_bytes(cfg, s) bytes (once per optimiser step), dXout[s] [M, lddx[s]] for "-> HBM" steps (NULL otherwise),
+ * dW[s] [N[s], lddw[s]] +=, db[s] [N[s]] += (NULL: no bias gradient).  dZ [M, lddz] enters the first step; rows_dev as in
+ * hos_mlp_chain128_fwd.  ws: hos_mlp_chain_bwd_ws_floats(cfg, M) floats of slab workspace; the slab reductions are deferrable like
+ * those of hos_linear_bwd_fused (hos_mlp_bwd_defer / hos_mlp_bwd_flush). */
+int hos_mlp_chain_bwd_steps(int cfg);
+long long hos_mlp_chain_bwd_image_bytes(int cfg, int step);
+long long hos_mlp_chain_bwd_ws_floats(int cfg, int M);
+int hos_mlp_chain_bwd_pack(int n, const int* cfg, const int* step, const float* const* W, const int* ldw, const int* N, const int* K,
+                           void* const* image, hos_stream_t stream);
+int hos_mlp_chain_bwd(int cfg, const float* dZ, int lddz, int M, const int32_t* rows_dev, const float* const* X, const int* ldx,
+                      const void* const* images, float* const* dXout, const int* lddx, float* const* dW, const int* lddw,
+                      float* const* db, const int* N, const int* K, float* ws, int64_t ws_floats, hos_stream_t stream);
+
 /* The canonical MLP the same way (`CanonicalMLP`, canonical_mlps/mlp_rgb_sigma.py:16-58: [fourier 63 | state 64] -> 8 x (256, ReLU),
  * the input re-concatenated in front of the activations before Linear #5 (383 wide) -> 4 -> sigmoid rgb, relu sigma N:539-540).
  *   hos_mlp_chain256_pack  weights9 / ldw9 / biases9: HOST arrays over pts_linears 0..7 + output_linear (fp32 [256 (4), ld]; layer 0

@@ -187,6 +187,43 @@ def test_folded_chain_backward_equals_the_row_form(net, P, n_live):
         assert e_fold < max(3.0 * e_rows, 1e-4), (k, e_fold, e_rows)
 
 
+@pytest.mark.parametrize("P,n_live", [(16384 + 77, None), (65536, None), (40000, 17777), (20000, 63)])
+def test_group_backward_equals_the_layer_launches(net, P, n_live):
+    """hos_mlp_chain_bwd (three group launches, dZ in LDS between the layers of a group) against the eight hos_linear_bwd_fused
+    launches it replaces: d loss / d x and every parameter gradient.  Same arithmetic (bf16 pairs, same product order), so the
+    input gradient must agree to rounding of the fp32 sums and the parameter gradients to the slab reduction's order."""
+    from hosnerf_amd.human_nerf import _NonRigidFn
+    x, cond, band = _inputs(P, seed=13)
+    g = torch.randn(P, 3, generator=torch.Generator().manual_seed(6)).to(DEV)
+    rows_dev = None if n_live is None else torch.tensor([n_live], dtype=torch.int32, device=DEV)
+    n = P if n_live is None else n_live
+    if n_live is not None:
+        g[n:] = 0
+    res = {}
+    prev = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS
+    try:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD_MIN_ROWS = True, 1, True, 1
+        for cb in (True, False):
+            ops.MLP_CHAIN_BWD = cb
+            net.zero_grad()
+            xx = x.clone().requires_grad_(True)
+            xyz = _NonRigidFn.apply(torch.zeros((), device=DEV, requires_grad=True), net, "nr", xx, cond, band, rows_dev)
+            xyz.backward(g)
+            torch.cuda.synchronize()
+            res[cb] = (xx.grad[:n].clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters() if k.startswith("non_rigid_mlp.")})
+    finally:
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS = prev
+        net.zero_grad()
+    gx, gx_ref = res[True][0], res[False][0]
+    assert torch.isfinite(gx).all()
+    assert float((gx - gx_ref).abs().max()) <= 1e-6 * float(gx_ref.abs().max()), float((gx - gx_ref).abs().max())
+    assert len(res[True][1]) == 14
+    for k, ref in res[False][1].items():
+        got = res[True][1][k]
+        scale = float(ref.abs().max()) + 1e-30
+        assert float((got - ref).abs().max()) <= 2e-6 * scale, (k, float((got - ref).abs().max()), scale)
+
+
 # ------------------------------------------------------------------------------------------------ canonical MLP (8 x 256)
 def _cnl_both(net, cnl, state):
     prev_c, prev_m, prev_2, prev_f = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256, ops.CNL_FOLD
