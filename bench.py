@@ -341,6 +341,48 @@ class Stage3(Workload):
         self.hos.human.finish_decoder_backward()
 
 
+class Stage3Fresh(Stage3):
+    """The stage-3 step with a NEW training item every step: a synthetic scene directory in the reference's
+    on-disk formats (`synth.write_scene_dir`) -> `dataset.SceneItems` builds each item on the device (two camera ray sets,
+    radii, the subject's box test, the random patch gather: hos_rays.hip + torch index ops; 26-joint pose algebra on the host)
+    -> the item's tensors are copied into the static batch of the captured step.  Everything `items[i]` does is inside the
+    timed region; the headline leg replays ONE resident batch instead."""
+    name = "stage3_fresh_items"
+    describe = ("stage-3 step at 4096 rays with the training item REBUILT every step from a scene directory (device-side rays / "
+                "box test / patch gather of dataset.SceneItems + copy into the captured step's batch), 192x192 synthetic frames")
+
+    def __init__(self, dev, rank, world, rays_global):
+        import shutil
+        import tempfile
+        from hosnerf_amd import formats, synth
+        from hosnerf_amd.dataset import SceneItems
+        Stage3.__init__(self, dev, rank, world, rays_global)
+        self.scene = tempfile.mkdtemp(prefix="hos_bench_scene_")
+        try:
+            H = W = 192
+            px = synth.write_scene_dir(self.scene, 16, H, W, seed=777)
+            formats.load_scene(self.scene, (H, W), masks=px["alphas"], near=0.1, far=1e6)
+            n_patches = max(1, self.rays_local // 1024)
+            self.ds = SceneItems(self.scene, px["images"], px["alphas"], px["flows"], n_patches=n_patches, patch_size=32, device=dev,
+                                 seed=777 + rank, bgcolor=[0.0, 0.0, 0.0])
+        finally:
+            shutil.rmtree(self.scene, ignore_errors=True)
+        # frames 8..15 lie behind the transition time 0.4 of the synthetic base directory: one state, flow supervision on
+        self.frames = list(range(8, 16))
+        first = self.ds[self.frames[0]]
+        drop = {"frame_name", "img_width", "img_height", "ray_mask", "ray_mask_bkg", "patch_div_indices", "rays_o_bkg_only",
+                "rays_d_bkg_only", "viewdirs_bkg_only", "radii_bkg_only"}
+        self.batch = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in first.items() if k not in drop}
+        self.batch["iter_val"] = 3e5
+        self.item_bytes = sum(v.numel() * v.element_size() for v in self.batch.values() if isinstance(v, torch.Tensor))
+
+    def host_prepare(self, i):
+        item = self.ds[self.frames[i % len(self.frames)]]
+        for k, dst in self.batch.items():
+            if isinstance(dst, torch.Tensor) and dst is not item.get(k):
+                dst.copy_(item[k], non_blocking=True)
+
+
 # ------------------------------------------------------------------------------------------------ timing
 def run_workload(wl, args, dev, rank, world, dist, want_events):
     """Warm up, capture, time exactly args.steps steps between barriers; returns (seconds [max over ranks], info dict)."""
@@ -614,11 +656,11 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
     on_gpu = device is not None
     dev = device if on_gpu else "cpu"
     if not on_gpu:
-        # torch's CPU GEMMs stop scaling (and oversubscribe badly) far below the 256 hardware threads of the GPU host: use
-        # the count that is fastest in practice and report exactly that
-        cores = min(os.cpu_count() or 1, int(os.environ.get("HOS_CPU_THREADS", "32")))
-        torch.set_num_threads(cores)
-        rays = 256 if stage == "stage1" else 128
+        # torch's CPU GEMMs stop scaling (and oversubscribe badly) far below the hardware threads of the GPU host: try a few
+        # thread counts on a 64-ray item, keep the fastest, and report exactly that next to the CPU model and the thread count
+        # the host offers
+        host_threads = os.cpu_count() or 1
+        rays = 256 if stage == "stage1" else 512
     if stage == "stage1":
         step = osteps.stage1_step(synth.background_state_dict(777, 2), synth.stage1_batch(rays, seed=777), device=dev)
     else:
@@ -627,6 +669,25 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
             step = osteps.stage2_step(synth.human_state_dict(777, 2), b, device=dev)
         else:
             step = osteps.stage3_step(synth.background_state_dict(777, 2), synth.human_state_dict(777, 2), b, device=dev)
+    if not on_gpu:
+        sweep, cores = {}, 1
+        tb = synth.add_patch_supervision(synth.human_batch(64, seed=778, time=0.5, is_train=True, iter_val=3e5), 1, 32, 778)
+        for th in sorted({min(host_threads, c) for c in (16, 32, 64, host_threads)}):
+            torch.set_num_threads(th)
+            if stage == "stage1":
+                st = osteps.stage1_step(synth.background_state_dict(777, 2), synth.stage1_batch(64, seed=778), device="cpu")
+            elif stage == "stage2":
+                st = osteps.stage2_step(synth.human_state_dict(777, 2), tb, device="cpu")
+            else:
+                st = osteps.stage3_step(synth.background_state_dict(777, 2), synth.human_state_dict(777, 2), tb, device="cpu")
+            dts, _ = _time_steps(st, 1, 1.5, 2)
+            sweep[str(th)] = round(64 / dts, 1)
+            del st
+        cores = int(max(sweep, key=lambda k: sweep[k]))
+        env = os.environ.get("HOS_CPU_THREADS")
+        if env:
+            cores = min(host_threads, int(env))
+        torch.set_num_threads(cores)
     if on_gpu:
         dt, n = _time_steps(step, 1, 4.0, 5, sync=torch.cuda.synchronize)
         del step
@@ -634,8 +695,25 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
         return {"value": rays / dt, "unit": "rays/s", "rays": rays, "steps": n,
                 "what": "the reference's op graph (oracle restatement) as PyTorch-ROCm ops on the same GPU: fp32 rocBLAS, autograd, torch Adam"}
     dt, n = _time_steps(step, 1, 12.0, 8)
+    full = {"stage1": 1024, "stage2": 2048, "stage3": GLOBAL_RAYS_S3}[stage]
     return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "workload": stage,
-            "sample": f"{n} timed step(s) of {rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads)"}
+            "cpu_model": cpu_model(), "host_threads": host_threads, "thread_sweep_rays_per_s": sweep,
+            "sample": f"{n} timed step(s) of {rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads = the fastest of "
+                      f"the thread counts tried on a 64-ray item, rays/s per count: {sweep}).  The full {full}-ray item was not run: at "
+                      f"this rate one step of it takes about {dt * full / rays:.0f} s (per-ray cost constant; its per-step work -- volume "
+                      f"decoder, Adam over all parameters -- is already inside every timed sample step)"}
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -672,13 +750,16 @@ def main():
         g = args.rays if (args.rays and args.primary == name) else (GLOBAL_RAYS_S3 if name == "stage3" else 2048)
         if g % world:
             raise SystemExit(f"{g} global rays do not divide over {world} ranks")
+        if name == "stage3_fresh_items":
+            return Stage3Fresh(dev, rank, world, args.rays if (args.rays and args.primary == "stage3") else GLOBAL_RAYS_S3)
         return (Stage3 if name == "stage3" else Stage2)(dev, rank, world, g)
 
     def measure(name, events):
         wl = make(name)
         dt, info, table = run_workload(wl, args, dev, rank, world, dist, events)
         rays_total = wl.rays_global * args.steps
-        flop_ray = FLOP_PER_RAY[name][0] + FLOP_PER_RAY[name][1] * info["f_cyc"]
+        fkey = "stage3" if name == "stage3_fresh_items" else name
+        flop_ray = FLOP_PER_RAY[fkey][0] + FLOP_PER_RAY[fkey][1] * info["f_cyc"]
         res = {"value": rays_total / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": wl.scaling,
                "rays_per_gpu": wl.rays_local, "global_rays": wl.rays_global, "workload": wl.describe,
                "grad_max_norm": GRAD_MAX_NORM, "flop_per_ray": flop_ray,
@@ -695,6 +776,13 @@ def main():
             if name == args.primary or (name == "stage2" and world > 1):
                 continue
             stages[name], _ = measure(name, False)
+        if args.primary == "stage3" and world == 1:
+            try:        # a secondary object must never cost the primary line
+                stages["stage3_fresh_items"], _ = measure("stage3_fresh_items", False)
+                stages["stage3_fresh_items"]["vs_resident_batch"] = stages["stage3_fresh_items"]["value"] / prim["value"]
+            except Exception as e:
+                stages["stage3_fresh_items"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize()
     infer = None
     if not args.only_primary and not args.no_infer and args.gemm == "planes":
         try:        # a secondary object must never cost the primary line

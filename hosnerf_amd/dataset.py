@@ -61,7 +61,15 @@ class SceneItems:
 
     def __init__(self, scene_dir: str, images, alphas, flows=None, frames: Optional[Sequence[str]] = None,
                  n_patches: int = 2, patch_size: int = 32, sample_subject_ratio: float = 0.8, bbox_offset: float = 0.6,
-                 volume_size: int = 32, resize_img_scale: float = 1.0, bgcolor=None, device="cuda", seed: Optional[int] = None):
+                 volume_size: int = 32, resize_img_scale: float = 1.0, bgcolor=None, device="cuda", seed: Optional[int] = None,
+                 stage: int = 3):
+        """`stage=2` builds the items of the stage-2 dataset (2nd_State_Conditional_Human-Object/core/data/human_nerf/train.py:
+        460-658): the frame is composited over the item's background colour with its alpha mask (T2:345), only the subject's
+        rays are kept (no background-branch rays, no `newsmpl_to_scale_world`), and a patch is CUT by the subject's box
+        (T2:321-332: ragged selection, `patch_masks` with holes, their pixels enter the MSE as background colour)."""
+        if stage not in (2, 3):
+            raise ValueError("stage must be 2 or 3")
+        self.stage = stage
         with open(os.path.join(scene_dir, "cameras_scaleworld.pkl"), "rb") as f:
             self.cameras = pickle.load(f)
         self.mesh_infos = formats.load_mesh_infos(os.path.join(scene_dir, "mesh_infos.pkl"), bbox_offset)
@@ -110,6 +118,8 @@ class SceneItems:
         H, W = int(img.shape[0]), int(img.shape[1])
         K, E, newsmpl_to_smpl = self._camera(name)
         cam = self.cameras[name]
+        if self.stage == 2:
+            return self._item_stage2(idx, name, time, flow_on, bg, img, H, W, K, E)
         item = frame_rays(H, W, K, E, self.mesh_infos[name]["bbox"], np.asarray(cam["scaleworld_to_camera"], dtype=np.float64), device=dev)
         rm = item["ray_mask"]
         item["ray_img"] = img.reshape(-1, 3)[rm]
@@ -124,6 +134,40 @@ class SceneItems:
         Rs, Ts, posevec = self._pose(name)
         host = {"dst_Rs": Rs, "dst_Ts": Ts, "dst_posevec": posevec, "bgcolor": bg,
                 "newsmpl_to_scale_world": (np.asarray(cam["smpl_to_scale_world"], dtype=np.float64) @ newsmpl_to_smpl).astype("float32"), **self._cnl}
+        if time > 0.005:
+            prev = self.frames[idx - 1]
+            Rp, Tp, pp = self._pose(prev)
+            Kp, Ep, _ = self._camera(prev)
+            host.update(dst_Rs_prev=Rp, dst_Ts_prev=Tp, dst_posevec_prev=pp, newsmpl_to_camera_prev=Ep.astype("float32"),
+                        intrinsics_prev=Kp.astype("float32"))
+        item.update({k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in host.items()})
+        item["motion_weights_priors"] = self._prior
+        item.update(frame_name=name, time=time, is_train=True)
+        return item
+
+
+    def _item_stage2(self, idx: int, name: str, time: float, flow_on: bool, bg, img, H: int, W: int, K, E) -> Dict:
+        """T2:460-658 with the per-pixel work on the device: composite, rays, box test, patch gather."""
+        dev = self.device
+        alpha = self.alphas[idx].to(dev)
+        bgc = torch.from_numpy(bg).to(dev) / 255.0
+        img = alpha[..., None] * img + (1.0 - alpha[..., None]) * bgc                       # T2:345 (+ the /255 of T2:479)
+        o, d = rays_mod.get_rays_from_KRT(H, W, K, E[:3, :3], E[:3, 3], device=dev)           # T2:501
+        o, d = o.reshape(-1, 3), d.reshape(-1, 3)
+        near, far, rm = rays_mod.rays_intersect_3d_bbox(self.mesh_infos[name]["bbox"], o, d)  # T2:509
+        item = {"img_width": W, "img_height": H, "ray_mask": rm, "rays": torch.stack([o[rm], d[rm]], 0),
+                "near": near[:, None], "far": far[:, None], "ray_img": img.reshape(-1, 3)[rm]}
+        if flow_on:
+            item["ray_grid"] = pixel_flow_grid(self.flows[idx].to(dev))[rm]
+        item = rays_mod.sample_patch_rays(item, img, alpha > 0.0, self.n_patches, self.patch_size, self.subject_ratio, self.rng,
+                                          cut_by_box=True)
+        item.pop("ray_img", None)
+        # constants of the patch MSE (`train.prepare_patch_targets`, M2:41-50): the cut pixels are filled with the background colour
+        pm, tp = item["patch_masks"], item["target_patches"]
+        item["mse_const"] = float((((bgc.expand(tp.shape) - tp) ** 2)[~pm]).sum())
+        item["mse_count"] = float(tp.numel())
+        Rs, Ts, posevec = self._pose(name)
+        host = {"dst_Rs": Rs, "dst_Ts": Ts, "dst_posevec": posevec, "bgcolor": bg, **self._cnl}
         if time > 0.005:
             prev = self.frames[idx - 1]
             Rp, Tp, pp = self._pose(prev)

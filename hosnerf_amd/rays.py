@@ -72,7 +72,7 @@ def rays_intersect_3d_bbox(bounds, ray_o: torch.Tensor, ray_d: torch.Tensor):
 
 # ------------------------------------------------------------------------------------------ training item: patches
 def get_patch_ray_indices(N_patch: int, ray_mask: torch.Tensor, subject_mask: torch.Tensor, bbox_mask: torch.Tensor,
-                          patch_size: int, H: int, W: int, sample_subject_ratio: float, rng=np.random):
+                          patch_size: int, H: int, W: int, sample_subject_ratio: float, rng=np.random, cut_by_box: bool = False):
     """`Dataset.get_patch_ray_indices` (core/data/human_nerf/train.py:225-332) with the masks resident on the device.
 
     The random decisions are the reference's, drawn from the same numpy stream in the same order (`rng.rand(1)`, then
@@ -98,6 +98,16 @@ def get_patch_ray_indices(N_patch: int, ray_mask: torch.Tensor, subject_mask: to
         y_min = torch.clamp(cy - P // 2, 0, H - P)
         pix.append(((y_min + dy) * W + (x_min + dx)).reshape(-1))
     pix = torch.cat(pix, 0)
+    if cut_by_box:
+        # STAGE 2 (2nd_State_Conditional_Human-Object/core/data/human_nerf/train.py:321-332): the patch rectangle is intersected
+        # with the rays that hit the subject's box -- the selection is ragged (its length is the one extra value read back per
+        # item), `patch_masks` marks the pixels that kept their ray and `patch_div_indices` delimits the patches
+        keep = ray_mask.reshape(-1).to(dev).bool()[pix]
+        patch_masks = keep.view(N_patch, P, P)
+        per = patch_masks.view(N_patch, -1).sum(1).cpu()
+        div = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(per, 0)])
+        pix_kept = pix[keep]
+        return masked_indices[pix_kept], pix, patch_masks, div
     sel = masked_indices[pix]
     sel = torch.where(sel < 0, sel + masked_indices[-1] + 1, sel)                      # numpy's negative index
     patch_masks = torch.ones(N_patch, P, P, dtype=torch.bool, device=dev)              # T:323, :330
@@ -109,15 +119,16 @@ _PATCH_KEYS = ("near", "far", "rays_o_bkg", "rays_d_bkg", "viewdirs_bkg", "radii
 
 
 def sample_patch_rays(item: dict, img: torch.Tensor, subject_mask: torch.Tensor, N_patches: int, patch_size: int,
-                      sample_subject_ratio: float, rng=np.random) -> dict:
+                      sample_subject_ratio: float, rng=np.random, cut_by_box: bool = False) -> dict:
     """`Dataset.sample_patch_rays` (T:410-436): pick the patches and gather every per-ray array of the item
     (`rays` [2,n,3] and the `_PATCH_KEYS` present, all box-compacted as `eval.frame_rays` returns them).  Returns the
     item with those arrays replaced by the selected rays plus `target_patches` [N,P,P,3], `patch_masks`,
-    `patch_div_indices` and `target_rgbs` (= the gathered `ray_img`)."""
+    `patch_div_indices` and `target_rgbs` (= the gathered `ray_img`).  `cut_by_box=True` is the stage-2 dataset's form
+    (S2 train.py:405-455): only the patch pixels whose rays hit the box are selected, `patch_masks` has holes."""
     H, W = int(item["img_height"]), int(item["img_width"])
     rm = item["ray_mask"]
     sel, pix, masks, div = get_patch_ray_indices(N_patches, rm, subject_mask, rm.view(H, W), patch_size, H, W,
-                                                 sample_subject_ratio, rng)
+                                                 sample_subject_ratio, rng, cut_by_box=cut_by_box)
     out = dict(item)
     out["rays"] = item["rays"].index_select(1, sel)
     for k in _PATCH_KEYS:

@@ -5,6 +5,8 @@ reference: `core/utils/camera_util.py` of stage 3 (`C:` below).  Imported only b
   rays_from_krt_bkg  C:185-216  get_rays_from_KRT_bkg   same + unit view directions + mip-NeRF radii (row differences)
   rays_aabb          C:219-265  rays_intersect_3d_bbox  six-plane AABB test, rays with exactly two hits, near/far
   patch_ray_indices  T:225-332  Dataset.get_patch_ray_indices  training item: random P x P patches -> ray indices
+  patch_ray_indices_s2  T2:215-332  the stage-2 dataset's form (2nd_State_Conditional_Human-Object/core/data/human_nerf/train.py):
+                                    the patch IS intersected with the box -> ragged selection, patch masks with holes
 """
 import numpy as np
 
@@ -69,5 +71,29 @@ def patch_ray_indices(N_patch, ray_mask, subject_mask, bbox_mask, patch_size, H,
         sels.append((np.cumsum(ray_mask) - 1)[np.where(m.reshape(-1))])              # T:322-328
         xy.append(np.array([x0, y0]))
         masks.append(m[y0:y0 + patch_size, x0:x0 + patch_size])
+        div.append(div[-1] + sels[-1].shape[0])
+    return np.concatenate(sels, 0), np.stack(xy, 0), np.stack(masks, 0), np.array(div)
+
+
+def patch_ray_indices_s2(N_patch, ray_mask, subject_mask, bbox_mask, patch_size, H, W, sample_subject_ratio, rng=np.random):
+    """T2:215-332 (`Dataset.get_patch_ray_indices` + `_get_patch_ray_indices` of STAGE 2).  Same random decisions as stage 3, but
+    the patch rectangle is intersected with the rays that hit the subject's box (T2:321-322): select_inds holds only those rays
+    (ragged, `patch_div_indices` delimits the patches) and the patch mask [P,P] marks the pixels that kept their ray (T2:329-332)."""
+    excl = np.bitwise_and(bbox_mask, np.bitwise_not(subject_mask))                   # T2:227-230
+    sels, xy, masks, div = [], [], [], [0]
+    masked_indices = np.cumsum(ray_mask) - 1                                         # T2:324
+    for _ in range(N_patch):
+        cand = subject_mask if rng.rand(1)[0] < sample_subject_ratio else excl       # T2:243-246
+        ys, xs = np.where(cand)                                                      # T2:286
+        k = rng.choice(ys.shape[0], size=[1], replace=False)[0]                      # T2:289-290
+        half = patch_size // 2
+        x0 = np.clip(xs[k] - half, 0, W - patch_size)                                # T2:296-303
+        y0 = np.clip(ys[k] - half, 0, H - patch_size)
+        m = np.zeros((H, W), dtype=bool)
+        m[y0:y0 + patch_size, x0:x0 + patch_size] = True                             # T2:305-306
+        inter = np.bitwise_and(m.reshape(-1), ray_mask)                              # T2:321
+        sels.append(masked_indices[np.where(inter)])                                 # T2:322-325
+        xy.append(np.array([x0, y0]))
+        masks.append(inter.reshape(H, W)[y0:y0 + patch_size, x0:x0 + patch_size])    # T2:327-330
         div.append(div[-1] + sels[-1].shape[0])
     return np.concatenate(sels, 0), np.stack(xy, 0), np.stack(masks, 0), np.array(div)

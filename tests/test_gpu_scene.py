@@ -63,3 +63,59 @@ def test_scene_directory_to_training_steps(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("[run] step")]
     assert len(lines) == 3 and all(np.isfinite(float(l.split("loss")[1].split()[0])) for l in lines), r.stdout[-2000:]
     assert "wrote" in r.stdout
+
+
+S2_KEYS = {"rays", "near", "far", "dst_Rs", "dst_Ts", "cnl_gtfms", "canonical_joints", "motion_weights_priors", "cnl_bbox_min_xyz",
+           "cnl_bbox_max_xyz", "cnl_bbox_scale_xyz", "dst_posevec", "bgcolor", "time", "is_train", "patch_masks", "target_patches",
+           "patch_div_indices", "target_rgbs", "ray_mask", "img_width", "img_height", "frame_name"}
+
+
+def test_scene_directory_to_stage2_items_and_steps(tmp_path):
+    """`SceneItems(stage=2)`: the items of the stage-2 dataset (S2 core/data/human_nerf/train.py:460-658) -- frame composited over
+    the item's background colour, the subject's rays only, patches CUT by the box (ragged selection) -- and two real stage-2
+    optimiser steps on them (in-network composite, patch MSE with the cut pixels as background colour, flow + cycle terms)."""
+    import json
+    from hosnerf_amd import formats, synth
+    from hosnerf_amd.dataset import SceneItems
+    from hosnerf_amd.human_nerf import Network, default_cfg
+    from hosnerf_amd.train import FusedAdam, human_lr_ranges, train_step_stage2
+    dev = torch.device("cuda")
+    scene = str(tmp_path / "scene")
+    H = W = 96
+    px = synth.write_scene_dir(scene, 16, H, W, seed=3)
+    formats.load_scene(scene, (H, W), masks=px["alphas"], near=0.1, far=1e6)
+    ds = SceneItems(scene, px["images"], px["alphas"], px["flows"], n_patches=6, patch_size=20, sample_subject_ratio=0.5, device=dev,
+                    seed=9, stage=2)
+    cut_items = 0
+    items = []
+    for i in (2, 5, 9, 12, 14):
+        it = ds[i]
+        assert S2_KEYS <= set(it) and FLOW_KEYS <= set(it), sorted((S2_KEYS | FLOW_KEYS) - set(it))
+        assert not ({"rays_o_bkg", "newsmpl_to_scale_world", "radii"} & set(it))
+        n = int(it["patch_masks"].sum())
+        assert it["rays"].shape == (2, n, 3) and it["near"].shape == (n, 1) and it["ray_grid"].shape == (n, 5)
+        assert int(it["patch_div_indices"][-1]) == n and it["target_patches"].shape == (6, 20, 20, 3)
+        # the selected rays ARE the patch pixels that hit the box, in patch order: their colours are the unmasked patch pixels
+        assert torch.equal(it["target_rgbs"], it["target_patches"][it["patch_masks"]])
+        # the composite: pixels outside the silhouette carry the item's background colour
+        bgc = it["bgcolor"] / 255.0
+        assert it["mse_count"] == 6 * 20 * 20 * 3
+        want = float((((bgc.expand(it["target_patches"].shape) - it["target_patches"]) ** 2)[~it["patch_masks"]]).sum())
+        assert abs(it["mse_const"] - want) <= 1e-5 * max(1.0, want)
+        cut_items += int(not bool(it["patch_masks"].all()))
+        items.append(it)
+    assert cut_items > 0, "no patch of the sample was cut by the subject's box"
+    d = str(tmp_path / "base")
+    os.makedirs(d)
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({"f0": {"time": 0.4}}, f)
+    net = Network(default_cfg(d), stage=2)
+    net.load_state_dict(synth.human_state_dict(777, 2), strict=True)
+    net = net.to(dev)
+    opt = FusedAdam(net, lr=1e-4, lr_ranges=human_lr_ranges(net, 1e-4, 1e-5))
+    for it in items[:2]:
+        batch = {k: v for k, v in it.items() if k not in ("frame_name", "ray_mask", "img_width", "img_height", "patch_div_indices")}
+        loss, parts = train_step_stage2(net, opt, batch, 1e-4)
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss) and all(torch.isfinite(v) for v in parts.values())
+    assert torch.isfinite(net.flat_param).all()

@@ -19,6 +19,11 @@ import oracle.losses as ol
 from hosnerf_amd import synth
 
 pytestmark = pytest.mark.gpu
+# Gradients of the pose / volume decoders against fp64: the bound is this factor times the fp32 oracle's own error (+ the discrete
+# floor).  Their gradients are near-total cancellations of terms the backward GEMMs carry as bf16 PAIRS (16-17 significant bits
+# per operand, where the fp32 graph has 24): the representation of the operands, not a missing product, sets the 2^7 ceiling;
+# measured factors are recorded (profiles/*parity_counts.json: stage2.decoder_gradients_vs_fp64).
+DECODER_GRAD_FACTOR = float(os.environ.get("HOS_DECODER_GRAD_FACTOR", "128"))
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -115,7 +120,7 @@ def test_stage2_step_vs_oracle(dev, net2):
         assert abs(float(parts[k]) - parts64[k]) < 3.0 * e_ref + 1e-5 * max(1e-3, abs(parts64[k])), (k, float(parts[k]), parts64[k])
     net2.scatter_compact_grads()           # the live taps of the first deconvolution layer -> its reference-shaped p.grad
     params = dict(net2.named_parameters())
-    seen, report = 0, {}
+    seen, report, ratios = 0, {}, []
     for n, t in grads["f64"].items():
         if t is None or float(t.abs().max()) == 0:
             continue
@@ -133,10 +138,15 @@ def test_stage2_step_vs_oracle(dev, net2):
             # measured ~1e-2 here against ~1e-3 for the fp32 graph (direction: cosine > 0.9999)
             a, t_ = params[n].grad.detach().double().cpu().reshape(-1), t.reshape(-1)
             cos = float((a @ t_) / (a.norm() * t_.norm() + 1e-30))
-            assert cos > 0.999 and e_hip < 128.0 * e_ref + 3e-3, (n, e_ref, e_hip, cos)
+            ratios.append(((e_hip - 3e-3) / max(e_ref, 1e-12), n, e_ref, e_hip))
+            assert cos > 0.999 and e_hip < DECODER_GRAD_FACTOR * e_ref + 3e-3, (n, e_ref, e_hip, cos)
         else:
             assert e_hip < 3.0 * e_ref + 3e-3, (n, e_ref, e_hip)
     assert seen >= 70
+    from tests._record import record
+    w = max(ratios)
+    record("stage2.decoder_gradients_vs_fp64", {"bound_factor": DECODER_GRAD_FACTOR, "worst_factor": w[0], "worst_param": w[1],
+                                                "fp32_oracle_rel_err": w[2], "hip_rel_err": w[3]})
     net2.zero_grad()
 
 

@@ -73,3 +73,49 @@ def test_host_patch_selection_matches_reference():
         assert np.array_equal(out["patch_div_indices"].numpy(), GP[f"s{s}_out_patch_div_indices"])
         assert torch.equal(out["target_rgbs"], out["rays"][0] + 1)
     assert saw_wrap, "fixture must contain a patch above the first box ray (index -1 wraps like numpy)"
+
+
+# ------------------------------------------------------------------ STAGE-2 patch selection (S2 train.py:215-455): cut by the box
+GP2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "patches_s2.npz"))
+
+
+def test_oracle_stage2_patch_indices_bit_exact():
+    H, W, P, N = (int(GP2[k]) for k in ("H", "W", "P", "N"))
+    bbox, subj, ratio = GP2["bbox_mask"], GP2["subject_mask"], float(GP2["ratio"])
+    cut = 0
+    for s in GP2["seeds"]:
+        np.random.seed(int(s))
+        sel, xy, masks, div = orays.patch_ray_indices_s2(N, bbox.reshape(-1), subj, bbox, P, H, W, ratio)
+        assert np.array_equal(sel, GP2[f"s{s}_select_inds"]) and np.array_equal(xy, GP2[f"s{s}_xy_min"])
+        assert np.array_equal(masks, GP2[f"s{s}_mask"]) and np.array_equal(div, GP2[f"s{s}_div"])
+        assert np.array_equal(np.random.rand(2), GP2[f"s{s}_rng_after"]), "numpy stream position after the call"
+        cut += int((~masks).sum())
+    assert cut > 0
+
+
+def test_host_stage2_patch_selection_matches_reference():
+    """hosnerf_amd.rays.sample_patch_rays(cut_by_box=True) on the reference's inputs: bit-exact ragged indices, gathered rays,
+    patch masks with holes, div indices, target patches and the numpy RNG stream position."""
+    import torch
+    from hosnerf_amd import rays as R
+    H, W, P, N = (int(GP2[k]) for k in ("H", "W", "P", "N"))
+    bbox, subj, ratio = GP2["bbox_mask"], GP2["subject_mask"], float(GP2["ratio"])
+    t = torch.from_numpy
+    item = {"img_height": H, "img_width": W, "ray_mask": t(bbox.reshape(-1)),
+            "rays": torch.stack([t(GP2["in_rays_o"]), t(GP2["in_rays_d"])], 0), "near": t(GP2["in_near"]), "far": t(GP2["in_far"]),
+            "ray_grid": t(GP2["in_ray_grid"]), "ray_img": t(GP2["in_ray_img"])}
+    for s in GP2["seeds"]:
+        np.random.seed(int(s))
+        sel, pix, masks, div = R.get_patch_ray_indices(N, item["ray_mask"], t(subj), t(bbox), P, H, W, ratio, cut_by_box=True)
+        assert np.array_equal(sel.numpy(), GP2[f"s{s}_select_inds"]) and np.array_equal(masks.numpy(), GP2[f"s{s}_mask"])
+        assert np.array_equal(div.numpy(), GP2[f"s{s}_div"])
+        assert np.array_equal(np.random.rand(2), GP2[f"s{s}_rng_after"])
+        np.random.seed(int(s))
+        out = R.sample_patch_rays(item, t(GP2["img"]), t(subj), N, P, ratio, cut_by_box=True)
+        assert np.array_equal(out["rays"][0].numpy(), GP2[f"s{s}_out_rays_o"]) and np.array_equal(out["rays"][1].numpy(), GP2[f"s{s}_out_rays_d"])
+        for k in ("ray_grid", "near", "far", "ray_img"):
+            assert np.array_equal(out[k].numpy(), GP2[f"s{s}_out_{k}"]), k
+        assert np.array_equal(out["target_patches"].numpy(), GP2[f"s{s}_out_target_patches"])
+        assert np.array_equal(out["patch_masks"].numpy(), GP2[f"s{s}_out_patch_masks"])
+        assert np.array_equal(out["patch_div_indices"].numpy(), GP2[f"s{s}_out_patch_div_indices"])
+        assert out["rays"].shape[1] == int(out["patch_masks"].sum())
