@@ -11,7 +11,9 @@ LIB   := hosnerf_amd/lib/libhosrender.so
 # what bounds any kernel).  tests/test_isa_hazards_cpu.py checks the built ISA for stragglers.
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result
 
-all: $(LIB)
+COMM  := hosnerf_amd/lib/libhoscomm.so
+
+all: $(LIB) $(COMM)
 
 build/%.o: hosnerf_amd/csrc/%.hip hosnerf_amd/csrc/hos_common.h hosnerf_amd/csrc/hos_gemm_common.h include/hosrender.h
 	@mkdir -p build
@@ -21,6 +23,12 @@ $(LIB): $(OBJ)
 	@mkdir -p hosnerf_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJ)
 
+# the collectives of the data-parallel step as a C ABI over RCCL (include/hoscomm.h); host code only, its own library so that
+# libhosrender.so does not depend on librccl.so
+$(COMM): hosnerf_amd/csrc_comm/hos_comm.cpp include/hoscomm.h
+	@mkdir -p hosnerf_amd/lib
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared -Iinclude -I/opt/rocm/include $< -o $@ -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(COMM)
 .PHONY: all clean

@@ -377,10 +377,17 @@ class Stage3Fresh(Stage3):
         self.item_bytes = sum(v.numel() * v.element_size() for v in self.batch.values() if isinstance(v, torch.Tensor))
 
     def host_prepare(self, i):
-        item = self.ds[self.frames[i % len(self.frames)]]
+        # the item is built on a side stream: SceneItems reads two candidate counts back per item, and on the step's stream that
+        # read would wait for the previous step's whole replay
+        if not hasattr(self, "side"):
+            self.side = torch.cuda.Stream()
+        with torch.cuda.stream(self.side):
+            item = self.ds[self.frames[i % len(self.frames)]]
+        torch.cuda.current_stream().wait_stream(self.side)
         for k, dst in self.batch.items():
             if isinstance(dst, torch.Tensor) and dst is not item.get(k):
                 dst.copy_(item[k], non_blocking=True)
+                item[k].record_stream(torch.cuda.current_stream())
 
 
 # ------------------------------------------------------------------------------------------------ timing
@@ -672,7 +679,9 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
     if not on_gpu:
         sweep, cores = {}, 1
         tb = synth.add_patch_supervision(synth.human_batch(64, seed=778, time=0.5, is_train=True, iter_val=3e5), 1, 32, 778)
-        for th in sorted({min(host_threads, c) for c in (16, 32, 64, host_threads)}):
+        # (all 256 hardware threads of this pool's host were tried once: 0.3 rays/s against 110 at 16 -- torch's intra-op pool
+        # oversubscribes; the sweep stops at 64)
+        for th in sorted({min(host_threads, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(th)
             if stage == "stage1":
                 st = osteps.stage1_step(synth.background_state_dict(777, 2), synth.stage1_batch(64, seed=778), device="cpu")

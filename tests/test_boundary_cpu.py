@@ -222,3 +222,17 @@ def test_first_deconv_layer_compact_copy_round_trips_through_state_dict():
     net.flat_grad.fill_(1.0)
     net.zero_grad()
     assert float(net.flat_grad[off:off + n].min()) == 1.0 and float(net.flat_grad[:off].abs().max()) == 0 and float(net.flat_grad[off + n:].abs().max()) == 0
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """libhoscomm.so (include/hoscomm.h, SURVEY 8(b).6: `hos_allreduce_*` over RCCL): loads without a GPU, exports every declared
+    entry point, and rejects null arguments without touching RCCL."""
+    from hosnerf_amd import comm
+    header = open(os.path.join(ROOT, "include", "hoscomm.h")).read()
+    declared = set(re.findall(r"\b(hos_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(comm.PROTOTYPES), declared ^ set(comm.PROTOTYPES)
+    lib = comm.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libhoscomm.so does not export {name}"
+    assert lib.hos_allreduce_avg_f32(0, 0, 16, 0) == -1 and lib.hos_comm_init(0, 2, 0, 0) == -1
+    assert lib.hos_allgather_f32(0, 0, 0, 4, 0) == -1 and lib.hos_allreduce_avg_f32_spans(0, 0, 0, 1, 0) == -1

@@ -324,7 +324,7 @@ def test_gradients_vs_oracle(dev, net):
     wf = max(((e_hip - 5e-3) / max(e_ref, 1e-12), n) for e_hip, e_ref, _, n in worst)
     record("human.gradients_vs_fp64[8 rays].worst_factor", {"factor": wf[0], "param": wf[1]})
     for e_hip, e_ref, cos, n in worst:
-        assert cos > 0.999 and e_hip <= 128.0 * e_ref + 5e-3, (n, cos, e_hip, e_ref)
+        assert cos > 0.999 and e_hip <= 16.0 * e_ref + 5e-3, (n, cos, e_hip, e_ref)        # measured worst factor: 2.5 (round 4)
     net.zero_grad()
 
 

@@ -21,9 +21,9 @@ from hosnerf_amd import synth
 pytestmark = pytest.mark.gpu
 # Gradients of the pose / volume decoders against fp64: the bound is this factor times the fp32 oracle's own error (+ the discrete
 # floor).  Their gradients are near-total cancellations of terms the backward GEMMs carry as bf16 PAIRS (16-17 significant bits
-# per operand, where the fp32 graph has 24): the representation of the operands, not a missing product, sets the 2^7 ceiling;
+# per operand, where the fp32 graph has 24): the representation of the operands, not a missing product, sets a 2^7 ceiling;
 # measured factors are recorded (profiles/*parity_counts.json: stage2.decoder_gradients_vs_fp64).
-DECODER_GRAD_FACTOR = float(os.environ.get("HOS_DECODER_GRAD_FACTOR", "128"))
+DECODER_GRAD_FACTOR = float(os.environ.get("HOS_DECODER_GRAD_FACTOR", "32"))      # measured worst factor: 10.4 (round 4)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
