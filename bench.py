@@ -549,8 +549,11 @@ def roofline_of(table, gemm):
         return None
     dom = max(table, key=lambda r: r["total_ms"])
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r03_pmc_gemmp_traffic.json")
-    if os.path.exists(tpath):
+    # the newest committed PMC pass whose kernel sources are the ones this library was built from
+    for tname in ("r04_pmc_gemmp_traffic.json", "r03_pmc_gemmp_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tpath) or traffic is not None:
+            continue
         with open(tpath) as f:
             tj = json.load(f)
         if tj.get("source_hash") == source_hash("hosnerf_amd/csrc/hos_gemmp.hip", "hosnerf_amd/csrc/hos_gemm_common.h", "Makefile"):

@@ -400,6 +400,7 @@ def fold_grad_workspace(device) -> torch.Tensor:
 # ---- backward of the non-rigid MLP as three group launches, dZ on chip between the layers of a group (hos_mlpbwd.hip, chain_bwd_kernel)
 MLP_CHAIN_BWD = os.environ.get("HOS_CHAIN_BWD", "1") != "0"
 MLP_CHAIN_BWD_MIN_ROWS = int(os.environ.get("HOS_CHAIN_BWD_MIN_ROWS", "16384"))
+MLP_CHAIN_BWD_GROUPS = int(os.environ.get("HOS_CHAIN_BWD_GROUPS", "3"))      # 2: the MLP as two groups of four steps (measured slower: spills)
 _CB_IMAGES = {}
 
 
@@ -421,9 +422,9 @@ def mlp_chain_bwd_images(key, cfgs, device):
 
 def mlp_chain_bwd_pack(jobs):
     """jobs: [(cfg, step, W [rows, ld] fp32 view, w_col0, N, K, image)], at most 8 per launch."""
+    import ctypes
     for i in range(0, len(jobs), 8):
         js = jobs[i:i + 8]
-        import ctypes
         Wp = (ctypes.c_void_p * len(js))(*[ptr(j[2]) + 4 * j[3] for j in js])
         call("hos_mlp_chain_bwd_pack", len(js), _int_array([j[0] for j in js]), _int_array([j[1] for j in js]), Wp,
              _int_array([j[2].stride(0) for j in js]), _int_array([j[4] for j in js]), _int_array([j[5] for j in js]),

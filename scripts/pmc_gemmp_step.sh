@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (rounds 2 and 3) of the planes GEMM at the shape of the primary bench line (M = 131072 = 4096 rays x 32 samples, N = K = 1024)
 # and at the stage-1 shape (M = 32768): HBM traffic (FETCH_SIZE, WRITE_SIZE) and MFMA busy cycles, separate passes, no tracing
-# domains combined with --pmc.  Writes gpurun_out/pmc_gemmp/r03_pmc_gemmp_traffic.json in the format bench.py reads
+# domains combined with --pmc.  Writes gpurun_out/pmc_gemmp/pmc_gemmp_traffic.json in the format bench.py reads
 # (keyed by bench.py's kernel names, with the hash of the kernel sources the library was built from).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -46,7 +46,7 @@ for GM in (131072, 32768):
                                "algorithmic_bytes_approx": alg,
                                "mfma_busy_cycles": mean("sq1_%d" % GM, tag, "SQ_VALU_MFMA_BUSY_CYCLES"), "insts_mfma": mean("sq1_%d" % GM, tag, "SQ_INSTS_MFMA"),
                                "gui_active_cycles": mean("sq1_%d" % GM, tag, "GRBM_GUI_ACTIVE")}
-json.dump(out, open(OUT + "/r03_pmc_gemmp_traffic.json", "w"), indent=1)
+json.dump(out, open(OUT + "/pmc_gemmp_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 cat $OUT/bench_131072.txt | head -8
