@@ -236,3 +236,20 @@ def test_comm_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libhoscomm.so does not export {name}"
     assert lib.hos_allreduce_avg_f32(0, 0, 16, 0) == -1 and lib.hos_comm_init(0, 2, 0, 0) == -1
     assert lib.hos_allgather_f32(0, 0, 0, 4, 0) == -1 and lib.hos_allreduce_avg_f32_spans(0, 0, 0, 1, 0) == -1
+
+
+def test_group_backward_entry_points_validate_without_gpu():
+    """hos_mlp_chain_bwd* (round 4): configuration tables and argument checks, no launch."""
+    from hosnerf_amd import _lib
+    lib = _lib.load()
+    assert [lib.hos_mlp_chain_bwd_steps(c) for c in range(6)] == [2, 3, 3, 3, 4, 4] and lib.hos_mlp_chain_bwd_steps(6) == -1
+    # LDS images: (hi, lo) planes of [N_][K_ + 16] bf16, rounded up to whole 8 KB copy rounds
+    assert lib.hos_mlp_chain_bwd_image_bytes(0, 0) == 24576 and lib.hos_mlp_chain_bwd_image_bytes(0, 1) == 73728
+    assert lib.hos_mlp_chain_bwd_image_bytes(1, 0) == 40960 and lib.hos_mlp_chain_bwd_image_bytes(2, 5) == 0
+    # slabs: 256 workgroups x sum over steps of (N_ * K_ + N_) floats from 16 384 rows on
+    assert lib.hos_mlp_chain_bwd_ws_floats(0, 262144) == 256 * ((32 * 128 + 32) + (128 * 128 + 128))
+    assert lib.hos_mlp_chain_bwd_ws_floats(2, 64) == 1 * (2 * (128 * 128 + 128) + (128 * 64 + 128))
+    assert lib.hos_mlp_chain_bwd_ws_floats(9, 64) == 0
+    assert lib.hos_mlp_chain_bwd_pack(0, 0, 0, 0, 0, 0, 0, 0, 0) == -1 and lib.hos_mlp_chain_bwd_pack(9, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert lib.hos_mlp_chain_bwd(0, 0, 32, 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+    assert lib.hos_mlp_chain_bwd(7, 0, 32, 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
