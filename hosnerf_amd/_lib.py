@@ -97,10 +97,6 @@ PROTOTYPES = {
     "hos_mlp_chain_bwd_ws_floats": [_I, _I],
     "hos_mlp_chain_bwd_pack": [_I, _P, _P, _P, _P, _P, _P, _P, _P],
     "hos_mlp_chain_bwd": [_I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
-    "hos_mlp_chain256_weight_bytes": [],
-    "hos_mlp_chain256_aux_floats": [],
-    "hos_mlp_chain256_pack": [_P, _P, _P, _P, _P, _P],
-    "hos_mlp_chain256_fwd": [_P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "hos_compact_workspace_ints": [],
     "hos_compact_rows": [_P, _F, _P, _P, _L, _P, _P, _P, _P, _P, _P],
     "hos_scatter_rows": [_P, _P, _P, _L, _P, _P],
@@ -135,8 +131,7 @@ PROTOTYPES = {
 _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "hos_train_losses_workspace_floats": c_int64,
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
              "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
-             "hos_mlp_chain_aux_floats": c_int64, "hos_mlp_chain256_weight_bytes": c_int64,
-             "hos_mlp_chain256_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64,
+             "hos_mlp_chain_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64,
              "hos_mlp_chain_bwd_image_bytes": c_int64, "hos_mlp_chain_bwd_ws_floats": c_int64}
 
 _lib = None

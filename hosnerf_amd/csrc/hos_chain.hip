@@ -368,218 +368,6 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(PackArgs p) {
 }
 
 
-// ================================================================================================================
-// The canonical MLP (`CanonicalMLP`, canonical_mlps/mlp_rgb_sigma.py:16-58): [fourier 63 | state 64] -> 8 x (256, ReLU) with the
-// input re-concatenated IN FRONT of the activations before Linear #5 (383 wide) -> 4 raw values -> sigmoid rgb, relu sigma
-// (N:539-540).  Same scheme as above with 24 operand slots per row: slots 0..7 hold the 127 + 1 input columns for the whole
-// tile (layers 0 and 5 read them), slots 8..23 the current 256 activations.  One workgroup per CU (128 accumulator + 192 operand
-// registers per lane), weight ring 2 x 48 KB.
-// ================================================================================================================
-constexpr int NL2 = 8;
-constexpr int CW2 = 256;
-constexpr int KS2MAX = 24;
-constexpr int CBUF2 = KS2MAX * 2 * 1024;
-constexpr int SKIP2 = 5;                        // the layer whose input is [emb | h]
-constexpr int CAT_LAYER = 4;                    // the layer whose output lands at column 127 of CAT (hos_linear_fwd's out_col0)
-__host__ __device__ constexpr int kbeg2(int l) { return (l == 0 || l == SKIP2) ? 0 : 8; }
-__host__ __device__ constexpr int kend2(int l) { return l == 0 ? 8 : 24; }
-__host__ __device__ constexpr int ks2(int l) { return kend2(l) - kbeg2(l); }
-__host__ __device__ constexpr int layer_off2(int l) {
-    int o = 0;
-    for (int i = 0; i < l; ++i) o += 8 * ks2(i) * 2048;
-    return o;
-}
-constexpr int WC2_BYTES = layer_off2(NL2);
-constexpr int AUX2_FLOATS = NL2 * CW2 + 4 * CW2 + 4;
-constexpr int AUX2_BYTES = (AUX2_FLOATS * 4 + 15) & ~15;
-
-struct Chain2Args {
-    const float* E; int lde;        // [P, >= 128]: [fourier 63 | state 64 | 0]
-    const uint16_t* Wc; const float* aux;
-    float* acts[NL2]; int ldact[NL2]; int col0[NL2];      // layer outputs (layer 4: CAT with column offset 127)
-    float* raw;                     // [P, 4] activated (sigmoid rgb, relu sigma)
-    long P; const int* p_dev; unsigned int* range_flag;
-};
-
-// (one request of the next chunk per k-step, between the MFMAs, as in the 128-wide kernel was measured WORSE here -- 1.83 vs
-// 1.53 ms per 262 144 rows: with one wave per SIMD and a single accumulator chain, every instruction between two dependent
-// MFMAs costs ~43 cycles; the requests are issued in one burst after the barrier instead)
-template <int KBEG, int KEND>
-__device__ __forceinline__ void chain2_kloop(f32x16& acc, const unsigned la, const h8 (&bh)[KS2MAX], const h8 (&bl)[KS2MAX]) {
-    h8 fh[2], fl[2];
-    CH_RD128(fh[0], la, 0);
-    CH_RD128(fl[0], la, 1024);
-#pragma unroll
-    for (int s = KBEG; s < KEND; ++s) {
-        const int j = s - KBEG;
-        if (s + 1 < KEND) {
-            CH_RD128(fh[(j + 1) & 1], la, (2 * j + 2) * 1024);
-            CH_RD128(fl[(j + 1) & 1], la, (2 * j + 3) * 1024);
-            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fh[j & 1]), "+v"(fl[j & 1]));
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fh[j & 1]), "+v"(fl[j & 1]));
-        }
-        acc = mfma3(fh[j & 1], fl[j & 1], bh[s], bl[s], acc);
-    }
-}
-
-__global__ __launch_bounds__(CT) void chain256_kernel(Chain2Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const wbuf = smem;
-    float* const s_aux = reinterpret_cast<float*>(smem + 2 * CBUF2);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    long P = a.P;
-    if (a.p_dev) P = min(P, (long)*a.p_dev);
-    for (int i = t; i < AUX2_FLOATS; i += CT) s_aux[i] = a.aux[i];
-    const long ntiles = (P + CROWS - 1) / CROWS;
-    if ((long)blockIdx.x >= ntiles) return;
-    const unsigned voff = (unsigned)(wave * 1024 + lane * 16);
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    // all requests of chunk (l, ob) by this wave: ks / 2 rounds of 4 KB.  Issued right after the barrier that frees the buffer;
-    // they complete under the chunk's 24-72 MFMAs.
-    auto issue_round = [&](int l, int ob, int parity, int q) {
-        const int ks = ks2(l);
-        dma16(reinterpret_cast<const char*>(a.Wc) + layer_off2(l) + ob * ks * 2048 + voff + q * 4096, wbuf + parity * CBUF2 + wave * 1024 + q * 4096);
-    };
-    for (int q = 0; q < ks2(0) / 2; ++q) issue_round(0, 0, 0, q);
-    bool big = false;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row = tile * CROWS + wave * 32 + r;
-        const long lrow = row < P ? row : P - 1;
-        h8 bh[KS2MAX], bl[KS2MAX];
-        {
-            const float* e = a.E + (size_t)lrow * a.lde + 4 * hh;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) load_split8(e + 16 * s, bh[s], bl[s]);
-#pragma unroll
-            for (int s = 8; s < KS2MAX; ++s)
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { bh[s][c] = (_Float16)0.f; bl[s][c] = (_Float16)0.f; }
-        }
-        float part[4] = {0.f, 0.f, 0.f, 0.f};
-        int parity = 0;
-#pragma unroll 1
-        for (int l = 0; l < NL2; ++l) {
-            f32x16 acc[8];
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ob][i] = 0.f;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                int nl = l, nob = ob + 1;
-                if (nob == 8) { nob = 0; nl = l + 1 == NL2 ? 0 : l + 1; }
-                for (int q = 0; q < ks2(nl) / 2; ++q) issue_round(nl, nob, parity ^ 1, q);
-                const unsigned la = lds_base + (unsigned)(parity * CBUF2 + lane * 16);
-                parity ^= 1;
-                if (l == 0) chain2_kloop<0, 8>(acc[ob], la, bh, bl);
-                else if (l == SKIP2) chain2_kloop<0, 24>(acc[ob], la, bh, bl);
-                else chain2_kloop<8, 24>(acc[ob], la, bh, bl);
-            }
-            // ---- epilogue: bias, ReLU, one store for the backward pass, next layer's operand slots 8..23 in place
-            const float* bias = s_aux + l * CW2 + 4 * hh;
-            float* out = a.acts[l] + (size_t)lrow * a.ldact[l] + a.col0[l] + 4 * hh;
-            const bool last = l == NL2 - 1;
-            const bool aligned = (a.col0[l] & 3) == 0;
-#pragma unroll
-            for (int ob = 0; ob < 8; ++ob) {
-#pragma unroll
-                for (int tq = 0; tq < 2; ++tq) {
-                    float v[8];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int q = 2 * tq + u;
-                        const int n0 = 32 * ob + 8 * q;
-                        const float4 b4 = *reinterpret_cast<const float4*>(bias + n0);
-                        v[4 * u + 0] = fmaxf(acc[ob][4 * q + 0] + b4.x, 0.f);
-                        v[4 * u + 1] = fmaxf(acc[ob][4 * q + 1] + b4.y, 0.f);
-                        v[4 * u + 2] = fmaxf(acc[ob][4 * q + 2] + b4.z, 0.f);
-                        v[4 * u + 3] = fmaxf(acc[ob][4 * q + 3] + b4.w, 0.f);
-                        if (row < P) {
-                            if (aligned) {
-                                *reinterpret_cast<float4*>(out + n0) = make_float4(v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]);
-                            } else {            // the skip concat's odd boundary (column 127 of CAT)
-                                out[n0] = v[4 * u]; out[n0 + 1] = v[4 * u + 1]; out[n0 + 2] = v[4 * u + 2]; out[n0 + 3] = v[4 * u + 3];
-                            }
-                        }
-                        if (last) {
-                            const float* wo = s_aux + NL2 * CW2 + 4 * hh;
-#pragma unroll
-                            for (int m = 0; m < 4; ++m) {
-                                const float4 w4 = *reinterpret_cast<const float4*>(wo + m * CW2 + n0);
-                                part[m] += v[4 * u] * w4.x + v[4 * u + 1] * w4.y + v[4 * u + 2] * w4.z + v[4 * u + 3] * w4.w;
-                            }
-                        }
-                    }
-                    float mx = v[0];
-#pragma unroll
-                    for (int c = 1; c < 8; ++c) mx = fmaxf(mx, v[c]);
-                    big |= mx > HOS_RANGE_LIMIT;
-                    h8 hi, lo;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) { _Float16 h_, l_; split_to(v[c], h_, l_); hi[c] = h_; lo[c] = l_; }
-                    bh[8 + 2 * ob + tq] = hi;
-                    bl[8 + 2 * ob + tq] = lo;
-                }
-            }
-        }
-        // ---- output layer (mlp_rgb_sigma.py:57-58) + activations (N:539-540)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) part[m] += __shfl_xor(part[m], 32, 64);
-        if (hh == 0 && row < P) {
-            const float* bo = s_aux + NL2 * CW2 + 4 * CW2;
-            float4 o;
-            o.x = sigmoid_f(part[0] + bo[0]); o.y = sigmoid_f(part[1] + bo[1]); o.z = sigmoid_f(part[2] + bo[2]);
-            o.w = fmaxf(part[3] + bo[3], 0.f);
-            *reinterpret_cast<float4*>(a.raw + row * 4) = o;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (a.range_flag != nullptr && __builtin_amdgcn_ballot_w64(big) != 0 && lane == 0) atomicOr(a.range_flag, 1u);
-}
-
-struct Pack2Args {
-    const float* W[NL2]; int ldw[NL2];
-    const float* b[NL2];
-    const float* Wo; int ldwo; const float* bo;
-    uint16_t* Wc; float* aux;
-};
-
-__global__ __launch_bounds__(256) void chain2_pack_kernel(Pack2Args p) {
-    const int l = blockIdx.y;
-    if (l == NL2) {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < AUX2_FLOATS; i += gridDim.x * 256) {
-            float v = 0.f;
-            if (i < NL2 * CW2) v = p.b[i / CW2][i % CW2];
-            else if (i < NL2 * CW2 + 4 * CW2) { const int j = i - NL2 * CW2; v = p.Wo[(j / CW2) * p.ldwo + j % CW2]; }
-            else if (i < NL2 * CW2 + 4 * CW2 + 4) v = p.bo[i - NL2 * CW2 - 4 * CW2];
-            p.aux[i] = v;
-        }
-        return;
-    }
-    const int ks = ks2(l), kb = kbeg2(l);
-    const int total = 8 * ks * 64 * 8;
-    uint16_t* dst = p.Wc + layer_off2(l) / 2;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int c = e & 7, lane = (e >> 3) & 63, j = (e >> 9) % ks, ob = (e >> 9) / ks;
-        const int n = 32 * ob + (lane & 31);
-        const int s = kb + j;                                            // operand slot
-        const int kk = 8 * (c >> 2) + 4 * (lane >> 5) + (c & 3);         // position inside the slot's group of 16
-        // weight column of (slot, position): slots 0..7 = the 127 input columns (+ one zero), slots 8..23 = the activations, which
-        // the skip layer's weight holds from column 127 on (cat([pos_embed, h]), mlp_rgb_sigma.py:52-54)
-        int col;
-        if (s < 8) col = (16 * s + kk < 127) ? 16 * s + kk : -1;
-        else col = (l == SKIP2 ? 127 : 0) + 16 * (s - 8) + kk;
-        const float w = col < 0 ? 0.f : p.W[l][(size_t)n * p.ldw[l] + col];
-        _Float16 hi, lo;
-        split_to(w, hi, lo);
-        const size_t o = (((size_t)(ob * ks + j) * 2) * 64 + lane) * 8 + c;
-        dst[o] = __builtin_bit_cast(uint16_t, hi);
-        dst[o + 64 * 8] = __builtin_bit_cast(uint16_t, lo);
-    }
-}
-
 }  // namespace
 
 extern "C" long long hos_mlp_chain_weight_bytes(void) { return WC_BYTES; }
@@ -675,50 +463,5 @@ extern "C" int hos_mlp_chain_unfold_grad(const float* gw0h, const float* db, con
     if (!gw0h || !db || !cond || !gW0 || !gb0 || ncond <= 0 || nfeat <= 0) return HOS_E_ARG;
     if (nfeat > W0H_LD || ldw < ncond + nfeat) return HOS_E_SHAPE;
     hipLaunchKernelGGL(chain_unfold_kernel, dim3(56), dim3(256), 0, static_cast<hipStream_t>(stream), gw0h, db, cond, ncond, nfeat, gW0, ldw, gb0);
-    return hos_launch_status();
-}
-
-extern "C" long long hos_mlp_chain256_weight_bytes(void) { return WC2_BYTES; }
-extern "C" long long hos_mlp_chain256_aux_floats(void) { return AUX2_FLOATS; }
-
-extern "C" int hos_mlp_chain256_pack(const float* const* weights9, const int* ldw9, const float* const* biases9, void* chain_planes,
-                                     float* aux, hos_stream_t stream) {
-    if (!weights9 || !ldw9 || !biases9 || !chain_planes || !aux) return HOS_E_ARG;
-    Pack2Args p{};
-    for (int l = 0; l < NL2; ++l) {
-        if (!weights9[l] || !biases9[l]) return HOS_E_ARG;
-        if (ldw9[l] < (l == 0 ? 127 : (l == SKIP2 ? 383 : 256))) return HOS_E_SHAPE;
-        p.W[l] = weights9[l]; p.ldw[l] = ldw9[l]; p.b[l] = biases9[l];
-    }
-    if (!weights9[NL2] || !biases9[NL2] || ldw9[NL2] < CW2) return HOS_E_ARG;
-    p.Wo = weights9[NL2]; p.ldwo = ldw9[NL2]; p.bo = biases9[NL2];
-    p.Wc = static_cast<uint16_t*>(chain_planes); p.aux = aux;
-    hipLaunchKernelGGL(chain2_pack_kernel, dim3(48, NL2 + 1), dim3(256), 0, static_cast<hipStream_t>(stream), p);
-    return hos_launch_status();
-}
-
-extern "C" int hos_mlp_chain256_fwd(const float* E, int lde, const void* chain_planes, const float* aux, float* const* acts8,
-                                    const int* ldact8, const int* col08, float* raw4, int64_t P, const int32_t* rows_dev,
-                                    hos_stream_t stream) {
-    if (!E || !chain_planes || !aux || !acts8 || !ldact8 || !col08 || !raw4 || P <= 0) return HOS_E_ARG;
-    if (lde < 128 || (lde & 3) || (((uintptr_t)E | (uintptr_t)chain_planes | (uintptr_t)raw4) & 15u)) return HOS_E_ALIGN;
-    Chain2Args a{};
-    a.E = E; a.lde = lde; a.Wc = static_cast<const uint16_t*>(chain_planes); a.aux = aux;
-    for (int l = 0; l < NL2; ++l) {
-        if (!acts8[l] || ldact8[l] < col08[l] + CW2 || col08[l] < 0) return HOS_E_ARG;
-        if ((col08[l] & 3) == 0 && ((((uintptr_t)acts8[l]) & 15u) || (ldact8[l] & 3))) return HOS_E_ALIGN;
-        a.acts[l] = acts8[l]; a.ldact[l] = ldact8[l]; a.col0[l] = col08[l];
-    }
-    a.raw = raw4; a.P = P; a.p_dev = rows_dev; a.range_flag = hos_range_flag_ptr();
-    constexpr size_t smem = 2 * CBUF2 + AUX2_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chain256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const long ntiles = (P + CROWS - 1) / CROWS;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL(chain256_kernel, dim3(grid), dim3(CT), smem, static_cast<hipStream_t>(stream), a);
     return hos_launch_status();
 }

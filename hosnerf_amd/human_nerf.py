@@ -479,21 +479,6 @@ class Network(FlatModule):
         Pn = cnl.shape[0]
         dev = cnl.device
         embed = self._embeds.view(self.store.param)[state]
-        if ops.MLP_CHAIN and ops.MLP_CHAIN256 and Pn >= ops.MLP_CHAIN_MIN_ROWS and ops.get_gemm_mode() != ops.GEMM_FP32:
-            # the whole canonical MLP in one launch, activations on chip across the eight layers (hos_chain.hip)
-            E = torch.empty(Pn, CNL_LDE, device=dev)
-            CAT = torch.empty(Pn, CNL_CAT, device=dev)
-            CAT[:, CNL_CAT - 1].zero_()
-            ops.embed_fourier(cnl, 10, embed, E, CAT)
-            bufs = self._chain_bufs.get("cnl")
-            if bufs is None or bufs[0].device != dev:
-                bufs = self._chain_bufs["cnl"] = ops.mlp_chain256_buffers(dev)
-            ws = [self._w(L) for L in self._cnl]
-            ops.mlp_chain256_pack([w for w, _ in ws], [b_ for _, b_ in ws], bufs[0], bufs[1])
-            acts = [CAT if i == 4 else torch.empty(Pn, 256, device=dev) for i in range(8)]
-            raw = torch.empty(Pn, 4, device=dev)
-            ops.mlp_chain256_fwd(E, bufs[0], bufs[1], acts, [127 if i == 4 else 0 for i in range(8)], raw)
-            return raw, ((E, acts, [None] * 8, None) if save else None)
         # The state embedding is ONE vector per call (N:177-230 picks it by frame time): its 64 columns of the input layer and of
         # the skip layer are biases of this call.  Folded form (hos_thin.hip: hos_canonical_fold_*): input rows [fourier 63 | 0],
         # concat rows [fourier 63 | 0 | h 256] with the h part 16-byte aligned -- 64 / 320 columns instead of 128 / 384, and the

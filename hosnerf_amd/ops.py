@@ -448,12 +448,6 @@ def mlp_chain_bwd(cfg, dZ, X, images, dXout, dW, w_col0, db, N, K, rows_dev=None
         _ptr_array(list(db)), _int_array(N), _int_array(K), ptr(ws), ws.numel()))
 
 
-# the canonical (8 x 256) MLP as a chain launch too: correct (tests/test_gpu_chain.py) but measured no faster than its eight thin
-# launches (1.53 vs 1.51 ms per 262 144 rows: 320 operand + accumulator registers per lane leave one wave per SIMD and one
-# accumulator chain, so the MFMAs run at ~60 % and nothing hides the epilogues) -- off by default
-MLP_CHAIN256 = os.environ.get("HOS_MLP_CHAIN256", "0") != "0"
-
-
 def mlp_chain_buffers(device):
     """(chain planes [bytes/2] int16, aux [floats]) for one 6 x 128 MLP -- filled by mlp_chain_pack."""
     lib = _lib.load()
@@ -490,30 +484,6 @@ def mlp_chain128_fwd(E, PE, x, planes, aux, acts, xyz, rows_dev=None):
     _timed(f"mlp_chain128{'' if E is not None else 'f'}[M={P}]", 2.0 * P * flop, lambda: call(
         "hos_mlp_chain128_fwd", ptr(E), 0 if E is None else E.stride(0), ptr(PE), PE.stride(0), ptr(x), ptr(planes, torch.int16), ptr(aux),
         _ptr_array(list(acts)), acts[0].stride(0), ptr(xyz), P, ptr(rows_dev, torch.int32)))
-
-
-def mlp_chain256_buffers(device):
-    lib = _lib.load()
-    return (torch.empty(int(lib.hos_mlp_chain256_weight_bytes()) // 2, dtype=torch.int16, device=device),
-            torch.empty(int(lib.hos_mlp_chain256_aux_floats()), device=device))
-
-
-def mlp_chain256_pack(weights, biases, planes, aux):
-    """weights: the canonical MLP's 9 fp32 matrices (8 hidden + output, nn.Linear layout [rows, ld]), biases: 9 vectors."""
-    import ctypes
-    ldw = (ctypes.c_int * 9)(*[int(w.stride(0)) for w in weights])
-    call("hos_mlp_chain256_pack", _ptr_array(list(weights)), ldw, _ptr_array(list(biases)), ptr(planes, torch.int16), ptr(aux))
-
-
-def mlp_chain256_fwd(E, planes, aux, acts, col0, raw, rows_dev=None):
-    """raw [P,4] = activated output of the canonical MLP on rows E [P,128]; `acts[l]` receives layer l's output at column col0[l]."""
-    import ctypes
-    P = E.shape[0]
-    ld = (ctypes.c_int * 8)(*[int(t.stride(0)) for t in acts])
-    c0 = (ctypes.c_int * 8)(*[int(c) for c in col0])
-    _timed(f"mlp_chain256[M={P}]", 2.0 * P * 524800, lambda: call(
-        "hos_mlp_chain256_fwd", ptr(E), E.stride(0), ptr(planes, torch.int16), ptr(aux), _ptr_array(list(acts)), ld, c0, ptr(raw), P,
-        ptr(rows_dev, torch.int32)))
 
 
 # ------------------------------------------------------------------------------------------ fp16 range guard

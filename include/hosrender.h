@@ -541,21 +541,6 @@ int hos_mlp_chain_bwd(int cfg, const float* dZ, int lddz, int M, const int32_t* 
                       const void* const* images, float* const* dXout, const int* lddx, float* const* dW, const int* lddw,
                       float* const* db, const int* N, const int* K, float* ws, int64_t ws_floats, hos_stream_t stream);
 
-/* The canonical MLP the same way (`CanonicalMLP`, canonical_mlps/mlp_rgb_sigma.py:16-58: [fourier 63 | state 64] -> 8 x (256, ReLU),
- * the input re-concatenated in front of the activations before Linear #5 (383 wide) -> 4 -> sigmoid rgb, relu sigma N:539-540).
- *   hos_mlp_chain256_pack  weights9 / ldw9 / biases9: HOST arrays over pts_linears 0..7 + output_linear (fp32 [256 (4), ld]; layer 0
- *                          ld >= 127, layer 5 ld >= 383 with columns [input 127 | activations 256]).
- *   hos_mlp_chain256_fwd   E [P, lde >= 128] = [fourier | state | 0]; acts8 / ldact8 / col08: HOST arrays -- layer l's output is
- *                          written at acts8[l][row * ldact8[l] + col08[l] + n] (layer 4 goes to column 127 of the skip-concat
- *                          buffer the backward pass reads); raw4 [P,4] activated output. */
-long long hos_mlp_chain256_weight_bytes(void);
-long long hos_mlp_chain256_aux_floats(void);
-int hos_mlp_chain256_pack(const float* const* weights9, const int* ldw9, const float* const* biases9, void* chain_planes,
-                          float* aux, hos_stream_t stream);
-int hos_mlp_chain256_fwd(const float* E, int lde, const void* chain_planes, const float* aux, float* const* acts8,
-                         const int* ldact8, const int* col08, float* raw4, int64_t P, const int32_t* rows_dev,
-                         hos_stream_t stream);
-
 /* ------------------------------------------------------------------------------------------
  * Cycle-consistency set (N:505-536): the sample points with fg_likelihood_mask > 0.005.
  * The reference selects them by boolean indexing (data-dependent shape = a host round trip per step);

@@ -7,7 +7,7 @@ found by a soak run with NaN-poisoned allocations, scripts/soak_poison.py).  The
 order (so it also sees hazards that cross basic blocks on the fall-through path) and reports every instruction that names a
 register of a still-outstanding ds_read.
 
-  python scripts/scan_inflight_reads.py hosnerf_amd/csrc/hos_chain.hip chain128_kernel chain256_kernel
+  python scripts/scan_inflight_reads.py hosnerf_amd/csrc/hos_chain.hip chain128_kernel
 Exit status 1 if a hazard is found."""
 import os
 import re

@@ -225,66 +225,6 @@ def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
         assert float((got - ref).abs().max()) <= 2e-6 * scale, (k, float((got - ref).abs().max()), scale)
 
 
-# ------------------------------------------------------------------------------------------------ canonical MLP (8 x 256)
-def _cnl_both(net, cnl, state):
-    prev_c, prev_m, prev_2, prev_f = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256, ops.CNL_FOLD
-    try:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = True, 1, True
-        ops.CNL_FOLD = False                     # the row form [fourier | state] on both sides (the folded form: tests below)
-        raw_c, (E, acts_c, _, _) = net._canonical_fwd(cnl, state, save=True)
-        ops.MLP_CHAIN = False
-        raw_l, (_, acts_l, _, _) = net._canonical_fwd(cnl, state, save=True)
-    finally:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256, ops.CNL_FOLD = prev_c, prev_m, prev_2, prev_f
-    return raw_c, acts_c, raw_l, acts_l, E
-
-
-@pytest.mark.parametrize("P", [1, 33, 128, 1000, 4096 + 77, 65536])
-@pytest.mark.parametrize("state", [0, 1])
-def test_canonical_chain_matches_layers_and_fp64(net, P, state):
-    g = torch.Generator().manual_seed(P + state)
-    cnl = (torch.rand(P, 3, generator=g) * 2 - 1).to(DEV)
-    with torch.no_grad():
-        raw_c, acts_c, raw_l, acts_l, E = _cnl_both(net, cnl, state)
-        # float64 reference of the same graph from the embedding on
-        h = E.double()[:, :127]
-        emb = h
-        racts = []
-        for i in range(8):
-            W, b = net._w(net._cnl[i])
-            inp = torch.cat([emb, h], 1) if i == 5 else h
-            h = torch.relu(inp @ W.double()[:256, :inp.shape[1]].T + b.double()[:256])
-            racts.append(h)
-        W, b = net._w(net._cnl[8])
-        o = h @ W.double()[:4, :256].T + b.double()[:4]
-        ref = torch.cat([torch.sigmoid(o[:, :3]), torch.relu(o[:, 3:])], 1)
-    for l in range(8):
-        got_c = acts_c[l][:, 127:383] if l == 4 else acts_c[l]
-        got_l = acts_l[l][:, 127:383] if l == 4 else acts_l[l]
-        scale = max(1.0, float(racts[l].abs().max()))
-        assert float((got_c.double() - racts[l]).abs().max()) < 3e-6 * scale, (l, P)
-        assert float((got_c - got_l).abs().max()) < 3e-6 * scale, (l, P)
-    assert torch.equal(acts_c[4][:, :127], acts_l[4][:, :127])                 # the embedder's part of the skip-concat buffer is untouched
-    rs = max(1.0, float(ref.abs().max()))                 # sigma = relu(.) is unbounded
-    assert float((raw_c.double() - ref).abs().max()) < 3e-6 * rs
-    assert float((raw_c - raw_l).abs().max()) < 3e-6 * rs
-
-
-def test_canonical_chain_vs_reference_fixture(net):
-    hp = np.load(os.path.join(HERE, "golden", "human_parts.npz"))
-    cn = torch.from_numpy(hp["flbs_pts"]).to(DEV)
-    prev_c, prev_m, prev_2 = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256
-    ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = True, 1, True
-    try:
-        with torch.no_grad():
-            raw, _ = net._canonical_fwd(cn, 1, save=False)
-    finally:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN256 = prev_c, prev_m, prev_2
-    want = torch.from_numpy(hp["cnl_raw"])
-    want = torch.cat([torch.sigmoid(want[:, :3]), torch.relu(want[:, 3:])], -1)
-    assert float((raw.cpu() - want).abs().max()) < 5e-5          # the bound tests/test_gpu_human.py uses for the layer-by-layer path
-
-
 # ------------------------------------------------------------------------------------------------ canonical MLP, folded state embedding
 def _cnl_ref64(net, cnl, state, g=None):
     """float64 autograd of CanonicalMLP on [fourier(cnl) | state embedding] (mlp_rgb_sigma.py:49-58 + N:539-540)."""
