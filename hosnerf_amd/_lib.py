@@ -44,6 +44,16 @@ PROTOTYPES = {
     "hos_mlp_bwd_ws_floats": [_I, _I, _I, _I],
     "hos_linear_wgrad_tr": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P],
     "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P],
+    "hos_lpips_prep": [_P, _L, _P, _P],
+    "hos_im2col3x3": [_P, _I, _I, _I, _I, _P, _I, _P],
+    "hos_col2im3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "hos_maxpool2x2_fwd": [_P, _I, _I, _I, _I, _P, _P],
+    "hos_maxpool2x2_bwd": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "hos_lpips_head_fwd": [_P, _P, _I, _I, _I, _F, _P, _P],
+    "hos_lpips_head_bwd": [_P, _P, _I, _I, _I, _F, _P, _I, _P, _P],
+    "hos_lpips_finish": [_P, _I, _P, _P],
+    "hos_unpack_patches_fwd": [_P, _P, _P, _F, _L, _P, _P],
+    "hos_unpack_patches_bwd": [_P, _P, _L, _F, _F, _F, _P, _P],
     "hos_camera_rays": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "hos_rays_aabb": [_P, _P, _L, _P, _P, _P, _P, _P],
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],

@@ -650,6 +650,35 @@ int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* 
                    const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
                    const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * LPIPS term of the stage-2 / stage-3 training loss (hos_lpips.hip): `LPIPS(net='vgg')` of third_parties/lpips/lpips.py:22-122 as
+ * src/model/mipnerf360/model.py:1664-1678 calls it on the unpacked P x P patches (weight 1.0 in configs/default.yaml:97-101), VGG-16
+ * frozen, eval mode.  The 3 x 3 convolutions are im2col + hos_linear_fwd (bias + ReLU epilogue) and, backward, hos_linear_dgrad +
+ * col2im (no weight gradient exists); everything is channel-last [image, y, x, channel]:
+ *   hos_lpips_prep        out = (2 x - 1 - shift_c) / scale_c for n_pixels RGB pixels in [0, 1]        (lpips.py:124-131, model.py:1661)
+ *   hos_im2col3x3         col [NI*H*W, ld >= 9 C] <- in [NI, H, W, C], kernel 3, padding 1, column tap * C + c, padding columns zero
+ *   hos_col2im3x3         dx [NI, H, W, C] <- dcol, times [relu_src > 0] (NULL: no mask): the input gradient of that convolution
+ *   hos_maxpool2x2_fwd/bwd  MaxPool2d(2, 2); bwd routes to the first maximum of a window (torch's rule) and applies [in > 0]
+ *   hos_lpips_head_fwd    part[i] += coef * sum_pixels sum_c w_c (f0_c / R0 - f1_c / R1)^2 for pair i (prediction i = image i,
+ *                         target i = image Np + i of feats [2 Np * HW, C]); R = sqrt(sum f^2 + 1e-10) + 1e-10   (lpips.py:92-100)
+ *   hos_lpips_head_bwd    g_feats [Np * HW, C] (+)= gscale[0] * coef * d/d f0, times [f0 > 0]
+ *   hos_lpips_finish      out[0] = sum_i part[i]
+ *   hos_unpack_patches_fwd/bwd  model.py:41-50 `_unpack_imgs`: img[p] = idx[p] >= 0 ? rgb[idx[p]] : bgcolor * bg_scale;  backward
+ *                         g_rgb[idx[p]] = g_img[p] * (s0, s1, s2) per channel (the caller zeroes g_rgb) */
+int hos_lpips_prep(const float* x01, int64_t n_pixels, float* out, hos_stream_t stream);
+int hos_im2col3x3(const float* in, int NI, int H, int W, int C, float* col, int ld, hos_stream_t stream);
+int hos_col2im3x3(const float* dcol, int ld, int NI, int H, int W, int C, const float* relu_src, float* dx, hos_stream_t stream);
+int hos_maxpool2x2_fwd(const float* in, int NI, int H, int W, int C, float* out, hos_stream_t stream);
+int hos_maxpool2x2_bwd(const float* g_out, const float* in, int NI, int H, int W, int C, float* g_in, hos_stream_t stream);
+int hos_lpips_head_fwd(const float* feats, const float* lin_w, int Np, int HW, int C, float coef, float* part, hos_stream_t stream);
+int hos_lpips_head_bwd(const float* feats, const float* lin_w, int Np, int HW, int C, float coef, const float* gscale,
+                       int accumulate, float* g_feats, hos_stream_t stream);
+int hos_lpips_finish(const float* part, int Np, float* out, hos_stream_t stream);
+int hos_unpack_patches_fwd(const float* rgb, const int32_t* idx, const float* bgcolor, float bg_scale, int64_t n_pixels, float* img,
+                           hos_stream_t stream);
+int hos_unpack_patches_bwd(const float* g_img, const int32_t* idx, int64_t n_pixels, float s0, float s1, float s2, float* g_rgb,
+                           hos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
