@@ -341,6 +341,40 @@ class Stage3(Workload):
         self.hos.human.finish_decoder_backward()
 
 
+class Stage3LPIPS(Stage3):
+    """The stage-3 step WITH the reference's LPIPS term (weight 1.0; `hosnerf_amd.lpips`): what the term costs per step.  The VGG-16
+    filters are He-normal random (torchvision's ImageNet weights are a download) and so are the calibration weights: a timing leg."""
+    name = "stage3_with_lpips"
+    describe = ("stage-3 step at 4096 rays + 1.0 x LPIPS(net='vgg') on the four unpacked 32x32 patches (forward of prediction and target "
+                "through VGG-16 relu1_2..relu5_3, input gradient of the prediction; random filters: timing only)")
+
+    def __init__(self, dev, rank, world, rays_global):
+        from hosnerf_amd.lpips import LPIPS, VGG16_CFG, CHNS, patch_ray_index
+        Stage3.__init__(self, dev, rank, world, rays_global)
+        g = torch.Generator().manual_seed(4321)
+        sd, cin, idx = {}, 3, 0
+        for v in VGG16_CFG:
+            if v == "M":
+                idx += 1
+                continue
+            sd[f"{idx}.weight"] = torch.randn(v, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+            sd[f"{idx}.bias"] = torch.zeros(v)
+            cin, idx = v, idx + 2
+        self.lpips = LPIPS().load_vgg16_features(sd, dev).load_lin(torch.rand(sum(CHNS), generator=g) * 0.1, dev)
+        self.batch["patch_ray_idx"] = patch_ray_index(self.batch["patch_masks"].to(dev))
+
+    def fwd_bwd(self, i):
+        from hosnerf_amd.train import stage3_losses
+        self.ob.zero_grad()
+        self.oh.zero_grad()
+        self.hos.human.split_decoder_backward = True
+        out = self.hos.render(self.batch, randomized=True, is_train=True, static_cycle=True)
+        self.cycle_count = out.get("cycle_count")
+        loss, _ = stage3_losses(out, self.batch, lpips=self.lpips)
+        loss.backward()
+        return loss.detach()
+
+
 class Stage3Fresh(Stage3):
     """The stage-3 step with a NEW training item every step: a synthetic scene directory in the reference's
     on-disk formats (`synth.write_scene_dir`) -> `dataset.SceneItems` builds each item on the device (two camera ray sets,
@@ -762,6 +796,8 @@ def main():
         g = args.rays if (args.rays and args.primary == name) else (GLOBAL_RAYS_S3 if name == "stage3" else 2048)
         if g % world:
             raise SystemExit(f"{g} global rays do not divide over {world} ranks")
+        if name == "stage3_with_lpips":
+            return Stage3LPIPS(dev, rank, world, args.rays if (args.rays and args.primary == "stage3") else GLOBAL_RAYS_S3)
         if name == "stage3_fresh_items":
             return Stage3Fresh(dev, rank, world, args.rays if (args.rays and args.primary == "stage3") else GLOBAL_RAYS_S3)
         return (Stage3 if name == "stage3" else Stage2)(dev, rank, world, g)
@@ -770,7 +806,7 @@ def main():
         wl = make(name)
         dt, info, table = run_workload(wl, args, dev, rank, world, dist, events)
         rays_total = wl.rays_global * args.steps
-        fkey = "stage3" if name == "stage3_fresh_items" else name
+        fkey = "stage3" if name in ("stage3_fresh_items", "stage3_with_lpips") else name
         flop_ray = FLOP_PER_RAY[fkey][0] + FLOP_PER_RAY[fkey][1] * info["f_cyc"]
         res = {"value": rays_total / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / args.steps, "scaling": wl.scaling,
                "rays_per_gpu": wl.rays_local, "global_rays": wl.rays_global, "workload": wl.describe,
@@ -790,6 +826,12 @@ def main():
             stages[name], _ = measure(name, False)
         if args.primary == "stage3" and world == 1:
             try:        # a secondary object must never cost the primary line
+                stages["stage3_with_lpips"], _ = measure("stage3_with_lpips", False)
+                stages["stage3_with_lpips"]["vs_without_lpips"] = stages["stage3_with_lpips"]["value"] / prim["value"]
+            except Exception as e:
+                stages["stage3_with_lpips"] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.synchronize()
+            try:
                 stages["stage3_fresh_items"], _ = measure("stage3_fresh_items", False)
                 stages["stage3_fresh_items"]["vs_resident_batch"] = stages["stage3_fresh_items"]["value"] / prim["value"]
             except Exception as e:

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "hos_lpips_head_fwd": [_P, _P, _I, _I, _I, _F, _P, _P],
     "hos_lpips_head_bwd": [_P, _P, _I, _I, _I, _F, _P, _I, _P, _P],
     "hos_lpips_finish": [_P, _I, _P, _P],
+    "hos_lpips_part_floats": [_I],
+    "hos_bias_relu": [_P, _P, _L, _I, _P],
     "hos_unpack_patches_fwd": [_P, _P, _P, _F, _L, _P, _P],
     "hos_unpack_patches_bwd": [_P, _P, _L, _F, _F, _F, _P, _P],
     "hos_camera_rays": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],

@@ -99,14 +99,16 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
 
 constexpr float LP_EPS = 1e-10f;
 
-// part[i] += coef * sum_pixels sum_c w_c (f0_c / R0 - f1_c / R1)^2,  R = sqrt(sum f^2 + eps) + eps (I:10-12), f0 = features of
-// prediction i, f1 = of target i (rows Np * HW further).  One workgroup per pair, one wave per pixel, fixed summation order.
+// part[i * LP_CHUNKS + j] += coef * sum over the pixels p = j (mod LP_CHUNKS) of pair i of sum_c w_c (f0_c / R0 - f1_c / R1)^2,
+// R = sqrt(sum f^2 + eps) + eps (I:10-12); f0 = features of prediction i, f1 = of target i (rows Np * HW further).  One workgroup
+// per (pair, chunk), one wave per pixel, fixed summation order (hos_lpips_finish adds the chunks in index order).
+constexpr int LP_CHUNKS = 32;
 __global__ __launch_bounds__(256) void lpips_head_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w, int Np, int HW, int C,
                                                              float coef, float* __restrict__ part) {
     __shared__ float s_w[4];
-    const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
-    for (int p = wave; p < HW; p += 4) {
+    for (int p = chunk + LP_CHUNKS * wave; p < HW; p += LP_CHUNKS * 4) {
         const float* f0 = f + ((size_t)i * HW + p) * C;
         const float* f1 = f + ((size_t)(Np + i) * HW + p) * C;
         float s0 = 0.f, s1 = 0.f;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void lpips_head_fwd_kernel(const float* __rest
     }
     if (lane == 0) s_w[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[i] += coef * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
+    if (threadIdx.x == 0) part[i * LP_CHUNKS + chunk] += coef * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
 }
 
 // g[(i, p), c] (+)= gscale * coef * d/d f0_c of the pixel's term, times [f0_c > 0] (the tap is a ReLU output):
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void lpips_head_bwd_kernel(const float* __rest
 __global__ void lpips_finish_kernel(const float* __restrict__ part, int Np, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
-        for (int i = 0; i < Np; ++i) s += part[i];
+        for (int i = 0; i < Np * LP_CHUNKS; ++i) s += part[i];
         out[0] = s;
     }
 }
@@ -173,6 +175,11 @@ __global__ __launch_bounds__(256) void unpack_patches_bwd_kernel(const float* __
         const int c = (int)(e % 3), r = idx[p];
         if (r >= 0) g_rgb[(size_t)r * 3 + c] = g_img[e] * (c == 0 ? s0 : (c == 1 ? s1 : s2));
     }
+}
+
+// y = relu(y + bias) in place (behind hos_linear_fwd_splitk, which has no epilogue)
+__global__ __launch_bounds__(256) void bias_relu_kernel(float* __restrict__ y, const float* __restrict__ bias, long M, int N) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < M * N; e += (long)gridDim.x * 256) y[e] = fmaxf(y[e] + bias[e % N], 0.f);
 }
 
 inline int blocks_for(long total) { long b = (total + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
@@ -215,7 +222,7 @@ extern "C" int hos_maxpool2x2_bwd(const float* g_out, const float* in, int NI, i
 
 extern "C" int hos_lpips_head_fwd(const float* feats, const float* lin_w, int Np, int HW, int C, float coef, float* part, hos_stream_t stream) {
     if (!feats || !lin_w || !part || Np <= 0 || HW <= 0 || C <= 0) return HOS_E_ARG;
-    hipLaunchKernelGGL(lpips_head_fwd_kernel, dim3(Np), dim3(256), 0, static_cast<hipStream_t>(stream), feats, lin_w, Np, HW, C, coef, part);
+    hipLaunchKernelGGL(lpips_head_fwd_kernel, dim3(Np, LP_CHUNKS), dim3(256), 0, static_cast<hipStream_t>(stream), feats, lin_w, Np, HW, C, coef, part);
     return hos_launch_status();
 }
 
@@ -247,5 +254,13 @@ extern "C" int hos_unpack_patches_bwd(const float* g_img, const int32_t* idx, in
     if (!g_img || !idx || !g_rgb || n_pixels <= 0) return HOS_E_ARG;
     hipLaunchKernelGGL(unpack_patches_bwd_kernel, dim3(blocks_for(n_pixels * 3)), dim3(256), 0, static_cast<hipStream_t>(stream), g_img, idx, (long)n_pixels,
                        s0, s1, s2, g_rgb);
+    return hos_launch_status();
+}
+
+extern "C" int hos_lpips_part_floats(int Np) { return Np > 0 ? Np * LP_CHUNKS : 0; }
+
+extern "C" int hos_bias_relu(float* y, const float* bias, int64_t M, int N, hos_stream_t stream) {
+    if (!y || !bias || M <= 0 || N <= 0) return HOS_E_ARG;
+    hipLaunchKernelGGL(bias_relu_kernel, dim3(blocks_for((long)M * N)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias, (long)M, N);
     return hos_launch_status();
 }

@@ -74,6 +74,12 @@ class LPIPS(nn.Module):
         self._lin = [p_.to(device).contiguous() for p_ in parts]
         return self
 
+    @classmethod
+    def from_files(cls, vgg16_path: str, lin_path: str, device="cuda") -> "LPIPS":
+        """`vgg16_path`: torchvision's `vgg16` checkpoint (`vgg16-397923af.pth`: keys `features.N.*`, the classifier is ignored);
+        `lin_path`: the reference's `third_parties/lpips/weights/v0.1/vgg.pth`."""
+        return cls().load_vgg16_features(torch.load(vgg16_path, map_location="cpu"), device).load_lin(torch.load(lin_path, map_location="cpu"), device)
+
     def ready(self) -> bool:
         return len(self._W) == 13 and len(self._lin) == 5
 
@@ -84,6 +90,11 @@ class LPIPS(nn.Module):
         if not self.ready():
             raise RuntimeError("LPIPS: load_vgg16_features() and load_lin() first (the ImageNet VGG-16 weights are not part of this repository)")
         return _LPIPSFn.apply(rgb, self, target_patches, ray_idx, bgcolor)
+
+
+def _lib_part(Np: int) -> int:
+    from . import _lib
+    return _lib.load().hos_lpips_part_floats(Np)
 
 
 def _vgg_forward(mod: LPIPS, x0: torch.Tensor, NI: int, P: int):
@@ -105,7 +116,14 @@ def _vgg_forward(mod: LPIPS, x0: torch.Tensor, NI: int, P: int):
             col = torch.empty(NI * H * H, kpad, device=dev)
             call("hos_im2col3x3", ptr(h), NI, H, H, C, ptr(col), kpad)
             y = torch.empty(NI * H * H, v, device=dev)
-            ops.linear_fwd(col, kpad, W, b, v, y, ops.EPI_RELU)
+            M = NI * H * H
+            if ((M + 127) // 128) * ((v + 127) // 128) < 64 and kpad >= 1152:
+                # few output tiles, long reduction (the 8 x 8 .. 2 x 2 feature maps): one tile kernel would walk 36-144 K tiles on
+                # 4-16 workgroups (205 us per layer); the reduction split over ~256 workgroups + a bias / ReLU pass
+                call("hos_linear_fwd_splitk", ptr(col), kpad, ptr(W), kpad, ptr(y), v, M, v, kpad)
+                call("hos_bias_relu", ptr(y), ptr(b), M, v)
+            else:
+                ops.linear_fwd(col, kpad, W, b, v, y, ops.EPI_RELU)
             conv_in.append(h)
             conv_out.append(y)
             geo.append((H, C, v))
@@ -129,7 +147,7 @@ class _LPIPSFn(torch.autograd.Function):
         call("hos_lpips_prep", ptr(pred), npix, ptr(x0))
         call("hos_lpips_prep", ptr(target.contiguous()), npix, ptr(x0) + 4 * 3 * npix)
         taps, conv_in, conv_out, pools, geo = _vgg_forward(mod, x0, 2 * Np, P)
-        part = ops.zeros(Np, dev)
+        part = ops.zeros(int(_lib_part(Np)), dev)
         for k, (f, HW, C) in enumerate(taps):
             call("hos_lpips_head_fwd", ptr(f), ptr(mod._lin[k]), Np, HW, C, 1.0 / (HW * Np), ptr(part))
         out = torch.empty(1, device=dev)

@@ -156,7 +156,7 @@ class LitHumanObject(_LitFlat):
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M2:576
         self.human.split_decoder_backward = self._human_opt is not None and torch.is_grad_enabled()
         out = self.human(static_cycle=True, **batch)
-        loss, _ = stage2_losses(out, batch)
+        loss, _ = stage2_losses(out, batch, lpips=getattr(self, "lpips", None))
         return loss
 
     def apply_lr(self, optimizer, step: int):
@@ -174,7 +174,8 @@ class LitHumanObject(_LitFlat):
 
 class LitHOSNeRF(_LitFlat):
     """Stage 3 (S3/src/model/mipnerf360/model.py:1501-1656): both renderers + the merged composite; one step =
-    render + 0.2 MSE + 0.01 flow + 0.01 cycle (the LPIPS term needs the VGG weights and stays with the reference)."""
+    render + 0.2 MSE + 0.01 flow + 0.01 cycle, and + 1.0 LPIPS once `self.lpips = hosnerf_amd.lpips.LPIPS.from_files(vgg16.pth,
+    third_parties/lpips/weights/v0.1/vgg.pth)` has been set (the ImageNet VGG-16 weights are torchvision's download: not shipped)."""
 
     LR = 6.667e-5           # configs/default.yaml train.lr_bkgd / lr_cnl_mlp; the other human modules train at LR / 10
 
@@ -200,7 +201,7 @@ class LitHOSNeRF(_LitFlat):
         batch["iter_val"] = torch.full((1,), float(self._global_step()))          # M:1506
         self.human.split_decoder_backward = self._human_opt is not None and torch.is_grad_enabled()
         out = self.net.render(batch, randomized=True, is_train=True, static_cycle=True)
-        loss, _ = stage3_losses(out, batch)
+        loss, _ = stage3_losses(out, batch, lpips=getattr(self, "lpips", None))
         return loss
 
     def _lr_bkgd(self) -> float:

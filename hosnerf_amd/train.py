@@ -484,11 +484,21 @@ def _loss_parts(parts: torch.Tensor) -> Dict[str, torch.Tensor]:
     return {"mse": parts[1], "flow": parts[2], "cycle": parts[3]}
 
 
+def _lpips_term(lpips, rgb, batch, w_lpips: float):
+    """`w_lpips * mean_i LPIPS(2 unpack(rgb)_i - 1, 2 target_i - 1)` (M:1673-1676; hosnerf_amd/lpips.py).  The index of every patch
+    pixel's ray is cached in the batch (`patch_ray_idx`: built once per item from `patch_masks`, outside a captured step)."""
+    from .lpips import patch_ray_index
+    if "patch_ray_idx" not in batch:
+        batch["patch_ray_idx"] = patch_ray_index(batch["patch_masks"].to(rgb.device))
+    return w_lpips * lpips.loss(rgb, batch["target_patches"], batch["patch_ray_idx"], batch["bgcolor"])
+
+
 def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
-                  w_flow: float = 0.01, w_cycle: float = 0.01):
-    """M:1690-1716 `get_loss` without the LPIPS term (third-party VGG, out of scope): 0.2*MSE + 0.01*flow + 0.01*cycle
-    (configs/default.yaml lossweights) -- one HIP launch (hos_train_losses_fwd), gradients in another.
-    Returns (total, {name: unweighted term}).
+                  w_flow: float = 0.01, w_cycle: float = 0.01, lpips=None, w_lpips: float = 1.0):
+    """M:1690-1716 `get_loss`: 0.2*MSE + 0.01*flow + 0.01*cycle (configs/default.yaml lossweights) -- one HIP launch
+    (hos_train_losses_fwd), gradients in another -- plus, when a loaded `lpips.LPIPS` module is passed, 1.0 * LPIPS on the
+    unpacked patches (its ImageNet VGG-16 filters do not exist offline, so the default is without it, on both sides of every
+    comparison).  Returns (total, {name: unweighted term}).
 
     The reference selects the foreground rows first (`ray_grid[idx_fg]`, `human_weights_onlyfg`, M:1704) -- a boolean
     index, i.e. a device->host round trip per step, next to its four `.item()` reads (M:1617-1622).  The kernel runs over
@@ -504,11 +514,16 @@ def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
         ray_grid=batch.get("ray_grid"), fg=out["idx_fg"], cam_prev=batch.get("newsmpl_to_camera_prev"),
         intrinsics_prev=batch.get("intrinsics_prev"), observe=out["observe_pts"], deform=out["deform_pts_final"],
         n_cyc_dev=out.get("cycle_count"), w_mse=w_mse, w_flow=w_flow, w_cycle=w_cycle)
-    return total, _loss_parts(parts)
+    named = _loss_parts(parts)
+    if lpips is not None:
+        term = _lpips_term(lpips, rgb, batch, w_lpips)
+        total = total + term
+        named["lpips"] = term.detach() / w_lpips
+    return total, named
 
 
 def stage2_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
-                  w_flow: float = 0.01, w_cycle: float = 0.01):
+                  w_flow: float = 0.01, w_cycle: float = 0.01, lpips=None, w_lpips: float = 1.0):
     """2nd_State_Conditional_Human-Object/src/model/mipnerf360/model.py:918-944 `get_loss` without the LPIPS term:
     0.2 * MSE on the unpacked patches + 0.01 * flow (weighted by the network's own composite `weights`, all rays)
     + 0.01 * cycle.  `batch` carries `target_rgbs` / `mse_const` / `mse_count` from `prepare_patch_targets`."""
@@ -519,7 +534,12 @@ def stage2_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
         ray_grid=batch.get("ray_grid"), fg=None, cam_prev=batch.get("newsmpl_to_camera_prev"),
         intrinsics_prev=batch.get("intrinsics_prev"), observe=out["observe_pts"], deform=out["deform_pts_final"],
         n_cyc_dev=out.get("cycle_count"), w_mse=w_mse, w_flow=w_flow, w_cycle=w_cycle)
-    return total, _loss_parts(parts)
+    named = _loss_parts(parts)
+    if lpips is not None:
+        term = _lpips_term(lpips, out["rgb"], batch, w_lpips)
+        total = total + term
+        named["lpips"] = term.detach() / w_lpips
+    return total, named
 
 
 def check_range(modules, device) -> bool:
@@ -561,21 +581,21 @@ def finish_backward_human(net, opt: Optional["FusedAdam"] = None, group=None):
         opt.grad_is_reduced = True
 
 
-def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, t_rand=None):
+def train_step_stage2(net, opt: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, t_rand=None, lpips=None):
     """One stage-2 optimisation step (M2:571-605 training_step + :606-634 optimizer_step): the human-object network with its
     in-network composite, 0.2 MSE on the unpacked patches + 0.01 flow + 0.01 cycle, backward, flat Adam with the
     per-module learning rates.  `batch` comes from `prepare_patch_targets` + `batch_to_device`."""
     opt.zero_grad()
     net.split_decoder_backward = True
     out = net(t_rand=t_rand, static_cycle=True, **batch)
-    loss, parts = stage2_losses(out, batch)
+    loss, parts = stage2_losses(out, batch, lpips=lpips)
     backward_human(net, loss, opt, opt.group)
     opt.step(lr, reduced=True)                  # clips by the optimiser's own GradClip (run.grad_max_norm), then Adam
     return loss.detach(), parts
 
 
 def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dict[str, torch.Tensor], lr: Optional[float] = None,
-                      jitters=None, t_rand=None):
+                      jitters=None, t_rand=None, lpips=None):
     """One stage-3 optimisation step (M:1501-1629 + optimizer_step :1631-1656): background forward (3 levels, only
     the NeRF level trains -- the proposal MLPs get no gradient in stage 3) + human branch + merge composite +
     losses + backward + ONE gradient-norm clip over both modules (when the optimisers share a `GradClip`: the Trainer's
@@ -584,7 +604,7 @@ def train_step_stage3(hos, opt_bkgd: FusedAdam, opt_human: FusedAdam, batch: Dic
     opt_human.zero_grad()
     hos.human.split_decoder_backward = True
     out = hos.render(batch, randomized=True, is_train=True, static_cycle=True, jitters=jitters, t_rand=t_rand)
-    loss, parts = stage3_losses(out, batch)
+    loss, parts = stage3_losses(out, batch, lpips=lpips)
     backward_human(hos.human, loss, opt_human, opt_human.group)
     step_all([opt_bkgd, opt_human], lr, reduced=[False, True])       # ONE gradient norm over both modules, then the two Adams
     return loss.detach(), parts

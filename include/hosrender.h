@@ -659,10 +659,12 @@ int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* 
  *   hos_im2col3x3         col [NI*H*W, ld >= 9 C] <- in [NI, H, W, C], kernel 3, padding 1, column tap * C + c, padding columns zero
  *   hos_col2im3x3         dx [NI, H, W, C] <- dcol, times [relu_src > 0] (NULL: no mask): the input gradient of that convolution
  *   hos_maxpool2x2_fwd/bwd  MaxPool2d(2, 2); bwd routes to the first maximum of a window (torch's rule) and applies [in > 0]
- *   hos_lpips_head_fwd    part[i] += coef * sum_pixels sum_c w_c (f0_c / R0 - f1_c / R1)^2 for pair i (prediction i = image i,
- *                         target i = image Np + i of feats [2 Np * HW, C]); R = sqrt(sum f^2 + 1e-10) + 1e-10   (lpips.py:92-100)
+ *   hos_lpips_head_fwd    part (hos_lpips_part_floats(Np) floats, zeroed by the caller) += coef * sum_pixels sum_c w_c (f0_c / R0 -
+ *                         f1_c / R1)^2 per pair i (prediction i = image i, target i = image Np + i of feats [2 Np * HW, C]) and pixel
+ *                         chunk; R = sqrt(sum f^2 + 1e-10) + 1e-10   (lpips.py:92-100)
  *   hos_lpips_head_bwd    g_feats [Np * HW, C] (+)= gscale[0] * coef * d/d f0, times [f0 > 0]
- *   hos_lpips_finish      out[0] = sum_i part[i]
+ *   hos_lpips_finish      out[0] = sum of part, in index order
+ *   hos_bias_relu         y = relu(y + bias) in place: the epilogue behind hos_linear_fwd_splitk for the deep, few-pixel convolutions
  *   hos_unpack_patches_fwd/bwd  model.py:41-50 `_unpack_imgs`: img[p] = idx[p] >= 0 ? rgb[idx[p]] : bgcolor * bg_scale;  backward
  *                         g_rgb[idx[p]] = g_img[p] * (s0, s1, s2) per channel (the caller zeroes g_rgb) */
 int hos_lpips_prep(const float* x01, int64_t n_pixels, float* out, hos_stream_t stream);
@@ -674,6 +676,8 @@ int hos_lpips_head_fwd(const float* feats, const float* lin_w, int Np, int HW, i
 int hos_lpips_head_bwd(const float* feats, const float* lin_w, int Np, int HW, int C, float coef, const float* gscale,
                        int accumulate, float* g_feats, hos_stream_t stream);
 int hos_lpips_finish(const float* part, int Np, float* out, hos_stream_t stream);
+int hos_lpips_part_floats(int Np);
+int hos_bias_relu(float* y, const float* bias, int64_t M, int N, hos_stream_t stream);
 int hos_unpack_patches_fwd(const float* rgb, const int32_t* idx, const float* bgcolor, float bg_scale, int64_t n_pixels, float* img,
                            hos_stream_t stream);
 int hos_unpack_patches_bwd(const float* g_img, const int32_t* idx, int64_t n_pixels, float s0, float s1, float s2, float* g_rgb,

@@ -253,3 +253,17 @@ def test_group_backward_entry_points_validate_without_gpu():
     assert lib.hos_mlp_chain_bwd_pack(0, 0, 0, 0, 0, 0, 0, 0, 0) == -1 and lib.hos_mlp_chain_bwd_pack(9, 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert lib.hos_mlp_chain_bwd(0, 0, 32, 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
     assert lib.hos_mlp_chain_bwd(7, 0, 32, 1024, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == -1
+
+
+def test_lpips_entry_points_validate_without_gpu():
+    """hos_lpips.hip (round 4): null pointers / odd sizes are rejected before any launch; the Python module refuses to run unloaded."""
+    from hosnerf_amd import _lib
+    from hosnerf_amd.lpips import LPIPS, VGG16_CFG, TAP_AFTER_CONV
+    lib = _lib.load()
+    assert lib.hos_lpips_prep(0, 16, 0, 0) == -1 and lib.hos_im2col3x3(0, 1, 4, 4, 3, 0, 32, 0) == -1
+    assert lib.hos_col2im3x3(0, 32, 1, 4, 4, 3, 0, 0, 0) == -1 and lib.hos_maxpool2x2_fwd(0, 1, 4, 4, 3, 0, 0) == -1
+    assert lib.hos_lpips_head_fwd(0, 0, 1, 4, 64, 0.25, 0, 0) == -1 and lib.hos_lpips_head_bwd(0, 0, 1, 4, 64, 0.25, 0, 0, 0, 0) == -1
+    assert lib.hos_unpack_patches_fwd(0, 0, 0, 1.0, 4, 0, 0) == -1 and lib.hos_unpack_patches_bwd(0, 0, 4, 1.0, 1.0, 1.0, 0, 0) == -1
+    assert lib.hos_lpips_finish(0, 2, 0, 0) == -1
+    assert sum(1 for v in VGG16_CFG if v != "M") == 13 and TAP_AFTER_CONV == (1, 3, 6, 9, 12)
+    assert not LPIPS().ready()
