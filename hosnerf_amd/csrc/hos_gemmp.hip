@@ -423,6 +423,9 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         if (!HOS_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);                                               \
     } while (0)
 
+#ifdef HOS_STATIC_PRIO   // experiment (MI355X_MICROARCH.md "Static priority for the younger half"): waves 4-7 at priority 1 for the whole K loop
+    if (wave >= 4) __builtin_amdgcn_s_setprio(HOS_STATIC_PRIO);
+#endif
     unsigned so = 0;                     // byte offset of the stage holding tile kt
     HOS_BSTAMP(1);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -493,6 +496,9 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         HOS_STAMP(7);
         so = sn;
     }
+#ifdef HOS_STATIC_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     HOS_BSTAMP(2);
 #undef HOS_GROUP
 #undef HOS_STAMP
