@@ -818,10 +818,12 @@ __global__ __launch_bounds__(MB_NT, 1) void chain_bwd_kernel(ChainBwdArgs a) {
         for (int i = 0; i < RW; ++i) *reinterpret_cast<u32x4*>(Wh + i * 8192 + toff) = rw[i];
     };
 
-    int rb = blockIdx.x;                                      // grid <= nrb
-    gloadZ(rb);
-    gloadX(std::integral_constant<int, 0>{}, rb);
-    loadW(std::integral_constant<int, 0>{});
+    int rb = blockIdx.x;                                      // grid <= nrb of the HOST row count; the device count may be smaller
+    if (nrb > 0) {                                            // (an empty cycle set: no row to clamp to -- only the zero partials below)
+        gloadZ(rb);
+        gloadX(std::integral_constant<int, 0>{}, rb);
+        loadW(std::integral_constant<int, 0>{});
+    }
 
     for (; rb < nrb; rb += G) {
         sstoreZ(rb);

@@ -188,7 +188,7 @@ def test_folded_chain_backward_equals_the_row_form(net, P, n_live):
 
 
 @pytest.mark.parametrize("groups", [3, 2])
-@pytest.mark.parametrize("P,n_live", [(16384 + 77, None), (65536, None), (40000, 17777), (20000, 63)])
+@pytest.mark.parametrize("P,n_live", [(16384 + 77, None), (65536, None), (40000, 17777), (20000, 63), (20000, 0)])
 def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
     """hos_mlp_chain_bwd (three group launches, dZ in LDS between the layers of a group) against the eight hos_linear_bwd_fused
     launches it replaces: d loss / d x and every parameter gradient.  Same arithmetic (bf16 pairs, same product order), so the
@@ -217,7 +217,8 @@ def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
         net.zero_grad()
     gx, gx_ref = res[True][0], res[False][0]
     assert torch.isfinite(gx).all()
-    assert float((gx - gx_ref).abs().max()) <= 1e-6 * float(gx_ref.abs().max()), float((gx - gx_ref).abs().max())
+    if n > 0:
+        assert float((gx - gx_ref).abs().max()) <= 1e-6 * float(gx_ref.abs().max()), float((gx - gx_ref).abs().max())
     assert len(res[True][1]) == 14
     for k, ref in res[False][1].items():
         got = res[True][1][k]
