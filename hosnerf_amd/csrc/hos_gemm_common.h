@@ -130,8 +130,9 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                     *relu_bits = rb;
                 }
                 if (simple && full && c_vec) {
+                    const float pre = (v[0] + v[1]) + (v[2] + v[3]);        // NaN iff a pre-activation is NaN: fmaxf below would hide it
                     if (a.epi == HOS_EPI_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    big |= fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT;
+                    big |= (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT) | (pre != pre);
                     *reinterpret_cast<float4*>(a.C + (size_t)row * a.ldc + colb) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
@@ -140,7 +141,7 @@ __device__ __forceinline__ void gemm_epilogue_tile(const GemmArgs& a, const f32x
                         if (col >= a.N) break;
                         float x = v[k];
                         if (fwd_epilogue_value(a, x, row, col)) a.C[(size_t)row * a.ldc + col] = x;
-                        if (simple) big |= fabsf(x) > HOS_RANGE_LIMIT;
+                        if (simple) big |= !(fabsf(x) <= HOS_RANGE_LIMIT);
                     }
                 }
             } else {   // MODE_DGRAD

@@ -429,8 +429,11 @@ __global__ __launch_bounds__(TH_NT, 1) void thin_fwd_fast_kernel(const ThinArgs 
                 for (int k = 0; k < 4; ++k) m = __builtin_amdgcn_alignbit(m, __float_as_uint(0.f - v[k]), 31);
                 rbits |= m << (12 - 4 * g);
             }
+            // a NaN pre-activation becomes 0 in fmaxf and would pass the range test below: the sum of the four pre-activations is
+            // NaN exactly when one of them is (or when +inf meets -inf), and NaN != NaN sets the flag
+            const float pre = (v[0] + v[1]) + (v[2] + v[3]);
             if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-            big |= fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT;
+            big |= (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) > HOS_RANGE_LIMIT) | (pre != pre);
 #ifdef HOS_EXP_NOSTORE     // timing experiment: results are written to the workgroup's first tile only (cache hits; results invalid)
             *reinterpret_cast<float4*>(a.C + (size_t)(blockIdx.x * R + q4 + 4 * lhi + 8 * g) * a.ldc + colb) = make_float4(v[0], v[1], v[2], v[3]);
 #else

@@ -268,6 +268,8 @@ class Network(FlatModule):
         lin.bias.zero_()
         for e in self.human_stateembeds:
             e.normal_()
+        if getattr(self, "_w0c", None) is not None and getattr(self.store, "param", None) is not None:
+            self._compact_from_full()          # the live taps follow the re-initialised parameter
 
     # ------------------------------------------------------------------ compact first deconvolution layer
     _LIVE_TAPS = [(od + 1) * 16 + (oh + 1) * 4 + (ow + 1) for od in range(2) for oh in range(2) for ow in range(2)]
@@ -433,9 +435,9 @@ class Network(FlatModule):
             # never built -- PE serves layer 0 and the skip layer (hos_chain.hip, FOLD).
             cond = cond.reshape(-1).contiguous()
             ops.embed_hannw(x, band_w, None, PE, rows_dev=rows_dev)
-            key = id(specs)
+            key = (id(specs),) + ops._stream_key(dev)          # per (device, stream): the folded bias belongs to this call's frame
             bufs = self._chain_bufs.get(key)
-            if bufs is None or bufs[0].device != dev or len(bufs) < 3:
+            if bufs is None or len(bufs) < 3:
                 bufs = self._chain_bufs[key] = ops.mlp_chain_buffers(dev) + (torch.empty(128, 64, device=dev),)
             ws = [self._w(L) for L in specs]
             ops.mlp_chain_pack_fold([w for w, _ in ws], [b_ for _, b_ in ws], cond, 6 * band_w.numel(), bufs[0], bufs[1], bufs[2])
@@ -485,9 +487,10 @@ class Network(FlatModule):
         # 320-wide skip layer fits the register-resident thin kernel (20 reduction steps) instead of the tiled GEMM.
         fold = None
         if ops.CNL_FOLD and ops.thin_dgrad_rows(Pn):
-            fb = self._chain_bufs.get("cnl_fold")
-            if fb is None or fb.device != dev:
-                fb = self._chain_bufs["cnl_fold"] = torch.empty(256 * (2 * CNL_NFP + 256 + 2), device=dev)
+            fkey = ("cnl_fold",) + ops._stream_key(dev)       # per (device, stream): packed with this call's embedding, read by its backward
+            fb = self._chain_bufs.get(fkey)
+            if fb is None:
+                fb = self._chain_bufs[fkey] = torch.empty(256 * (2 * CNL_NFP + 256 + 2), device=dev)
             fw = ops.cnl_fold_views(fb, 256, CNL_NFP, 256)
             (W0, b0), (W5, b5) = self._w(self._cnl[0]), self._w(self._cnl[5])
             ops.canonical_fold_pack(W0, b0, W5, b5, embed, 256, CNL_NF, 256, fw)

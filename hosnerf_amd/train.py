@@ -210,6 +210,7 @@ class FusedAdam:
         1/world scaling is applied here.  `clip_sumsq`: the joint sum of squares `step_all` formed over every optimiser of
         the step (a device scalar, or None = no clipping); left at False this optimiser clips by its own norm."""
         self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
+        _no_pending_decoder_backward(self.module)
         reduced, self.grad_is_reduced = reduced or self.grad_is_reduced, False
         g = self.module.flat_grad
         if self.exp_avg.device != g.device:       # the module was moved after the optimiser was built (`lit.to(device)`)
@@ -296,6 +297,16 @@ def range_skips(device) -> int:
     return ops.range_skips(device)
 
 
+def _no_pending_decoder_backward(module):
+    """A human network whose forward cut the graph at the motion-weight volume (`split_decoder_backward`) has the decoder's
+    backward still pending after `loss.backward()`: stepping now would train every module but the decoder, silently.
+    `train.backward_human` / `finish_backward_human` / `Network.finish_decoder_backward` run it."""
+    pend = getattr(module, "pending_volume_grad", None)
+    if pend is not None and pend() is not None:
+        raise RuntimeError("optimizer step with the volume decoder's backward still pending: call train.finish_backward_human(net, opt) "
+                           "(or net.finish_decoder_backward()) after loss.backward(), or leave net.split_decoder_backward False")
+
+
 def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
     """The optimiser step of a training step that owns several flat modules (stage 3: background + human; the reference has
     ONE torch Adam over both, optimizer.py:19-60, and Lightning clips ONE norm over it): (1) every flat gradient that was
@@ -307,6 +318,7 @@ def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
     red = list(reduced) if isinstance(reduced, (list, tuple)) else [reduced] * len(opts)
     for o, r in zip(opts, red):
         o.module.store.ensure_bound()
+        _no_pending_decoder_backward(o.module)
         if not (r or o.grad_is_reduced):
             allreduce_flat_grad(o.module, o.group)
         o.grad_is_reduced = False
