@@ -44,6 +44,8 @@ PROTOTYPES = {
     "hos_mlp_bwd_ws_floats": [_I, _I, _I, _I],
     "hos_linear_wgrad_tr": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _L, _P],
     "hos_linear_bwd_fused": [_P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P, _P],
+    "hos_stage1_loss_fwd": [_P, _P, _I, _P, _P, _I, _P, _F, _F, _F, _F, _P, _P],
+    "hos_stage1_loss_bwd": [_P, _P, _I, _I, _P, _P, _F, _F, _F, _F, _P, _P, _P, _P],
     "hos_lpips_prep": [_P, _L, _P, _P],
     "hos_im2col3x3": [_P, _I, _I, _I, _I, _P, _I, _P],
     "hos_col2im3x3": [_P, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -249,3 +249,78 @@ extern "C" int hos_train_losses_bwd(const float* g_total, const float* out8, con
     hipLaunchKernelGGL(losses_bwd_kernel, dim3(grid_for(a)), dim3(LT), 0, static_cast<hipStream_t>(stream), a);
     return hos_launch_status();
 }
+
+// ================================================================================================================
+// Tail of the stage-1 loss (1st_State-Conditional_Scene/src/model/mipnerf360/model.py:491-514): from the rendered colours and the
+// per-ray interlevel / distortion terms (hos_interlevel_fwd, hos_distortion_fwd) to the scalar the step differentiates,
+//   total = m_data sqrt(mean((rgb - target)^2) + pad^2) + m_inter sum_l sum_rays(inter_l) / (B Sc) + m_dist mean_rays(dist),
+// as one single-workgroup launch (fixed summation order) and one backward launch -- the torch form was ~15 element-wise / reduction
+// launches forward and as many backward, 2 % of the 1024-ray step.  out = [total, mse, interlevel, distortion].
+// ================================================================================================================
+namespace {
+
+__device__ __forceinline__ float block_sum_1024(float v, float* s_red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < 16; ++i) t += s_red[i];
+    __syncthreads();
+    return t;                         // valid in thread 0
+}
+
+__global__ __launch_bounds__(1024) void stage1_loss_fwd_kernel(const float* __restrict__ rgb, const float* __restrict__ target, int B,
+                                                               const float* __restrict__ inter0, const float* __restrict__ inter1, int Sc,
+                                                               const float* __restrict__ dist, float m_data, float m_inter, float m_dist,
+                                                               float pad, float* __restrict__ out) {
+    __shared__ float s_red[16];
+    float a = 0.f, b0 = 0.f, b1 = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < 3 * B; i += 1024) { const float d = rgb[i] - target[i]; a += d * d; }
+    for (int i = threadIdx.x; i < B; i += 1024) {
+        if (inter0) b0 += inter0[i];
+        if (inter1) b1 += inter1[i];
+        c += dist[i];
+    }
+    const float sa = block_sum_1024(a, s_red), s0 = block_sum_1024(b0, s_red), s1 = block_sum_1024(b1, s_red), sc = block_sum_1024(c, s_red);
+    if (threadIdx.x == 0) {
+        const float mse = sa / (3.f * B);
+        const float inter = s0 / ((float)B * Sc) + s1 / ((float)B * Sc);
+        const float dm = sc / (float)B;
+        out[0] = sqrtf(mse + pad * pad) * m_data + inter * m_inter + dm * m_dist;
+        out[1] = mse; out[2] = inter; out[3] = dm;
+    }
+}
+
+// g_rgb = gout m_data (rgb - target) / (3 B sqrt(mse + pad^2));  g_inter (both levels) = gout m_inter / (B Sc);  g_dist = gout m_dist / B
+__global__ __launch_bounds__(256) void stage1_loss_bwd_kernel(const float* __restrict__ rgb, const float* __restrict__ target, int B, int Sc,
+                                                              const float* __restrict__ fwd_out, const float* __restrict__ gout, float m_data,
+                                                              float m_inter, float m_dist, float pad, float* __restrict__ g_rgb,
+                                                              float* __restrict__ g_inter, float* __restrict__ g_dist) {
+    const float g = gout[0];
+    const float k = g * m_data / (3.f * B * sqrtf(fwd_out[1] + pad * pad));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * B; i += gridDim.x * 256) g_rgb[i] = k * (rgb[i] - target[i]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) {
+        g_inter[i] = g * m_inter / ((float)B * Sc);
+        g_dist[i] = g * m_dist / (float)B;
+    }
+}
+
+}  // namespace
+
+extern "C" int hos_stage1_loss_fwd(const float* rgb, const float* target, int B, const float* inter0, const float* inter1, int Sc, const float* dist,
+                                   float m_data, float m_inter, float m_dist, float charb_padding, float* out4, hos_stream_t stream) {
+    if (!rgb || !target || !dist || !out4 || B <= 0 || Sc <= 0) return HOS_E_ARG;
+    hipLaunchKernelGGL(stage1_loss_fwd_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), rgb, target, B, inter0, inter1, Sc, dist, m_data,
+                       m_inter, m_dist, charb_padding, out4);
+    return hos_launch_status();
+}
+
+extern "C" int hos_stage1_loss_bwd(const float* rgb, const float* target, int B, int Sc, const float* fwd_out4, const float* gout, float m_data,
+                                   float m_inter, float m_dist, float charb_padding, float* g_rgb, float* g_inter, float* g_dist, hos_stream_t stream) {
+    if (!rgb || !target || !fwd_out4 || !gout || !g_rgb || !g_inter || !g_dist || B <= 0 || Sc <= 0) return HOS_E_ARG;
+    int blocks = (3 * B + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(stage1_loss_bwd_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rgb, target, B, Sc, fwd_out4, gout, m_data,
+                       m_inter, m_dist, charb_padding, g_rgb, g_inter, g_dist);
+    return hos_launch_status();
+}

@@ -955,6 +955,42 @@ def distortion_loss_per_ray(t, w):
     return _Distortion.apply(t.detach().contiguous(), w.contiguous())
 
 
+class _Stage1LossTail(torch.autograd.Function):
+    """M1:491-514 behind the per-ray terms: one forward and one backward launch (hos_stage1_loss_{fwd,bwd})."""
+
+    @staticmethod
+    def forward(ctx, rgb, target, dist, Sc, mults, inter0, inter1):
+        rgb, target, dist = rgb.contiguous(), target.contiguous(), dist.contiguous()
+        i0 = None if inter0 is None else inter0.contiguous()
+        i1 = None if inter1 is None else inter1.contiguous()
+        out = torch.empty(4, device=rgb.device)
+        call("hos_stage1_loss_fwd", ptr(rgb), ptr(target), rgb.shape[0], ptr(i0), ptr(i1), Sc, ptr(dist), *mults, ptr(out))
+        ctx.save_for_backward(rgb, target, out)
+        ctx.Sc, ctx.mults, ctx.have = Sc, mults, (inter0 is not None, inter1 is not None)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g_total, _g_parts):
+        rgb, target, out = ctx.saved_tensors
+        B = rgb.shape[0]
+        g_rgb = torch.empty_like(rgb)
+        g_inter = torch.empty(B, device=rgb.device)
+        g_dist = torch.empty(B, device=rgb.device)
+        call("hos_stage1_loss_bwd", ptr(rgb), ptr(target), B, ctx.Sc, ptr(out), ptr(g_total.reshape(1).contiguous()), *ctx.mults,
+             ptr(g_rgb), ptr(g_inter), ptr(g_dist))
+        return g_rgb, None, g_dist, None, None, (g_inter if ctx.have[0] else None), (g_inter if ctx.have[1] else None)
+
+
+def stage1_loss_tail(rgb, target, inter, dist, Sc, m_data, m_inter, m_dist, pad):
+    """(total, [total, mse, interlevel, distortion]) from the per-ray terms `inter` (list of at most two [B] tensors) and `dist` [B]."""
+    if len(inter) > 2:
+        raise _lib.HosLibraryError("stage1_loss_tail: at most two proposal levels")
+    i0 = inter[0] if len(inter) > 0 else None
+    i1 = inter[1] if len(inter) > 1 else None
+    return _Stage1LossTail.apply(rgb, target, dist, int(Sc), (float(m_data), float(m_inter), float(m_dist), float(pad)), i0, i1)
+
+
 def head_grad_padded(g_density, density, g_rgb, rgb, rgb_padding, dz_density, col_dd, dz_rgb):
     """head_grad that also zeroes the padding columns of its two operand rows (which may be uninitialised storage)."""
     P = density.numel()

@@ -21,12 +21,19 @@ from .flat import FlatModule
 def stage1_loss(rgb: torch.Tensor, target: torch.Tensor, ray_history: List[Dict[str, torch.Tensor]],
                 data_loss_mult: float = 1.0, interlevel_loss_mult: float = 1.0, distortion_loss_mult: float = 0.01,
                 charb_padding: float = 0.001) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-    """M1:491-514: sqrt(mse + charb^2) + interlevel + 0.01 * distortion (means over the local ray batch)."""
-    mse = torch.mean((rgb - target.to(rgb.dtype)) ** 2)
-    loss = torch.sqrt(mse + charb_padding**2) * data_loss_mult
+    """M1:491-514: sqrt(mse + charb^2) + interlevel + 0.01 * distortion (means over the local ray batch).  On the device the tail behind
+    the per-ray interlevel / distortion kernels is ONE launch each way (ops.stage1_loss_tail); CPU tensors take the torch form."""
     last = ray_history[-1]
     c, w = last["sdist"], last["weights"]
     B, Sc = w.shape
+    if rgb.is_cuda and len(ray_history) <= 3:
+        inter = [ops.interlevel_loss_per_ray(c, w, h["sdist"], h["weights"]) for h in ray_history[:-1]]
+        dist_ray = ops.distortion_loss_per_ray(c, w)
+        total, parts = ops.stage1_loss_tail(rgb, target.to(rgb.dtype), inter, dist_ray, Sc, data_loss_mult, interlevel_loss_mult,
+                                            distortion_loss_mult, charb_padding)
+        return total, {"mse": parts[1], "interlevel": parts[2], "distortion": parts[3]}
+    mse = torch.mean((rgb - target.to(rgb.dtype)) ** 2)
+    loss = torch.sqrt(mse + charb_padding**2) * data_loss_mult
     inter = rgb.new_zeros(())
     for h in ray_history[:-1]:
         inter = inter + ops.interlevel_loss_per_ray(c, w, h["sdist"], h["weights"]).sum() / (B * Sc)

@@ -683,6 +683,15 @@ int hos_unpack_patches_fwd(const float* rgb, const int32_t* idx, const float* bg
 int hos_unpack_patches_bwd(const float* g_img, const int32_t* idx, int64_t n_pixels, float s0, float s1, float s2, float* g_rgb,
                            hos_stream_t stream);
 
+/* Tail of the stage-1 loss (1st_State-Conditional_Scene/src/model/mipnerf360/model.py:491-514) in one launch each way:
+ *   out4 = [m_data sqrt(mse + pad^2) + m_inter (sum inter0 + sum inter1) / (B Sc) + m_dist mean(dist), mse, interlevel, distortion]
+ * from rgb / target [B,3] and the per-ray terms of hos_interlevel_fwd (inter0 / inter1 [B], either may be NULL) and hos_distortion_fwd
+ * (dist [B]); the backward writes g_rgb [B,3] and the (constant) gradients of the per-ray terms, scaled by gout[0]. */
+int hos_stage1_loss_fwd(const float* rgb, const float* target, int B, const float* inter0, const float* inter1, int Sc, const float* dist,
+                        float m_data, float m_inter, float m_dist, float charb_padding, float* out4, hos_stream_t stream);
+int hos_stage1_loss_bwd(const float* rgb, const float* target, int B, int Sc, const float* fwd_out4, const float* gout, float m_data,
+                        float m_inter, float m_dist, float charb_padding, float* g_rgb, float* g_inter, float* g_dist, hos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
