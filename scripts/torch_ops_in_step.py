@@ -1,6 +1,6 @@
 """Which torch (aten) kernels does a stage-3 step still launch, and from which source line?  A TorchDispatchMode records every
 aten call of one eager step (forward on this thread, backward on the autograd thread) with the innermost hosnerf_amd / bench frame.
-  python scripts/torch_ops_in_step.py [rays]"""
+  python scripts/torch_ops_in_step.py [rays] [stage3|stage2|stage1]"""
 import collections, os, sys, threading, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,10 +9,12 @@ import bench
 from hosnerf_amd import ops
 
 rays = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+STAGE = sys.argv[2] if len(sys.argv) > 2 else "stage3"
 dev = torch.device("cuda")
 ops.set_gemm_mode(ops.GEMM_PLANES)
-w = bench.Stage3(dev, 0, 1, rays)
-w.hos.two_streams = False
+w = {"stage3": bench.Stage3, "stage2": bench.Stage2, "stage1": bench.Stage1}[STAGE](dev, 0, 1, rays)
+if STAGE == "stage3":
+    w.hos.two_streams = False
 for i in range(3):
     w.eager_step(i)
 torch.cuda.synchronize()
@@ -44,6 +46,6 @@ torch.autograd.set_multithreading_enabled(False)
 with Rec():
     w.eager_step(3)
 torch.cuda.synchronize()
-print(f"device aten calls in one {rays}-ray stage-3 step (views / allocations not counted): {sum(agg.values())}")
+print(f"device aten calls in one {rays}-ray {STAGE} step (views / allocations not counted): {sum(agg.values())}")
 for (name, site), n in sorted(agg.items(), key=lambda kv: (-kv[1], kv[0])):
     print(f"{n:4d} x {name:26s} {site}")
