@@ -50,6 +50,9 @@ def parse_args(argv=None):
     # additions of this build
     p.add_argument("--cpu", action="store_true", help="plumbing only (BASELINE configs[0]): no kernel is launched, no GPU needed")
     p.add_argument("--items", type=str, default=None, help="torch-saved list of dataset items (reference keys); default: synthetic")
+    p.add_argument("--lpips_vgg16", type=str, default=None, help="torchvision's vgg16 checkpoint (vgg16-397923af.pth): with --lpips_lin "
+                   "enables the reference's LPIPS term (weight 1.0, configs/default.yaml:97-101) in stages 2 / 3")
+    p.add_argument("--lpips_lin", type=str, default=None, help="the reference's third_parties/lpips/weights/v0.1/vgg.pth")
     p.add_argument("--rays", type=int, default=0, help="rays per step and GPU for synthetic items (default: the stage's reference batch)")
     return p.parse_args(argv)
 
@@ -194,6 +197,12 @@ def run(args, gin):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     lit = lit.to(dev)
+    if args.lpips_vgg16 or args.lpips_lin:
+        if not (args.lpips_vgg16 and args.lpips_lin) or not hasattr(lit, "human"):
+            raise SystemExit("--lpips_vgg16 and --lpips_lin go together and apply to the stages that own the human-object network")
+        from hosnerf_amd.lpips import LPIPS
+        lit.lpips = LPIPS.from_files(args.lpips_vgg16, args.lpips_lin, dev)          # M:582-584
+        print(f"[run] LPIPS term enabled (weight 1.0): {args.lpips_vgg16}, {args.lpips_lin}")
     items = torch.load(args.items, weights_only=False) if args.items else None
     run_train = bool(kw.get("run_train", True))
     log_every = int(kw.get("log_every_n_steps", 100))

@@ -119,3 +119,28 @@ def test_stage2_step_with_the_lpips_term(net, tmp_path):
     opt.step(1e-4)
     torch.cuda.synchronize()
     assert torch.isfinite(hn.flat_param).all() and float(hn.flat_grad.abs().max()) > 0
+
+
+def test_launcher_enables_the_term_from_weight_files(tmp_path):
+    """`run.py --lpips_vgg16 <torchvision checkpoint> --lpips_lin <the reference's vgg.pth>`: files in the formats of the two real
+    checkpoints (`features.N.*` keys; `lin{k}.model.1.weight` [1, C, 1, 1]) -> two real stage-3 optimiser steps with the term."""
+    import subprocess
+    from make_golden_lpips import vgg16_features_state
+    from hosnerf_amd.lpips import CHNS
+    root = os.path.dirname(HERE)
+    vgg = {f"features.{k}": v for k, v in vgg16_features_state().items()}
+    vgg["classifier.0.weight"] = torch.zeros(2, 2)                  # the classifier of the real checkpoint is ignored
+    torch.save(vgg, str(tmp_path / "vgg16.pth"))
+    lin, off = {}, 0
+    for k, c in enumerate(CHNS):
+        lin[f"lin{k}.model.1.weight"] = torch.from_numpy(G["lin"][off:off + c].copy()).view(1, c, 1, 1)
+        off += c
+    torch.save(lin, str(tmp_path / "lin.pth"))
+    cmd = [sys.executable, os.path.join(root, "run.py"), "--ginc", os.path.join(root, "configs", "hosnerf_backpack.gin"), "--ginb", "run.max_steps=2",
+           "--ginb", "run.log_every_n_steps=1", "--ginb", 'run.human_path=""', "--ginb", 'run.bkgd_path=""', "--logbase", str(tmp_path / "logs"),
+           "--scene_name", "synthetic", "--rays", "1024", "--lpips_vgg16", str(tmp_path / "vgg16.pth"), "--lpips_lin", str(tmp_path / "lin.pth")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "LPIPS term enabled" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("[run] step")]
+    assert len(lines) == 2 and all(np.isfinite(float(l.split("loss")[1].split()[0])) for l in lines), r.stdout[-2000:]
