@@ -12,8 +12,14 @@ LIB   := hosnerf_amd/lib/libhosrender.so
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -Xclang -target-feature -Xclang -packed-fp32-ops -Iinclude -Ihosnerf_amd/csrc -Wno-unused-result
 
 COMM  := hosnerf_amd/lib/libhoscomm.so
+ROCM_PATH ?= $(shell d=$$(dirname $$(dirname $$(readlink -f $(HIPCC)))); [ -d $$d/include ] && echo $$d || echo /opt/rocm)
+HAVE_RCCL := $(shell [ -f $(ROCM_PATH)/include/rccl/rccl.h ] && ls $(ROCM_PATH)/lib/librccl.so* >/dev/null 2>&1 && echo 1)
 
-all: $(LIB) $(COMM)
+# libhoscomm.so (in-graph collectives, optional: torch.distributed stays the default path) is built only where RCCL exists
+all: $(LIB) $(if $(HAVE_RCCL),$(COMM),comm-skipped)
+
+comm-skipped:
+	@echo "note: rccl.h / librccl.so not found under $(ROCM_PATH): libhoscomm.so not built (hosnerf_amd.comm falls back to torch.distributed)"
 
 build/%.o: hosnerf_amd/csrc/%.hip hosnerf_amd/csrc/hos_common.h hosnerf_amd/csrc/hos_gemm_common.h include/hosrender.h
 	@mkdir -p build
@@ -27,8 +33,8 @@ $(LIB): $(OBJ)
 # libhosrender.so does not depend on librccl.so
 $(COMM): hosnerf_amd/csrc_comm/hos_comm.cpp include/hoscomm.h
 	@mkdir -p hosnerf_amd/lib
-	$(HIPCC) -O2 -std=c++17 -fPIC -shared -Iinclude -I/opt/rocm/include $< -o $@ -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared -Iinclude -I$(ROCM_PATH)/include $< -o $@ -L$(ROCM_PATH)/lib -lrccl -Wl,-rpath,$(ROCM_PATH)/lib
 
 clean:
 	rm -rf build $(LIB) $(COMM)
-.PHONY: all clean
+.PHONY: all clean comm-skipped

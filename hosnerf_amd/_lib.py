@@ -71,6 +71,8 @@ PROTOTYPES = {
     "hos_split_planes_t_batch": [_I, _P, _P, _P, _P, _P, _P, _P],
     "hos_split_planes2": [_P, _I, _I, _I, _P, _I, _P, _I, _P],
     "hos_planes_rowdot": [_P, _I, _I, _P, _P, _F, _I, _L, _P, _P],
+    "hos_planes_rowdot_b": [_P, _I, _I, _P, _P, _F, _I, _L, _P, _P],
+    "hos_linearp_fwd_b": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P, _I, _F, _P],
     "hos_linearp_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _I, _P],
     "hos_linearp_wgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hos_resample": [_P, _P, _I, _I, _I, _F, _F, _P, _F, _F, _P, _P, _F, _F, _F, _P, _P, _P, _P],

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
             feat(s, c, a0, a1);
             feat(s, c + 1, b0, b1);
             const size_t o0 = plane_off(p0 + s, c, ldx), o1 = plane_off(p0 + s, c + HALF, ldx);
-            split_store2<_Float16>(p16, o0, a0, b0); split_store2<_Float16>(p16, o1, a1, b1);
+            if (p16 != nullptr) { split_store2<_Float16>(p16, o0, a0, b0); split_store2<_Float16>(p16, o1, a1, b1); }
             if (pb != nullptr) { split_store2<__bf16>(pb, o0, a0, b0); split_store2<__bf16>(pb, o1, a1, b1); }
         }
     }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
             if (p0 + s >= P) break;
             const float v0 = (c < NEMB) ? s_embed[c] : 0.f, v1 = (c + 1 < NEMB) ? s_embed[c + 1] : 0.f;
             const size_t o = plane_off(p0 + s, NIPE + c, ldx);
-            split_store2<_Float16>(p16, o, v0, v1);
+            if (p16 != nullptr) split_store2<_Float16>(p16, o, v0, v1);
             if (pb != nullptr) split_store2<__bf16>(pb, o, v0, v1);
         }
     }
@@ -229,7 +229,7 @@ extern "C" int hos_encode_ipe(const float* tdist, const float* rays_o, const flo
 extern "C" int hos_encode_ipe_planes(const float* tdist, const float* rays_o, const float* rays_d, const float* radii,
                                      const float* basis, const float* embed, int B, int S, void* p16, void* pb, int ld,
                                      hos_stream_t stream) {
-    if (!tdist || !rays_o || !rays_d || !radii || !basis || !embed || !p16 || B <= 0 || S <= 0) return HOS_E_ARG;
+    if (!tdist || !rays_o || !rays_d || !radii || !basis || !embed || (!p16 && !pb) || B <= 0 || S <= 0) return HOS_E_ARG;
     if (ld < NIPE + NEMB || (ld & 31)) return HOS_E_SHAPE;
     const long P = (long)B * S;
     hipLaunchKernelGGL(encode_ipe_kernel<true>, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0,

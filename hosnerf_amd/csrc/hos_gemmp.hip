@@ -40,13 +40,12 @@
 #ifndef HOS_ABLATE_DMA
 #define HOS_ABLATE_DMA 0
 #endif
-#ifndef HOS_NO_SETPRIO
-#define HOS_NO_SETPRIO 0
-#endif
-// 1 / 2: the B waves issue their DMA requests in group 1 / 2 of the NEXT iteration instead of group 4 (0: both in group 4).
-// Measured at [131072,1024,1024]: fwd 730 -> 705 us, dgrad 825 -> 805 us, wgrad unchanged.
-#ifndef HOS_DMA_STAGGER
-#define HOS_DMA_STAGGER 1
+// Round 5: FWD / DGRAD launches of the 256-wide tile are PERSISTENT -- one workgroup per CU walks the output tiles and the K
+// pipeline (LDS-DMA two tiles ahead) runs straight across tile boundaries, so a tile has no prologue: its first two K tiles
+// are requested while the previous tile still multiplies, and its epilogue's stores drain under the next tile's K loop.
+// 0 = one workgroup per output tile (the round 1-4 launch), kept for same-box A/B.
+#ifndef HOS_GEMMP_PERSIST
+#define HOS_GEMMP_PERSIST 1
 #endif
 
 namespace {
@@ -84,7 +83,7 @@ struct PArgs {
     uint16_t* Y; int ldy;                         // row-major planes [M][ldy]: fp16 for FWD, bf16 for DGRAD
     uint16_t* Yb; int ldyb;                       // FWD only: the same values as bf16 planes (WGRAD operand)
     uint32_t* bits; int bits_nb;                  // ReLU bit mask (FWD writes, DGRAD reads), 64-column blocks per row block
-    int stagger;                                  // experiment: first-round workgroups start ((bid>>3)&7) * stagger * ~4 us late
+    int total;                                    // output tiles x K splits (virtual block ids)
 };
 
 template <typename E> __device__ __forceinline__ uint16_t to_bits(E v) { return __builtin_bit_cast(uint16_t, v); }
@@ -127,8 +126,10 @@ __device__ __forceinline__ s16x4 lds_tr(const char* p) {
 }
 
 // TR = false: both operands k-contiguous (FWD, DGRAD).  TR = true: both operands reduction-row-major (WGRAD).
-template <int BN, int EPI, typename EIN, bool TR>
+// PERSIST: the workgroup walks output tiles blockIdx.x, blockIdx.x + gridDim.x, ... (k-contiguous form, BN = 256, nk >= 2).
+template <int BN, int EPI, typename EIN, bool TR, bool PERSIST>
 __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
+    static_assert(!PERSIST || (!TR && BN == 256), "persistent form: k-contiguous operands, 256-wide tile");
     typedef typename PVec<EIN>::x8 ex8;
     constexpr int WN = 2;
     constexpr int TM = PBM / (4 * 32);       // 2
@@ -147,33 +148,28 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int nb = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nb >> 3, r = nb & 7, x = bid & 7, y = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
-    }
-    const int tn_i = bid % a.tiles_n;
-    const int tm_i = (bid / a.tiles_n) % a.tiles_m;
-    const int split = bid / (a.tiles_n * a.tiles_m);
-    const int i0 = tm_i * PBM, j0 = tn_i * BN;
-    const int kt_begin = split * a.kt_per_split;
-    const int kt_end = min(a.nk, kt_begin + a.kt_per_split);
+    // virtual block id -> (row tile, column tile, K split); consecutive ids of one XCD share the A panel
+    const int nb = a.total;
+    int tm_i, tn_i, split;
+    auto decode = [&](int vb) {
+        const int q = nb >> 3, r = nb & 7, x = vb & 7, y = vb >> 3;
+        const int bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + y;
+        tn_i = bid % a.tiles_n;
+        tm_i = (bid / a.tiles_n) % a.tiles_m;
+        split = bid / (a.tiles_n * a.tiles_m);
+    };
+    int vb = blockIdx.x;
+    decode(vb);
+    int i0 = tm_i * PBM, j0 = tn_i * BN;
+    const int kt_begin = PERSIST ? 0 : split * a.kt_per_split;
+    const int kt_end = PERSIST ? a.nk : min(a.nk, kt_begin + a.kt_per_split);
     if (kt_begin >= kt_end) return;
-    if (a.stagger > 0 && blockIdx.x < 256) {
-        const int g = (blockIdx.x >> 3) & 7;
-        for (int i = 0; i < g * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
 
     // ---- DMA plan of this wave -----------------------------------------------------------------------------------
     const bool isB = wave >= 4;                  // waves 0-3 stage the A tile, waves 4-7 the B tile
     const int quarter = wave & 3;                // ... one quarter of it each
     const int nq = isB ? QB : QA;                // instructions per K tile
-#ifdef HOS_EXP_SAME_A      // timing experiment: every workgroup streams the SAME A panel (all L2 hits)
-    const int g_row0 = isB ? j0 : 0;
-#else
-    const int g_row0 = isB ? j0 : i0;            // first output row (k-contiguous) / first column (TR) of this side
-#endif
+    int g_row0 = isB ? j0 : i0;                  // first output row (k-contiguous) / first column (TR) of this side
     const int g_limit = isB ? a.N : a.M;
     // Source arrays selected ONCE into scalars.  (Selecting them inside the DMA lambda made hipcc build a pointer
     // table in scratch; every scratch_load result was then waited for with vmcnt(0), which drained the LDS-DMA
@@ -192,13 +188,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // TR form: instruction q covers 1 KB of this wave's 8 reduction rows; pitch = 4 * (columns of the tile)
     const int tr_pitch = isB ? B_PITCH : A_PITCH;
 
-    auto issue_dma = [&](int q, int kt, int stage) {
-#ifdef HOS_EXP_SKIP_B_DMA      // timing experiment: only the A tile is staged (half the DMA bytes; results invalid)
-        if (isB) return;
-#endif
-#ifdef HOS_EXP_SKIP_A_DMA
-        if (!isB) return;
-#endif
+    auto issue_dma = [&](int q, int kt, int stage, int row0) {
         size_t off;            // 64-bit: 4 Mi rows x 576 columns x 2 planes already exceeds 2^32 elements (65 536-ray proposal levels)
         const uint16_t* P;
         if constexpr (!TR) {
@@ -206,7 +196,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             P = seg1 ? P1 : P0;
             const int ld = seg1 ? ld1 : ld0;
             const int kb = seg1 ? kt - kt0 : kt;                         // 32-column block of the row
-            int gr = g_row0 + kc_row + 8 * q;
+            int gr = row0 + kc_row + 8 * q;
             gr = gr < g_limit ? gr : g_limit - 1;                       // clamp: out-of-range rows are never stored
             const int chunk = kc_pos ^ (kc_swz | ((q & 1) << 2));       // 0-3: hi k 0..31, 4-7: lo
             off = (size_t)gr * (size_t)(2 * ld) + (size_t)(kb * 64 + chunk * 8);
@@ -216,7 +206,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             const int m = quarter * 8 + pos / tr_pitch;                 // reduction row inside the K tile
             const int rb = pos % tr_pitch;                              // byte inside the LDS row
             const int unit = (rb >> 6) ^ (m & 3);                       // source 64-byte unit (swizzle on the source)
-            int gc = g_row0 + (unit >> 1) * 32 + ((rb >> 4) & 3) * 8;   // logical column of this 16-byte piece
+            int gc = row0 + (unit >> 1) * 32 + ((rb >> 4) & 3) * 8;     // logical column of this 16-byte piece
             gc = gc < ((g_limit + 7) & ~7) ? gc : 0;                    // clamp: columns past the operand are never stored
             off = (size_t)(kt * PBK + m) * (size_t)(2 * ld0) + (size_t)((gc >> 5) * 64 + (unit & 1) * 32 + (gc & 31));
         }
@@ -224,13 +214,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     };
 
     f32x16 acc[TM][TN];
-#pragma unroll
-    for (int x = 0; x < TM; ++x)
-#pragma unroll
-        for (int y = 0; y < TN; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-
+    unsigned bw_ok_mask = 0xffffffffu;         // DGRAD: blocks whose ReLU bit dword exists (set per tile)
     const int l31 = lane & 31, lhi = lane >> 5;
     float dbsum[TM];
 #pragma unroll
@@ -241,7 +225,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // hipcc's own waitcnt insertion puts lgkmcnt(0) in front of every MFMA group of this loop (it stops counting
     // once an LDS-DMA is in flight), i.e. it would also wait for the reads just issued for the NEXT quarter.  The
     // reads are therefore asm statements the compiler does not count, every MFMA group is preceded by an asm
-    // s_waitcnt lgkmcnt(N), N = LDS reads issued after the ones the group needs (LDS returns in order), and the
+    // s_waitcnt lgkmcnt(0) (LDS returns in order and the next quarter's reads are issued BEHIND that wait), and the
     // fragments pass through that statement as "+v" operands so no MFMA can be scheduled above its wait
     // (cdna_hip_programming.md 5.7, form (ii)).
     //   k-contiguous: lane (row = l31, k half = lhi) reads chunk (2s + lhi) [hi] / 4 + (2s + lhi) [lo] of its 128-byte
@@ -311,10 +295,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         }                                                                                                      \
     } while (0)
 #define HOS_READ_B(SET_H, SET_L, STG, S, YH) do { HOS_READ_B1(SET_H, SET_L, STG, S, YH, 0); HOS_READ_B1(SET_H, SET_L, STG, S, YH, 1); } while (0)
-    constexpr int RPF = TR ? 2 : 1;                  // LDS read instructions per fragment
-    constexpr int NRA = 2 * TM * RPF;                // ... per A fragment set
-    constexpr int NRB = 2 * TH * RPF;                // ... per B fragment set
-    // wait until at most N LDS reads are outstanding, then make the fragments of one A and one B set visible
+    // make the fragments of one A and one B set visible behind a wait
     auto tie = [&](Frag& f) {
         if constexpr (!TR) { asm volatile("" : "+v"(f.v)); }
         else {
@@ -323,12 +304,6 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             f.v = __builtin_bit_cast(ex8, j);
         }
     };
-#define HOS_WAIT(N, AH, AL, BH, BL)                                                      \
-    do {                                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"((N) > 15 ? 15 : (N)) : "memory");    \
-        _Pragma("unroll") for (int x = 0; x < TM; ++x) { tie(AH[x]); tie(AL[x]); }       \
-        _Pragma("unroll") for (int y = 0; y < TH; ++y) { tie(BH[y]); tie(BL[y]); }       \
-    } while (0)
     // bias gradient (WGRAD): the A fragments of the wn == 0 waves hold dZ[m][n] for 8 m per lane
     auto db_acc = [&](const Frag (&ah)[TM], const Frag (&al)[TM]) {
         if constexpr (EPI == PEPI_WGRAD) {
@@ -344,34 +319,20 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // ---- main loop: software-pipelined over QUARTER tiles (k half s = 0/1  x  column half yh = 0/1) -----------
     // Two A fragment sets (one per k half) and two B fragment sets (one per quarter) rotate so that every
     // quarter's LDS reads fly under the previous quarter's MFMAs; two LDS stages; the DMA runs one tile ahead:
-    //     read B1=(s0,yh1)              | MFMA (A0,B0)
-    //     read A1=(s1), B0=(s1,yh0)     | MFMA (A0,B1)
-    //     read B1=(s1,yh1)              | MFMA (A1,B0)
+    //     read B1=(s0,yh1), B waves: DMA(kt+1) | MFMA (A0,B0)
+    //     read A1=(s1), B0=(s1,yh0)            | MFMA (A0,B1)
+    //     read B1=(s1,yh1)                     | MFMA (A1,B0)
     //     wait DMA(kt+1) + own reads, barrier        <- one barrier per K tile
-    //     DMA(kt+2) -> stage(kt) | read A0,B0 of kt+1 | MFMA (A1,B1)
+    //     A waves: DMA(kt+2) -> stage(kt) | read A0,B0 of kt+1 | MFMA (A1,B1)
+    // Each SIMD holds one A wave and one B wave; the older (A) wave wins the MFMA arbitration, so the B wave is starved
+    // during the first group behind the barrier anyway and issues its requests there (weights: L2 hits, short latency)
+    // instead of together with the A wave in the last group, where both stalled on DMA issue at once (-3 %).
     // All waits are explicit (asm s_waitcnt + raw s_barrier): __syncthreads() would drain the LDS-DMA queue
     // (vmcnt(0)) wherever the compiler places it, which serialises DMA and MFMA at one workgroup per CU.
-#define HOS_MMA(AH, AL, BH, BL, YH)                                                      \
-    do {                                                                                 \
-        __builtin_amdgcn_s_setprio(1);                                                   \
-        if (!HOS_ABLATE_MFMA) {                                                          \
-            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
-            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
-                acc[x][(YH) * TH + y] = pmfma(AL[x].v, BH[y].v, acc[x][(YH) * TH + y]);  \
-            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
-            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
-                acc[x][(YH) * TH + y] = pmfma(AH[x].v, BL[y].v, acc[x][(YH) * TH + y]);  \
-            _Pragma("unroll") for (int x = 0; x < TM; ++x)                               \
-            _Pragma("unroll") for (int y = 0; y < TH; ++y)                               \
-                acc[x][(YH) * TH + y] = pmfma(AH[x].v, BH[y].v, acc[x][(YH) * TH + y]);  \
-        }                                                                                \
-        __builtin_amdgcn_s_setprio(0);                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-    } while (0)
-    auto issue_tile = [&](int kt, int stage) {
+    auto issue_tile = [&](int kt, int stage, int row0) {
         if (HOS_ABLATE_DMA) return;
 #pragma unroll
-        for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt, stage);
+        for (int q = 0; q < QMAX; ++q) if (q < nq) issue_dma(q, kt, stage, row0);
     };
 
 #ifdef HOS_TRACE   // block timeline: entry / loop start / loop end / exit of workgroups 0 and 300 (second round)
@@ -382,9 +343,29 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #else
 #define HOS_BSTAMP(slot) do {} while (0)
 #endif
+#ifdef HOS_TRACE2  // per-tile timeline of workgroups 0 and 100, waves 0 and 4: K loop start / end, epilogue end, next tile ready
+    int tile_no = 0;
+#define HOS_TSTAMP(slot) do { if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && (wave & 3) == 0 && a.f32.aux && tile_no < 16) \
+        reinterpret_cast<long long*>(a.f32.aux)[(((blockIdx.x ? 1 : 0) * 2 + (wave >> 2)) * 16 + tile_no) * 4 + (slot)] = clock64(); } while (0)
+#define HOS_WSTAMP(slot) do { if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && (wave & 3) == 0 && a.f32.aux) { \
+        reinterpret_cast<long long*>(a.f32.aux)[256 + (((blockIdx.x ? 1 : 0) * 2 + (wave >> 2)) * 2 + (slot)) * 2] = wall_clock64(); \
+        reinterpret_cast<long long*>(a.f32.aux)[256 + (((blockIdx.x ? 1 : 0) * 2 + (wave >> 2)) * 2 + (slot)) * 2 + 1] = clock64(); } } while (0)
+// every workgroup: wall clock at entry / exit and its XCC id (aux[512 + 4 b ..])
+#define HOS_ASTAMP(slot) do { if (lane == 0 && wave == 0 && a.f32.aux && blockIdx.x < 4096) { \
+        reinterpret_cast<long long*>(a.f32.aux)[512 + 4 * blockIdx.x + (slot)] = wall_clock64(); \
+        if ((slot) == 0) { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+                           unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); \
+                           reinterpret_cast<long long*>(a.f32.aux)[512 + 4 * blockIdx.x + 2] = (long long)(xcc & 0xf) | ((long long)hwid << 8); } } } while (0)
+#else
+#define HOS_TSTAMP(slot) do {} while (0)
+#define HOS_WSTAMP(slot) do {} while (0)
+#define HOS_ASTAMP(slot) do {} while (0)
+#endif
     HOS_BSTAMP(0);
-    issue_tile(kt_begin, 0);
-    if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
+    HOS_WSTAMP(0);
+    HOS_ASTAMP(0);
+    issue_tile(kt_begin, 0, g_row0);
+    if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1, g_row0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     HOS_READ_A(a0h, a0l, 0u, 0);
@@ -392,12 +373,12 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 
 #ifdef HOS_TRACE   // timing experiment: lane 0 of every wave of workgroup 0 stamps the phase boundaries of K tiles 8..11
     long long* const trbuf = reinterpret_cast<long long*>(a.f32.aux);
-#define HOS_STAMP(slot) do { if (bid == 0 && lane == 0 && trbuf && kt >= kt_begin + 8 && kt < kt_begin + 12) trbuf[(wave * 4 + (kt - kt_begin - 8)) * 8 + (slot)] = clock64(); } while (0)
+#define HOS_STAMP(slot) do { if (blockIdx.x == 0 && first_tile && lane == 0 && trbuf && kt >= kt_begin + 8 && kt < kt_begin + 12) trbuf[(wave * 4 + (kt - kt_begin - 8)) * 8 + (slot)] = clock64(); } while (0)
 #else
 #define HOS_STAMP(slot) do {} while (0)
 #endif
-    // One quarter = NM MFMAs (3 products x TM x TH tiles) with the LDS reads of the NEXT quarter (and, in the last
-    // quarter, the DMA requests of tile kt+2) issued BETWEEN them: `fill(i)` runs right behind MFMA i.  A wave issues
+    // One quarter = NM MFMAs (3 products x TM x TH tiles) with the LDS reads of the NEXT quarter (and the DMA requests of a
+    // later tile) issued BETWEEN them: `fill(i)` runs right behind MFMA i.  A wave issues
     // in order, so anything placed in front of an MFMA group delays it; placed between MFMAs it costs nothing
     // while the matrix pipe is busy.  Eight back-to-back global_load_lds stalled a wave for 600-1900 cycles
     // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once).
@@ -408,7 +389,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         _Pragma("unroll") for (int x = 0; x < TM; ++x) { tie(AH[x]); tie(AL[x]); }                        \
         _Pragma("unroll") for (int y = 0; y < TH; ++y) { tie(BH[y]); tie(BL[y]); }                        \
         if (YH == 0) db_acc(AH, AL);                                                                      \
-        if (!HOS_NO_SETPRIO) __builtin_amdgcn_s_setprio(1);                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                    \
         _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
             const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;                           \
             if (!HOS_ABLATE_MFMA) {                                                                       \
@@ -420,35 +401,76 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             FILL(i);                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                            \
         }                                                                                                 \
-        if (!HOS_NO_SETPRIO) __builtin_amdgcn_s_setprio(0);                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                    \
     } while (0)
 
-#ifdef HOS_STATIC_PRIO   // experiment (MI355X_MICROARCH.md "Static priority for the younger half"): waves 4-7 at priority 1 for the whole K loop
-    if (wave >= 4) __builtin_amdgcn_s_setprio(HOS_STATIC_PRIO);
-#endif
-    unsigned so = 0;                     // byte offset of the stage holding tile kt
+    unsigned so = 0;                     // byte offset of the stage holding the K tile being multiplied
+    bool first_tile = true;
     HOS_BSTAMP(1);
+  for (;;) {                             // ---- output tiles of this workgroup (one unless PERSIST) ----
+    // the tile behind this one: its first K tiles are requested by the last two iterations of this tile's loop
+    const int vnext = vb + (int)gridDim.x;
+    const bool has_next = PERSIST && vnext < nb;
+    int n_row0 = 0;
+    if (has_next) { decode(vnext); n_row0 = isB ? tn_i * BN : tm_i * PBM; }
+#pragma unroll
+    for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+    // What the plane epilogues read from global memory -- the bias of this lane's columns (FWD), this lane's dword of every
+    // block's ReLU bit mask (DGRAD) -- is requested HERE, as asm loads the compiler does not track: they land under the K loop
+    // (every iteration ends in an explicit vmcnt(0)) and the epilogue issues no load at all.  A compiler-visible load or LDS
+    // access anywhere in this loop nest makes hipcc put s_waitcnt vmcnt(0) at the top of every K iteration (it cannot see the
+    // asm waits and assumes the LDS-DMA writes may alias), which drains the DMA queue once per K tile.
+    float bias_r[TN];
+    uint32_t bw[TM][TN / 2];
+    bw_ok_mask = 0xffffffffu;
+    if constexpr (EPI == PEPI_PLANES_FWD) {
+        const float* const bp = a.bias != nullptr ? a.bias : reinterpret_cast<const float*>(a.B);
+        const int nmax = a.bias != nullptr ? a.N - 1 : 0;
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+            const int col = j0 + wn * (TN * 32) + y * 32 + l31;
+            const float* const q = bp + (col < nmax ? col : nmax);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(bias_r[y]) : "v"(q));
+        }
+    }
+    if constexpr (EPI == PEPI_PLANES_DGRAD) {
+        const uint32_t* const bp = a.bits != nullptr ? a.bits : reinterpret_cast<const uint32_t*>(a.B);
+#pragma unroll
+        for (int x = 0; x < TM; ++x)
+#pragma unroll
+            for (int yp = 0; yp < TN / 2; ++yp) {
+                const int rb = (i0 + wm * (TM * 32) + x * 32) >> 5, cbk = (j0 + wn * (TN * 32) + yp * 64) >> 6;
+                const bool ok = a.bits != nullptr && rb * 32 < a.M && cbk < a.bits_nb;
+                const uint32_t* const q = bp + (ok ? ((size_t)rb * a.bits_nb + cbk) * 64 + lane : (size_t)0);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(bw[x][yp]) : "v"(q));
+                if (!ok) bw_ok_mask &= ~(1u << (x * (TN / 2) + yp));
+            }
+    }
+    HOS_TSTAMP(0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const unsigned sn = STAGE - so;
-        const bool more2 = kt + 2 < kt_end, more1 = kt + 1 < kt_end;
+        const bool more1 = kt + 1 < kt_end;
         const int dstage = so ? 1 : 0;
+        // K tile v+1 / v+2 of this workgroup's stream: inside this output tile, or the first / second of the next one
+        const bool w1 = kt + 1 >= kt_end, w2 = kt + 2 >= kt_end;
+        const bool dma1 = !w1 || has_next, dma2 = !w2 || has_next;
+        const int kt1 = w1 ? kt + 1 - kt_end : kt + 1, row1 = w1 ? n_row0 : g_row0;
+        const int kt2 = w2 ? kt + 2 - kt_end : kt + 2, row2 = w2 ? n_row0 : g_row0;
+        const bool b_issue = !HOS_ABLATE_DMA && isB && dma1 && !(first_tile && kt == kt_begin);     // (the prologue requested tile 1)
+        const bool a_issue = !HOS_ABLATE_DMA && !isB && dma2;
         HOS_STAMP(0);
-        // experiment HOS_DMA_STAGGER = g: the B waves (weights: L2 hits, short latency) request tile kt+1 in group g of
-        // this iteration instead of in the last group of the previous one, so the two waves of a SIMD (one A wave, one
-        // B wave) never stall on DMA issue together
-        auto stag_dma = [&](int i) {
-            constexpr int D0 = NM / 3, ND = NM - D0;
-            if (!HOS_ABLATE_DMA && isB && more1 && kt > kt_begin && i >= D0) {
-#pragma unroll
-                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 1, dstage ^ 1);
-            }
-        };
-        auto fill1 = [&](int i) {                // under (A0,B0): B1 = (s0, yh1)
+        auto fill1 = [&](int i) {                // under (A0,B0): B1 = (s0, yh1); B waves: the DMA of tile v+1
             if (i == 1) HOS_READ_B1(b1h, b1l, so, 0, 1, 0);
             if (i == 3) HOS_READ_B1(b1h, b1l, so, 0, 1, 1);
-#if HOS_DMA_STAGGER == 1
-            stag_dma(i);
-#endif
+            constexpr int D0 = NM / 3, ND = NM - D0;          // DMA slots: the last two thirds of the group
+            if (b_issue && i >= D0) {
+#pragma unroll
+                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt1, dstage ^ 1, row1);
+            }
         };
         HOS_GROUP(a0h, a0l, b0h, b0l, 0, fill1);
         HOS_STAMP(1);
@@ -457,9 +479,6 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             if (i == 1) HOS_READ_A1(a1h, a1l, so, 1, 1);
             if (i == 2) HOS_READ_B1(b0h, b0l, so, 1, 0, 0);
             if (i == 3) HOS_READ_B1(b0h, b0l, so, 1, 0, 1);
-#if HOS_DMA_STAGGER == 2
-            stag_dma(i);
-#endif
         };
         HOS_GROUP(a0h, a0l, b1h, b1l, 1, fill2);
         HOS_STAMP(2);
@@ -469,47 +488,34 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         };
         HOS_GROUP(a1h, a1l, b0h, b0l, 0, fill3);
         HOS_STAMP(3);
-        // this wave's share of tile kt+1 has landed and its reads of this stage are complete; after the barrier
+        // this wave's share of tile v+1 has landed and its reads of this stage are complete; after the barrier
         // that holds for every wave, so the stage may be refilled and the other one read
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         HOS_STAMP(4);
         asm volatile("s_barrier" ::: "memory");
         HOS_STAMP(5);
-        auto fill4 = [&](int i) {                // under (A1,B1): A0, B0 of tile kt+1, then the DMA of tile kt+2
+        auto fill4 = [&](int i) {                // under (A1,B1): A0, B0 of tile kt+1, A waves: the DMA of tile v+2
             if (more1) {
                 if (i == 0) HOS_READ_A1(a0h, a0l, sn, 0, 0);
                 if (i == 1) HOS_READ_A1(a0h, a0l, sn, 0, 1);
                 if (i == 2) HOS_READ_B1(b0h, b0l, sn, 0, 0, 0);
                 if (i == 3) HOS_READ_B1(b0h, b0l, sn, 0, 0, 1);
             }
-            constexpr int D0 = NM / 3, ND = NM - D0;          // DMA slots: the last two thirds of the group
-#if HOS_DMA_STAGGER
-            if (!HOS_ABLATE_DMA && more2 && !isB && i >= D0) {
-#else
-            if (!HOS_ABLATE_DMA && more2 && i >= D0) {
-#endif
+            constexpr int D0 = NM / 3, ND = NM - D0;
+            if (a_issue && i >= D0) {
 #pragma unroll
-                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt + 2, dstage);
+                for (int q = (i - D0) * QMAX / ND; q < (i - D0 + 1) * QMAX / ND; ++q) if (q < nq) issue_dma(q, kt2, dstage, row2);
             }
         };
         HOS_GROUP(a1h, a1l, b1h, b1l, 1, fill4);
         HOS_STAMP(7);
         so = sn;
     }
-#ifdef HOS_STATIC_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     HOS_BSTAMP(2);
-#undef HOS_GROUP
-#undef HOS_STAMP
-#undef HOS_MMA
-#undef HOS_WAIT
-#undef HOS_READ_A
-#undef HOS_READ_A1
-#undef HOS_READ_B
-#undef HOS_READ_B1
-#undef HOS_RD128
-#undef HOS_RDTR
+    HOS_TSTAMP(1);
+    // Here: every wave has passed the last iteration's barrier, so nobody reads the stage of the last K tile any more
+    // (`STAGE - so`).  PERSIST: the A waves' requests for the next tile's second K tile are in flight into the A half of that
+    // stage, the next tile's first K tile has landed in stage `so`; the B half of the free stage is the epilogue's staging memory.
 
     // ---------------------------------------------------------------------------------------- epilogues
     if constexpr (EPI == PEPI_F32 || EPI == PEPI_WGRAD) {
@@ -544,8 +550,8 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
             }
         }
     } else {
-        // Plane outputs.  Every wave owns 8 KB of the (now idle) stage memory.  Per (x, pair of y) = 32 rows x 64
-        // columns: each lane packs (hi, lo) of its values into one dword and writes it at [row][col] (ds_write_b32,
+        // Plane outputs.  Every wave owns a private piece of idle stage memory.  Per block of 32 rows x (32 YB) columns:
+        // each lane packs (hi, lo) of its values into one dword and writes it at [row][col] (ds_write_b32,
         // 32 consecutive dwords per half wave: conflict free); after the wave's own writes have landed every lane
         // reads 32 bytes = eight consecutive columns of one row, keeps their hi or their lo halves and stores 16 bytes.
         // ReLU mask of the backward pass: FWD can emit one BIT per output element in ACCUMULATOR layout (a.bits: per
@@ -553,28 +559,28 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         // column 32 yy + (lane&31)) of the block), and DGRAD, whose accumulators have the same layout, reads its own dword
         // back: 8 KB per tile instead of the 256 KB of the fp16 planes of the layer input (whose fetch at ~11 B/clk/CU
         // cost ~16 us at the end of every tile: 110 us of an 817 us launch at M = 131072).
-        uint32_t bw[TM][TN / 2];                                  // DGRAD: this lane's dword of each block's bit mask
-        if constexpr (EPI == PEPI_PLANES_DGRAD) {
-            if (a.bits != nullptr) {
+        constexpr int YB = PERSIST ? 1 : 2;                       // 32-column blocks per staging round (4 / 8 KB per wave)
+        if constexpr (!PERSIST) asm volatile("s_barrier" ::: "memory");       // all waves are done with the stage memory
+        // the loads issued at the top of the tile have landed (the K loop waited vmcnt(0)); make that visible to the compiler
+        if constexpr (EPI == PEPI_PLANES_FWD) {
 #pragma unroll
-                for (int x = 0; x < TM; ++x)
-#pragma unroll
-                    for (int yp = 0; yp < TN / 2; ++yp) {
-                        const int rb = (i0 + wm * (TM * 32) + x * 32) >> 5, cbk = (j0 + wn * (TN * 32) + yp * 64) >> 6;
-                        bw[x][yp] = (rb * 32 < a.M && cbk < a.bits_nb) ? a.bits[((size_t)rb * a.bits_nb + cbk) * 64 + lane] : 0u;
-                    }
-            }
+            for (int y = 0; y < TN; ++y) asm volatile("" : "+v"(bias_r[y]));
         }
-        asm volatile("s_barrier" ::: "memory");                   // all waves are done with the stage memory
-#ifdef HOS_EXP_NO_EPI
-        { float sacc = 0.f;
-          for (int x = 0; x < TM; ++x) for (int y = 0; y < TN; ++y) for (int r = 0; r < 16; ++r) sacc += acc[x][y][r];
-          if (sacc == 1.2345f) a.Y[0] = 1;
-          return; }
-#endif
-        char* const stg = smemp + wave * 8192;
+        if constexpr (EPI == PEPI_PLANES_DGRAD) {
+#pragma unroll
+            for (int x = 0; x < TM; ++x)
+#pragma unroll
+                for (int yp = 0; yp < TN / 2; ++yp) asm volatile("" : "+v"(bw[x][yp]));
+        }
+        // staging memory as raw LDS addresses; every access below is an asm statement (see the note at the top of the tile)
+        const unsigned stg = lds_base + (PERSIST ? (STAGE - so) + A_TILE + wave * 4096 : wave * 8192);
+        const unsigned stg_w = stg + (4 * lhi * (32 * YB) + l31) * 4;                    // + row / block immediates
+        const unsigned stg_r = YB == 2 ? stg + (lane >> 4) * 256 + ((lane >> 3) & 1) * 128 + (lane & 3) * 32
+                                       : stg + (lane >> 3) * 128 + (lane & 3) * 32;       // + pass * 1024
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const bool dual = (EPI == PEPI_PLANES_FWD) && a.Yb != nullptr;
         const bool first = a.Y != nullptr;
+        const bool legacy_mask = (EPI == PEPI_PLANES_DGRAD) && a.bits == nullptr && a.mask != nullptr;     // never on a persistent launch
         float vmax = 0.f;          // largest hidden activation: beyond the exact fp16 hi/lo range (HOS_RANGE_LIMIT)?
 #pragma unroll
         for (int x = 0; x < TM; ++x)
@@ -584,12 +590,15 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 const int col0 = j0 + wn * (TN * 32) + yp * 64;
                 // activation (FWD) / ReLU mask (DGRAD) once, in place in the accumulators; both formats are split from that
                 uint32_t mybits = 0u;            // FWD: v > 0 of this lane's 32 values of the block, value (yy, r) at bit 31 - (16 yy + r)
-                const uint32_t keepbits = (EPI == PEPI_PLANES_DGRAD && a.bits != nullptr) ? bw[x][yp] : 0xffffffffu;
+                uint32_t keepbits = 0xffffffffu;
+                if constexpr (EPI == PEPI_PLANES_DGRAD) {
+                    if (a.bits != nullptr) keepbits = ((bw_ok_mask >> (x * (TN / 2) + yp)) & 1u) ? bw[x][yp] : 0u;
+                }
 #pragma unroll
                 for (int yy = 0; yy < 2; ++yy) {
                     const int col = col0 + yy * 32 + l31;
                     float bcol = 0.f;
-                    if (EPI == PEPI_PLANES_FWD && a.bias != nullptr && col < a.N) bcol = a.bias[col];
+                    if constexpr (EPI == PEPI_PLANES_FWD) bcol = a.bias != nullptr ? bias_r[2 * yp + yy] : 0.f;
                     const bool inb = col < a.N;                                        // zero the padding columns
                     // ReLU and the zeroing of padding columns as ONE clamp: [0, inf) / (-inf, inf) / [0, 0]
                     const float vlo = inb ? (a.relu ? 0.f : -__builtin_inff()) : 0.f, vhi = inb ? __builtin_inff() : 0.f;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                         if constexpr (EPI == PEPI_PLANES_FWD) {
                             v = __builtin_amdgcn_fmed3f(v + bcol, vlo, vhi);
                             mybits = __builtin_amdgcn_alignbit(mybits, __builtin_bit_cast(uint32_t, 0.f - v), 31);    // sign of -v: v > 0
-                            vmax = fmaxf(vmax, fabsf(v));
+                            if constexpr (__is_same(EIN, _Float16)) vmax = fmaxf(vmax, fabsf(v));
                         } else {
                             if (!inb) v = 0.f;
                             v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) & (uint32_t)__builtin_amdgcn_sbfe(keepbits, 31 - (yy * 16 + r), 1));
@@ -611,82 +620,140 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
                 for (int fmt = 0; fmt < 2; ++fmt) {
                     if (fmt == 0 && !first) continue;
                     if (fmt == 1 && !dual) continue;
-#pragma unroll
-                    for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = acc[x][2 * yp + yy][r];
-                            const int rl = (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                            const uint32_t p = (EPI == PEPI_PLANES_FWD && fmt == 0) ? split_pack_pk(v, (_Float16)0) : split_pack_pk(v, (__bf16)0);
-                            *reinterpret_cast<uint32_t*>(stg + (rl * 64 + yy * 32 + l31) * 4) = p;
-                        }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     uint16_t* const Po = fmt == 0 ? a.Y : a.Yb;
                     const int ldo = fmt == 0 ? a.ldy : a.ldyb;
-                    // 16-byte stores, whole lines per instruction: 8 lanes per (row, 32-column block) -- lanes 0-3 the hi
-                    // half of the line (8 columns each), lanes 4-7 the lo half; a wave instruction writes 8 complete
-                    // 128-byte lines.
 #pragma unroll
-                    for (int pass = 0; pass < 8; ++pass) {
-                        const int idx = pass * 64 + lane;
-                        const int rl = idx >> 4, cb = (idx >> 3) & 1, half = (idx >> 2) & 1, c8 = (idx & 3) * 8;
-                        const uint4 w0 = *reinterpret_cast<const uint4*>(stg + (rl * 64 + cb * 32 + c8) * 4);
-                        const uint4 w1 = *reinterpret_cast<const uint4*>(stg + (rl * 64 + cb * 32 + c8 + 4) * 4);
-                        const int row = row0 + rl, col = col0 + cb * 32;
-                        const uint32_t sel = half ? 0x07060302u : 0x05040100u;
-                        uint4 o4 = make_uint4(__builtin_amdgcn_perm(w0.y, w0.x, sel), __builtin_amdgcn_perm(w0.w, w0.z, sel),
-                                              __builtin_amdgcn_perm(w1.y, w1.x, sel), __builtin_amdgcn_perm(w1.w, w1.z, sel));
-                        if constexpr (EPI == PEPI_PLANES_DGRAD) {
-                            if (a.bits == nullptr && a.mask != nullptr && row < a.M && col < a.ldmask) {
-                                const uint4 mk = *reinterpret_cast<const uint4*>(a.mask + (size_t)row * (2 * a.ldmask) + (col >> 5) * 64 + c8);
-                                const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-                                uint32_t* ov = reinterpret_cast<uint32_t*>(&o4);
+                    for (int y0 = 0; y0 < 2; y0 += YB) {
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) {          // fp16 hi part of the layer input: x > 0 ?
-                                    const uint32_t lo16 = mw[k] & 0xffffu, hi16 = mw[k] >> 16;
-                                    uint32_t keep = 0u;
-                                    if (!(lo16 & 0x8000u) && lo16 != 0u) keep |= 0x0000ffffu;
-                                    if (!(hi16 & 0x8000u) && hi16 != 0u) keep |= 0xffff0000u;
-                                    ov[k] &= keep;
+                        for (int yy = y0; yy < y0 + YB; ++yy)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[x][2 * yp + yy][r];
+                                const uint32_t p = (EPI == PEPI_PLANES_FWD && fmt == 0) ? split_pack_pk(v, (EIN)0) : split_pack_pk(v, (__bf16)0);
+                                asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(stg_w), "v"(p),
+                                             "n"((((r & 3) + 8 * (r >> 2)) * (32 * YB) + (yy - y0) * 32) * 4) : "memory");
+                            }
+                        // 16-byte stores, whole lines per instruction: 8 lanes per (row, 32-column block) -- lanes 0-3 the hi
+                        // half of the line (8 columns each), lanes 4-7 the lo half; a wave instruction writes 8 complete
+                        // 128-byte lines.  Four passes (8 reads of 16 bytes) per wait.
+#pragma unroll
+                        for (int p0 = 0; p0 < 4 * YB; p0 += 4) {
+                            u32x4 w0[4], w1[4];
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the wave's own writes have landed)
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0[k]) : "v"(stg_r), "n"((p0 + k) * 1024) : "memory");
+                                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1[k]) : "v"(stg_r), "n"((p0 + k) * 1024 + 16) : "memory");
+                            }
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(w0[k]), "+v"(w1[k]));
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int idx = (p0 + k) * 64 + lane;
+                                const int rl = YB == 2 ? idx >> 4 : idx >> 3, cb = YB == 2 ? (idx >> 3) & 1 : 0, half = (idx >> 2) & 1, c8 = (idx & 3) * 8;
+                                const int row = row0 + rl, col = col0 + (y0 + cb) * 32;
+                                const uint32_t sel = half ? 0x07060302u : 0x05040100u;
+                                uint4 o4 = make_uint4(__builtin_amdgcn_perm(w0[k].y, w0[k].x, sel), __builtin_amdgcn_perm(w0[k].w, w0[k].z, sel),
+                                                      __builtin_amdgcn_perm(w1[k].y, w1[k].x, sel), __builtin_amdgcn_perm(w1[k].w, w1[k].z, sel));
+                                if constexpr (EPI == PEPI_PLANES_DGRAD && !PERSIST) {
+                                    if (legacy_mask && row < a.M && col < a.ldmask) {
+                                        const uint4 mk = *reinterpret_cast<const uint4*>(a.mask + (size_t)row * (2 * a.ldmask) + (col >> 5) * 64 + c8);
+                                        const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+                                        uint32_t* ov = reinterpret_cast<uint32_t*>(&o4);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) {          // 16-bit hi part of the layer input: x > 0 ?
+                                            const uint32_t lo16 = mw[e] & 0xffffu, hi16 = mw[e] >> 16;
+                                            uint32_t keep = 0u;
+                                            if (!(lo16 & 0x8000u) && lo16 != 0u) keep |= 0x0000ffffu;
+                                            if (!(hi16 & 0x8000u) && hi16 != 0u) keep |= 0xffff0000u;
+                                            ov[e] &= keep;
+                                        }
+                                    }
                                 }
+                                if (row < a.M && col < ldo)
+                                    *reinterpret_cast<uint4*>(Po + (size_t)row * (2 * ldo) + (col >> 5) * 64 + half * 32 + c8) = o4;
                             }
                         }
-#ifndef HOS_EXP_NO_EPI_STORE
-                        if (row < a.M && col < ldo)
-                            *reinterpret_cast<uint4*>(Po + (size_t)row * (2 * ldo) + (col >> 5) * 64 + half * 32 + c8) = o4;
-#else
-                        if (row < a.M && col < ldo && o4.x == 0x12345u) *reinterpret_cast<uint4*>(Po) = o4;
-#endif
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // staging reads done before it is rewritten
                 }
                 if (EPI == PEPI_PLANES_FWD && a.bits != nullptr && first && row0 < a.M && (col0 >> 6) < a.bits_nb)
                     a.bits[((size_t)(row0 >> 5) * a.bits_nb + (col0 >> 6)) * 64 + lane] = mybits;
             }
-        if (EPI == PEPI_PLANES_FWD && a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(vmax > HOS_RANGE_LIMIT) != 0 && lane == 0)
-            atomicOr(a.f32.range_flag, 1u);
+        if constexpr (EPI == PEPI_PLANES_FWD && __is_same(EIN, _Float16)) {
+            if (a.f32.range_flag != nullptr && __builtin_amdgcn_ballot_w64(vmax > HOS_RANGE_LIMIT) != 0 && lane == 0)
+                atomicOr(a.f32.range_flag, 1u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    HOS_TSTAMP(2);
+    if (!has_next) break;
+    // ---- next output tile: its first K tile is in stage `so`; the staging memory becomes a DMA target again ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    HOS_READ_A(a0h, a0l, so, 0);
+    HOS_READ_B(b0h, b0l, so, 0, 0);
+    vb = vnext;
+    i0 = tm_i * PBM; j0 = tn_i * BN;           // (decode(vnext) above left the next tile's coordinates in tm_i / tn_i)
+    g_row0 = n_row0;
+    first_tile = false;
+    HOS_TSTAMP(3);
+#ifdef HOS_TRACE2
+    ++tile_no;
+#endif
+  }
+#ifdef HOS_TRACE2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    HOS_WSTAMP(1);
+    HOS_ASTAMP(1);
 #ifdef HOS_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     HOS_BSTAMP(3);
 #undef HOS_BSTAMP
+#undef HOS_TSTAMP
+#undef HOS_WSTAMP
+#undef HOS_ASTAMP
+#undef HOS_GROUP
+#undef HOS_STAMP
+#undef HOS_READ_A
+#undef HOS_READ_A1
+#undef HOS_READ_B
+#undef HOS_READ_B1
+#undef HOS_RD128
+#undef HOS_RDTR
 }
 
-template <int BN, int EPI, typename EIN, bool TR>
-int launchp(PArgs& a, int splits, hipStream_t stream) {
+// number of compute units (persistent grids), queried once
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+template <int BN, int EPI, typename EIN, bool TR, bool PERSIST>
+int launchp_impl(PArgs& a, int grid, hipStream_t stream) {
     constexpr size_t smem = 2 * (PBM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmp_kernel<BN, EPI, EIN, TR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmp_kernel<BN, EPI, EIN, TR, PERSIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemmp_kernel<BN, EPI, EIN, TR, PERSIST>), dim3(grid), dim3(PNT), smem, stream, a);
+    return hos_launch_status();
+}
+
+template <int BN, int EPI, typename EIN, bool TR>
+int launchp(PArgs& a, int splits, hipStream_t stream) {
     a.tiles_m = hos_cdiv(a.M, PBM);
     a.tiles_n = hos_cdiv(a.N, BN);
-    static const int env_stagger = getenv("HOS_GEMMP_STAGGER") ? atoi(getenv("HOS_GEMMP_STAGGER")) : 0;
-    a.stagger = env_stagger;
     if (EPI == PEPI_WGRAD) {
         a.kt_per_split = hos_cdiv(a.nk, splits);          // splits chosen by wgrad_splits()
         splits = hos_cdiv(a.nk, a.kt_per_split);
@@ -694,8 +761,14 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
         splits = 1;
         a.kt_per_split = a.nk;
     }
-    hipLaunchKernelGGL((gemmp_kernel<BN, EPI, EIN, TR>), dim3(a.tiles_m * a.tiles_n * splits), dim3(PNT), smem, stream, a);
-    return hos_launch_status();
+    a.total = a.tiles_m * a.tiles_n * splits;
+    if constexpr (!TR && BN == 256 && HOS_GEMMP_PERSIST && (EPI == PEPI_PLANES_FWD || EPI == PEPI_PLANES_DGRAD)) {
+        static const int env_persist = getenv("HOS_GEMMP_PERSIST") ? atoi(getenv("HOS_GEMMP_PERSIST")) : 1;
+        const int cus = cu_count();
+        const bool legacy_mask = EPI == PEPI_PLANES_DGRAD && a.bits == nullptr && a.mask != nullptr;
+        if (env_persist && a.nk >= 2 && a.total > cus && !legacy_mask) return launchp_impl<BN, EPI, EIN, TR, true>(a, cus, stream);
+    }
+    return launchp_impl<BN, EPI, EIN, TR, false>(a, a.total, stream);
 }
 
 // element offset of (row r, column c) in an interleaved-planes array with `ld` logical columns: hi there, lo 32 further
@@ -889,10 +962,14 @@ extern "C" int hos_split_planes_t_batch(int n, const float* const* src, const in
     return hos_launch_status();
 }
 
-extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
-                               const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
-                               float* C, int ldc, int epilogue, float* aux, int aux_col, float p0,
-                               hos_stream_t stream) {
+namespace {
+// FWD on operands of element type E: fp16 planes (22 mantissa bits per value: the proposal MLPs, whose densities steer the
+// resampling and must reproduce the reference's sample indices) or bf16 planes (16 bits: the NeRF MLP, whose outputs are only
+// rendered -- 2.9e-5 RGB L-inf on the reference model, SURVEY 7.1 -- ONE activation format for forward, dgrad mask and wgrad).
+template <typename E>
+int linearp_fwd_impl(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                     const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
+                     float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream) {
     if (!A || !W || M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return HOS_E_ARG;
     if (K1 > 0 && !A1) return HOS_E_ARG;
     if ((K0 % PBK) || (K1 % PBK)) return HOS_E_SHAPE;
@@ -916,7 +993,7 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
     if (epilogue == HOS_EPI_RESIDUAL) { a.f32.mask = aux; a.f32.ldmask = aux_col; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool wide = N > 128;
-    if (planes_out) return wide ? launchp<256, PEPI_PLANES_FWD, _Float16, false>(a, 1, s) : launchp<128, PEPI_PLANES_FWD, _Float16, false>(a, 1, s);
+    if (planes_out) return wide ? launchp<256, PEPI_PLANES_FWD, E, false>(a, 1, s) : launchp<128, PEPI_PLANES_FWD, E, false>(a, 1, s);
     // N = 256 q + r with a short remainder (the NeRF head: 256 bottleneck columns + 1 density column): the last column tile
     // of a 256-wide launch would be a whole 256 x 256 tile for r columns -- as much MFMA work and A traffic again as the
     // first q.  The remainder goes to the 128-wide tile instead (fp32 epilogues only: their fields are all relative to the
@@ -932,10 +1009,27 @@ extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, i
         if (bias) { b.bias = bias + n0; b.f32.bias = bias + n0; }
         if (C) b.f32.C = C + n0;
         b.f32.aux_col = aux_col >= n0 ? aux_col - n0 : -1;
-        const int rc = launchp<256, PEPI_F32, _Float16, false>(a, 1, s);
-        return rc != 0 ? rc : launchp<128, PEPI_F32, _Float16, false>(b, 1, s);
+        const int rc = launchp<256, PEPI_F32, E, false>(a, 1, s);
+        return rc != 0 ? rc : launchp<128, PEPI_F32, E, false>(b, 1, s);
     }
-    return wide ? launchp<256, PEPI_F32, _Float16, false>(a, 1, s) : launchp<128, PEPI_F32, _Float16, false>(a, 1, s);
+    return wide ? launchp<256, PEPI_F32, E, false>(a, 1, s) : launchp<128, PEPI_F32, E, false>(a, 1, s);
+}
+}  // namespace
+
+extern "C" int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                               const float* bias, int M, int N, int relu, void* Y, int ldy, void* Yb, int ldyb, void* relu_bits,
+                               float* C, int ldc, int epilogue, float* aux, int aux_col, float p0,
+                               hos_stream_t stream) {
+    return linearp_fwd_impl<_Float16>(A, lda, K0, A1, lda1, K1, W, ldw, bias, M, N, relu, Y, ldy, Yb, ldyb, relu_bits, C, ldc, epilogue,
+                                      aux, aux_col, p0, stream);
+}
+
+// The same layer on bf16 planes throughout: A, A1, W and the ONE plane output Y (with its optional ReLU bit mask) are bf16 planes.
+extern "C" int hos_linearp_fwd_b(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                                 const float* bias, int M, int N, int relu, void* Y, int ldy, void* relu_bits,
+                                 float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream) {
+    return linearp_fwd_impl<__bf16>(A, lda, K0, A1, lda1, K1, W, ldw, bias, M, N, relu, Y, ldy, nullptr, 0, relu_bits, C, ldc, epilogue,
+                                    aux, aux_col, p0, stream);
 }
 
 extern "C" int hos_linearp_dgrad(const void* dZ, int lddz, const void* WT, int ldwt, int Npad, const void* mask, int ldmask,

@@ -1050,16 +1050,15 @@ __global__ __launch_bounds__(256) void chain_bwd_pack_kernel(const ChainBwdPackJ
 }
 
 struct ChainBwdCfg { int S; int code[CB_MAXS]; };
-constexpr int CB_NCFG = 6;
+constexpr int CB_NCFG = 4;
 // 0: {offset head 3 -> 128, layer 5}          1: {skip concat's hann columns, layer 4, layer 3}      2: {layers 2, 1, folded layer 0}
-// 3: {layers 2, 1, layer 0 on the unfolded [cond | hann] rows}    4, 5: the same MLP as TWO groups (experiment: register pressure)
+// 3: {layers 2, 1, layer 0 on the unfolded [cond | hann] rows}
+// (round 4 also instantiated the MLP as TWO groups of four steps: 803 vs 650 us per MLP backward, spills -- removed)
 constexpr ChainBwdCfg CB_CFG[CB_NCFG] = {
     {2, {cb_code(1, 4, 1, 0), cb_code(4, 4, 1, 1), 0, 0}},
     {3, {cb_code(4, 2, 0, 1), cb_code(4, 4, 1, 0), cb_code(4, 4, 1, 1), 0}},
     {3, {cb_code(4, 4, 1, 0), cb_code(4, 4, 1, 0), cb_code(4, 2, 0, 1), 0}},
     {3, {cb_code(4, 4, 1, 0), cb_code(4, 4, 1, 0), cb_code(4, 4, 0, 1), 0}},
-    {4, {cb_code(1, 4, 1, 0), cb_code(4, 4, 1, 0), cb_code(4, 2, 0, 1), cb_code(4, 4, 1, 1)}},
-    {4, {cb_code(4, 4, 1, 0), cb_code(4, 4, 1, 0), cb_code(4, 4, 1, 0), cb_code(4, 2, 0, 1)}},
 };
 
 template <int... CODE>
@@ -1205,9 +1204,7 @@ extern "C" int hos_mlp_chain_bwd(int cfg, const float* dZ, int lddz, int M, cons
         case 0: rc = launch_chain_bwd<CB_CFG[0].code[0], CB_CFG[0].code[1]>(a, grid, st); break;
         case 1: rc = launch_chain_bwd<CB_CFG[1].code[0], CB_CFG[1].code[1], CB_CFG[1].code[2]>(a, grid, st); break;
         case 2: rc = launch_chain_bwd<CB_CFG[2].code[0], CB_CFG[2].code[1], CB_CFG[2].code[2]>(a, grid, st); break;
-        case 3: rc = launch_chain_bwd<CB_CFG[3].code[0], CB_CFG[3].code[1], CB_CFG[3].code[2]>(a, grid, st); break;
-        case 4: rc = launch_chain_bwd<CB_CFG[4].code[0], CB_CFG[4].code[1], CB_CFG[4].code[2], CB_CFG[4].code[3]>(a, grid, st); break;
-        default: rc = launch_chain_bwd<CB_CFG[5].code[0], CB_CFG[5].code[1], CB_CFG[5].code[2], CB_CFG[5].code[3]>(a, grid, st); break;
+        default: rc = launch_chain_bwd<CB_CFG[3].code[0], CB_CFG[3].code[1], CB_CFG[3].code[2]>(a, grid, st); break;
     }
     if (rc != 0) return rc;
     for (int s = 0; s < C.S; ++s) {

@@ -101,9 +101,20 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
                                                          const float* __restrict__ partial, int n_partial, float max_norm,
                                                          const unsigned int* __restrict__ guard, unsigned int* __restrict__ skipped) {
     // fp16 range guard: a hidden activation of this step's forward left the exact hi/lo range (the forward epilogues OR the word):
-    // the step must not reach the parameters.  The word stays set until the host re-arms it (train.check_range), `skipped` counts.
-    if (guard != nullptr && *guard != 0u) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && skipped != nullptr) atomicAdd(skipped, 1u);
+    // THIS step must not reach the parameters -- and only this one (round 5; the word used to stay set until a host poll, so a loop
+    // that never polled lost every later step).  Every workgroup reads the word when it starts; the LAST one to finish (ticket
+    // counter skipped[1], self-resetting, so a replayed graph behaves the same) counts the skip in skipped[0] and clears the word:
+    // by then every workgroup has read it, and the next step's forward epilogues are behind this launch in stream order.
+    const bool skip = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (skip) {
+        if (threadIdx.x == 0 && skipped != nullptr) {
+            const unsigned ticket = atomicAdd(skipped + 1, 1u);
+            if (ticket == gridDim.x - 1) {
+                atomicAdd(skipped, 1u);
+                skipped[1] = 0u;
+                __hip_atomic_store(const_cast<unsigned int*>(guard), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
         return;
     }
     float gs = grad_scale;
@@ -202,7 +213,9 @@ extern "C" int hos_sumsq_partials(int n, const float* const* g, const long long*
 // groups are contiguous ranges here).  Span s: p/g/m/v[s][0 .. count[s]) with count % 4 == 0; its step scalars come from device
 // memory (hyper[s] = {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}, graph replay) or, where hyper[s] is NULL, from lr[s] and `step`.
 // partial (NULL: no clipping): hos_sumsq_partials' output, summed here; coefficient min(max_norm / (sqrt(sum) * |grad_scale| + 1e-6), 1).
-// guard (NULL: off): the range-guard word (hos_set_range_flag); non-zero -> NOTHING is updated and *skipped (NULL ok) is incremented.
+// guard (NULL: off): the range-guard word (hos_set_range_flag); non-zero -> NOTHING is updated by this launch, skipped[0] is
+// incremented and the word is cleared for the next step.  skipped: two zero-initialised words {count, ticket scratch} (NULL: the word
+// is left set, nothing is counted).
 extern "C" int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
                               const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
                               const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream) {

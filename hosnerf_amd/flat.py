@@ -69,6 +69,7 @@ class FlatStore:
         """Create an nn.Parameter that is the sub-view region[index].reshape(shape) of the flat buffer."""
         p = nn.Parameter(region.view(self.param)[index].view(shape))
         p.grad = region.view(self.grad)[index].view(shape)
+        p._hos_flat_grad = True          # nodes that accumulate into `.grad` in place (ops._DecoderHead) do so only for these
         self._bindings.append((p, region, index, shape))
         return p
 

@@ -566,30 +566,12 @@ class Network(FlatModule):
             Wm = [self._w(L)[0] for L in specs]
             G = [self._w(L, grad=True) for L in specs]
             im = ops.mlp_chain_bwd_images(id(specs), (0, 1, 2), dev)
-            ops.mlp_chain_bwd_pack([] if ops.MLP_CHAIN_BWD_GROUPS == 2 else [
+            ops.mlp_chain_bwd_pack([
                 (0, 0, Wm[6], 0, 3, 128, im[0][0]), (0, 1, Wm[5], 0, 128, 128, im[0][1]),
                 (1, 0, Wm[4], 128, 128, NR_LDPE, im[1][0]), (1, 1, Wm[4], 0, 128, 128, im[1][1]), (1, 2, Wm[3], 0, 128, 128, im[1][2]),
                 (2, 0, Wm[2], 0, 128, 128, im[2][0]), (2, 1, Wm[1], 0, 128, 128, im[2][1]), (2, 2, fold[0], 0, 128, NR_LDPE, im[2][2])])
             dPE = torch.empty(Pn, NR_LDPE, device=dev)
             dE = torch.empty(Pn, NR_LDPE, device=dev)
-            if ops.MLP_CHAIN_BWD_GROUPS == 2:    # experiment (HOS_CHAIN_BWD_GROUPS=2): two groups of four steps, one hand-over
-                im2 = ops.mlp_chain_bwd_images(id(specs), (4, 5), dev)
-                ops.mlp_chain_bwd_pack([
-                    (4, 0, Wm[6], 0, 3, 128, im2[0][0]), (4, 1, Wm[5], 0, 128, 128, im2[0][1]), (4, 2, Wm[4], 128, 128, NR_LDPE, im2[0][2]),
-                    (4, 3, Wm[4], 0, 128, 128, im2[0][3]), (5, 0, Wm[3], 0, 128, 128, im2[1][0]), (5, 1, Wm[2], 0, 128, 128, im2[1][1]),
-                    (5, 2, Wm[1], 0, 128, 128, im2[1][2]), (5, 3, fold[0], 0, 128, NR_LDPE, im2[1][3])])
-                dz3 = torch.empty(Pn, 128, device=dev)
-                with ops.deferred_bwd_reduce():
-                    ops.mlp_chain_bwd(4, dz6, [acts[5], acts[4], PE, acts[3]], im2[0], [None, None, dPE, dz3],
-                                      [G[6][0], G[5][0], G[4][0], G[4][0]], [0, 0, 128, 0], [G[6][1], G[5][1], None, G[4][1]],
-                                      [3, 128, 128, 128], [128, 128, NR_LDPE, 128], rows_dev=rows_dev)
-                    ops.mlp_chain_bwd(5, dz3, [acts[2], acts[1], acts[0], PE], im2[1], [None, None, None, dE],
-                                      [G[3][0], G[2][0], G[1][0], gw0h], [0, 0, 0, 0], [G[3][1], G[2][1], G[1][1], db0],
-                                      [128, 128, 128, 128], [128, 128, 128, NR_LDPE], rows_dev=rows_dev)
-                res = g_xyz.contiguous()
-                gW0, gb0 = self._w(specs[0], grad=True)
-                ops.mlp_chain_unfold_grad(gw0h, db0, fold[1], 6 * band_w.numel(), gW0, gb0)
-                return ops.embed_bwd_res(x, band_w, band_w.numel(), False, dE, 0, dPE, 0, res, rows_dev=rows_dev)
             dz4 = torch.empty(Pn, 128, device=dev)
             dz2 = torch.empty(Pn, 128, device=dev)
             with ops.deferred_bwd_reduce():      # the eight slab reductions as one launch at the end

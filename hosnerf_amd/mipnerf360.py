@@ -329,6 +329,16 @@ class MipNeRF360MLP(FlatModule):
     def _use_planes(self) -> bool:
         return ops.get_gemm_mode() == ops.GEMM_PLANES and self.netwidth >= self.PLANES_MIN_WIDTH
 
+    # Round 5: ONE activation format (bf16 planes) for an MLP whose outputs are only rendered.  The proposal MLPs keep fp16
+    # (hi, lo) forward planes: their densities steer the resampling, and 22-bit operands are what keeps `bin_idx` on the
+    # reference's values; the NeRF MLP's density and colour go straight into the composite, where bf16 pairs
+    # (2^-17 per product) cost ~3e-5 RGB L-inf.  Its layers then write their output once -- forward operand, ReLU
+    # mask and weight-gradient operand are the same planes -- and there is no fp16 range to guard.  HOS_NERF_BF16_FWD=0: fp16.
+    BF16_FWD = False
+
+    def _bf16_fwd(self) -> bool:
+        return self.BF16_FWD and os.environ.get("HOS_NERF_BF16_FWD", "1") != "0"
+
     def _weight_planes(self, need_t: bool):
         """fp16 hi/lo planes of every weight (one pass over this MLP's span of the flat buffer: the planes keep the
         flat layout, so a layer's planes are a view at its region offset) and, for the backward pass, transposed
@@ -338,7 +348,10 @@ class MipNeRF360MLP(FlatModule):
         lo = min(L.W.offset for L in specs)
         hi = max(L.W.offset + L.W.numel for L in specs)
         span = st.param[lo:hi].view(1, -1)
-        w16, _ = ops.split_planes2(span, ld=hi - lo, wantb=False)
+        if self._bf16_fwd():
+            _, w16 = ops.split_planes2(span, ld=hi - lo, want16=False)
+        else:
+            w16, _ = ops.split_planes2(span, ld=hi - lo, wantb=False)
         flat16 = w16.t.view(-1)
 
         def view16(L):
@@ -354,12 +367,15 @@ class MipNeRF360MLP(FlatModule):
         """X: (fp16 Planes, bf16 Planes | None) from hos_encode_ipe_planes, or an fp32 [P, X_LD] tensor (split here)."""
         W = self.netwidth
         W16, WT = self._weight_planes(need_t=save)
+        one_fmt = self._bf16_fwd()
         if isinstance(X, tuple):
             X16, Xb = X
-            if save and Xb is None:
-                raise ValueError("the backward pass needs the bf16 planes of the encoding")
+            if (save or one_fmt) and Xb is None:
+                raise ValueError("the backward pass / the bf16-only forward needs the bf16 planes of the encoding")
         else:
-            X16, Xb = ops.split_planes2(X, C=X_LD, ld=X_LD, wantb=save)
+            X16, Xb = ops.split_planes2(X, C=X_LD, ld=X_LD, want16=not one_fmt, wantb=save or one_fmt)
+        if one_fmt:
+            X16 = Xb            # the forward operand IS the bf16 planes
         P = X16.rows
         dev = X16.t.device
         h = X16
@@ -367,19 +383,21 @@ class MipNeRF360MLP(FlatModule):
         y16: List[ops.Planes] = []
         yb: List[ops.Planes] = []
         ping = [None, None]
+        fdt = torch.bfloat16 if one_fmt else torch.float16
         for i, L in enumerate(self._layers):
             if save:
-                out = ops.Planes.empty(P, W, torch.float16, dev, relu_bits=True)      # + 1 bit per element: the ReLU mask of the backward pass
-                outb = ops.Planes.empty(P, W, torch.bfloat16, dev)
+                out = ops.Planes.empty(P, W, fdt, dev, relu_bits=True)      # + 1 bit per element: the ReLU mask of the backward pass
+                outb = out if one_fmt else ops.Planes.empty(P, W, torch.bfloat16, dev)
             else:
                 if ping[i & 1] is None:
-                    ping[i & 1] = ops.Planes.empty(P, W, torch.float16, dev)
-                out, outb = ping[i & 1], None
+                    ping[i & 1] = ops.Planes.empty(P, W, fdt, dev)
+                out, outb = ping[i & 1], (ping[i & 1] if one_fmt else None)
             _, bt = self._w(L)
+            Yf, Ybf = (None, out) if one_fmt else (out, outb)
             if i in self._skip_consumers:
-                ops.linearp_fwd(h, W, W16[i], bt, P, W, True, out, outb, A1=X16, K1=X_LD)
+                ops.linearp_fwd(h, W, W16[i], bt, P, W, True, Yf, Ybf, A1=X16, K1=X_LD)
             else:
-                ops.linearp_fwd(h, kin, W16[i], bt, P, W, True, out, outb)
+                ops.linearp_fwd(h, kin, W16[i], bt, P, W, True, Yf, Ybf)
             if save:
                 y16.append(out)
                 yb.append(outb)
@@ -498,8 +516,9 @@ class MipNeRF360MLP(FlatModule):
         state = select_state(time, self.transitions_times)
         embed = self._embeds.view(self.store.param)[state]
         if self._use_planes():      # the encoder writes the 16-bit planes the trunk consumes (no fp32 copy of X)
+            one_fmt = self._bf16_fwd()
             X = ops.encode_ipe_planes(tdist, rays_o, rays_d, radii, self.pos_basis_t, embed, X_LD,
-                                      want_bf16=torch.is_grad_enabled())
+                                      want_bf16=torch.is_grad_enabled() or one_fmt, want_fp16=not one_fmt)
         else:
             X = ops.encode_ipe(tdist, rays_o, rays_d, radii, self.pos_basis_t, embed, X_LD)
         if torch.is_grad_enabled():
@@ -538,6 +557,7 @@ class _MLPFn(torch.autograd.Function):
 @_configurable()
 class NeRFMLP(MipNeRF360MLP):
     """M:354-362."""
+    BF16_FWD = True
 
     def __init__(self, basedir, netdepth: int = 8, netwidth: int = 1024):
         super().__init__(basedir, netdepth=netdepth, netwidth=netwidth)

@@ -400,8 +400,8 @@ def fold_grad_workspace(device) -> torch.Tensor:
 # ---- backward of the non-rigid MLP as three group launches, dZ on chip between the layers of a group (hos_mlpbwd.hip, chain_bwd_kernel)
 MLP_CHAIN_BWD = os.environ.get("HOS_CHAIN_BWD", "1") != "0"
 MLP_CHAIN_BWD_MIN_ROWS = int(os.environ.get("HOS_CHAIN_BWD_MIN_ROWS", "16384"))
-MLP_CHAIN_BWD_GROUPS = int(os.environ.get("HOS_CHAIN_BWD_GROUPS", "3"))      # 2: the MLP as two groups of four steps (measured slower: spills)
 _CB_IMAGES = {}
+_CB_IMAGES_MAX = 16        # (key, groups, device, stream) entries kept; oldest evicted first (buffers are repacked every backward)
 
 
 def _int_array(vals):
@@ -415,6 +415,8 @@ def mlp_chain_bwd_images(key, cfgs, device):
     k = (key, tuple(cfgs)) + _stream_key(device)
     bufs = _CB_IMAGES.get(k)
     if bufs is None:
+        while len(_CB_IMAGES) >= _CB_IMAGES_MAX:        # a process that rebuilds Network objects must not accumulate images
+            _CB_IMAGES.pop(next(iter(_CB_IMAGES)))
         bufs = _CB_IMAGES[k] = [[torch.empty(int(lib.hos_mlp_chain_bwd_image_bytes(c, s)) // 2, dtype=torch.int16, device=device)
                                  for s in range(int(lib.hos_mlp_chain_bwd_steps(c)))] for c in cfgs]
     return bufs
@@ -513,12 +515,14 @@ def range_events(device, reset: bool = True) -> int:
 
 
 _RANGE_SKIPS = {}
+_RANGE_SKIPS_SEEN = {}
 
 
 def range_guard_words(device):
-    """(guard word, skipped-steps counter) for hos_adam_multi, or (None, None) when the guard is off.  The word is the library's
-    range flag (registered here if it was not yet): the forward epilogues of a training step OR it, the optimiser launch of the
-    same step reads it.  Never allocates while a graph is being captured (a captured fill would clear the word on every replay)."""
+    """(guard word, {skipped-steps counter, ticket scratch}) for hos_adam_multi, or (None, None) when the guard is off.  The word is
+    the library's range flag (registered here if it was not yet): the forward epilogues of a training step OR it, the optimiser
+    launch of the same step reads it, skips the update if it is set, counts the skip and clears the word for the next step (the
+    kernel's last workgroup does; round 5).  Never allocates while a graph is being captured."""
     if not RANGE_GUARD:
         return None, None
     key = str(device)
@@ -526,13 +530,20 @@ def range_guard_words(device):
         if torch.cuda.is_current_stream_capturing():
             return None, None
         arm_range_flag(device)
-        _RANGE_SKIPS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        _RANGE_SKIPS[key] = torch.zeros(2, dtype=torch.int32, device=device)
     return _RANGE_FLAG[key], _RANGE_SKIPS[key]
 
 
-def range_skips(device) -> int:
-    t = _RANGE_SKIPS.get(str(device))
-    return 0 if t is None else int(t.item())
+def range_skips(device, since_last_poll: bool = False) -> int:
+    """Optimiser steps the device-side range guard has skipped (one 4-byte read: poll it rarely); since_last_poll: only the new ones."""
+    key = str(device)
+    t = _RANGE_SKIPS.get(key)
+    if t is None:
+        return 0
+    n = int(t[0].item())
+    if since_last_poll:
+        n, _RANGE_SKIPS_SEEN[key] = n - _RANGE_SKIPS_SEEN.get(key, 0), n
+    return n
 
 
 def guarded_forward(module, device, run):
@@ -682,6 +693,9 @@ def deconv3d_first(x: torch.Tensor, wc: torch.Tensor, gwc: torch.Tensor, bias: t
     return _Deconv3dFirst.apply(x, wc, gwc, bias, leaky)
 
 
+DECODER_HEAD_INPLACE = True      # the training step's loss.backward(); set False around torch.autograd.grad / gradcheck of this node
+
+
 class _DecoderHead(torch.autograd.Function):
     """h [1, N] = LeakyReLU(0.2)(W [N, K] . e [K] + b): `block_mlp` of the volume decoder on its constant embedding
     (network_util.py:21-30, deconv_vol_decoder.py:36-37) -- one row-dot launch (was F.linear -> a library GEMM, + leaky_relu);
@@ -700,8 +714,10 @@ class _DecoderHead(torch.autograd.Function):
         emb, weight, bias, y = ctx.saved_tensors
         N, K = weight.shape
         g = g.contiguous()
-        ok = lambda p_: p_.grad is not None and p_.grad.is_contiguous()
-        in_place = ok(emb) and ok(weight) and ok(bias)
+        # in place only when the flat store owns these gradients (FlatStore marks its aliased `.grad`s): torch.autograd.grad(...),
+        # gradient checks or a second backward over the graph then get (gx, gW, gb) back like from any other node
+        ok = lambda p_: p_.grad is not None and p_.grad.is_contiguous() and getattr(p_, "_hos_flat_grad", False)
+        in_place = ok(emb) and ok(weight) and ok(bias) and DECODER_HEAD_INPLACE
         if in_place:
             gW, gb, gx = weight.grad, bias.grad, emb.grad
         else:
@@ -827,11 +843,11 @@ def encode_ipe(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, out=N
     return X
 
 
-def encode_ipe_planes(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, want_bf16: bool = True):
-    """Same encoder, output directly as Planes (fp16, and bf16 if want_bf16) -- no fp32 copy of the encoding."""
+def encode_ipe_planes(tdist, rays_o, rays_d, radii, basis, embed, ldx: int = 576, want_bf16: bool = True, want_fp16: bool = True):
+    """Same encoder, output directly as Planes (fp16 if want_fp16, bf16 if want_bf16) -- no fp32 copy of the encoding."""
     B, S1 = tdist.shape
     S = S1 - 1
-    p16 = Planes.empty(B * S, ldx, torch.float16, tdist.device)
+    p16 = Planes.empty(B * S, ldx, torch.float16, tdist.device) if want_fp16 else None
     pb = Planes.empty(B * S, ldx, torch.bfloat16, tdist.device) if want_bf16 else None
     call("hos_encode_ipe_planes", ptr(tdist), ptr(rays_o), ptr(rays_d), ptr(radii.reshape(-1)), ptr(basis), ptr(embed),
          B, S, _pp(p16), _pp(pb), ldx)
@@ -1636,9 +1652,20 @@ def split_planes2(src: torch.Tensor, C: Optional[int] = None, ld: Optional[int] 
 def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool = True, Y: Optional[Planes] = None,
                 Yb: Optional[Planes] = None, A1: Optional[Planes] = None, K1: int = 0, C: Optional[torch.Tensor] = None,
                 epilogue: int = EPI_NONE, aux=None, aux_col: int = -1, p0: float = 0.0):
-    """Y (fp16 planes) / Yb (bf16 planes) = relu?([A | A1] @ W^T + bias), or the fp32 epilogues into C / aux."""
+    """Y (fp16 planes) / Yb (bf16 planes) = relu?([A | A1] @ W^T + bias), or the fp32 epilogues into C / aux.
+    bf16 operands (A.t.dtype == torch.bfloat16): the one-format layer hos_linearp_fwd_b -- the output is Yb (bf16 planes, with its
+    ReLU bits), Y must be None."""
     if epilogue == EPI_RESIDUAL:
         aux_col = aux.stride(0)
+    if A.t.dtype == torch.bfloat16:
+        if Y is not None or W.t.dtype != torch.bfloat16 or (A1 is not None and A1.t.dtype != torch.bfloat16):
+            raise _lib.HosLibraryError("linearp_fwd: bf16 operands take bf16 weights and write ONE output format (Yb)")
+        _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
+            "hos_linearp_fwd_b", _pp(A), A.ld, K0, _pp(A1), 0 if A1 is None else A1.ld, K1, _pp(W), W.ld, ptr(bias), M, N, int(relu),
+            _pp(Yb), 0 if Yb is None else Yb.ld,
+            ptr(Yb.bits, torch.int32) if (relu and Yb is not None and Yb.bits is not None) else 0,
+            ptr(C), 0 if C is None else C.stride(0), epilogue, ptr(aux), aux_col, float(p0)))
+        return
     _timed(f"gemmp_fwd[M={M},N={N},K={K0 + K1}]", 2.0 * M * N * (K0 + K1), lambda: call(
         "hos_linearp_fwd", _pp(A), A.ld, K0, _pp(A1), 0 if A1 is None else A1.ld, K1, _pp(W), W.ld, ptr(bias), M, N, int(relu),
         _pp(Y), 0 if Y is None else Y.ld, _pp(Yb), 0 if Yb is None else Yb.ld,
@@ -1647,11 +1674,12 @@ def linearp_fwd(A: Planes, K0: int, W: Planes, bias, M: int, N: int, relu: bool 
 
 
 def planes_rowdot(A: Planes, K: int, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, p0: float = 0.0, softplus: bool = True):
-    """out[M] = softplus?(A[:, :K] . w[:K] + bias[0] + p0): a one-column head as one pass over the fp16 planes A (w: fp32 row of the
-    weight, 16-byte aligned; bias: 1-element device tensor or None)."""
+    """out[M] = softplus?(A[:, :K] . w[:K] + bias[0] + p0): a one-column head as one pass over the planes A (fp16 or bf16; w: fp32 row
+    of the weight, 16-byte aligned; bias: 1-element device tensor or None)."""
     M = A.rows
+    fn = "hos_planes_rowdot_b" if A.t.dtype == torch.bfloat16 else "hos_planes_rowdot"
     _timed(f"planes_rowdot[M={M},K={K}]", 2.0 * M * K, lambda: call(
-        "hos_planes_rowdot", _pp(A), A.ld, K, ptr(w), ptr(bias), float(p0), int(softplus), M, ptr(out)))
+        fn, _pp(A), A.ld, K, ptr(w), ptr(bias), float(p0), int(softplus), M, ptr(out)))
     return out
 
 

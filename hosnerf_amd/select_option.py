@@ -64,6 +64,24 @@ class _LitFlat(_Base):
             optimizer.step(closure=closure)
             self.apply_lr(optimizer, step)
         self._step += 1                     # without a Trainer this module counts the optimiser steps itself
+        if self.RANGE_POLL_EVERY > 0 and self._step % self.RANGE_POLL_EVERY == 0:
+            self.poll_range_guard()
+
+    RANGE_POLL_EVERY = 200
+
+    def poll_range_guard(self) -> bool:
+        """Every RANGE_POLL_EVERY steps: did the optimiser kernel skip steps because a hidden activation left the fp16 hi/lo range?
+        If so the flat modules continue in exact fp32 MFMA (train.check_range) and the loop says so."""
+        mods = self._flat_modules()
+        dev = mods[0].flat_param.device
+        if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return False
+        from .train import check_range
+        if check_range(mods, dev):
+            import warnings
+            warnings.warn(f"{type(self).__name__}: optimizer steps were skipped by the fp16 range guard; continuing in exact fp32 MFMA")
+            return True
+        return False
 
     def apply_lr(self, optimizer, step: int):
         raise NotImplementedError

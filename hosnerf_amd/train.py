@@ -77,6 +77,7 @@ def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
         return 1
     world = dist.get_world_size(group)
     if world > 1:
+        _allreduce_range_guard(module.flat_grad.device, group)
         if ranges is None and getattr(module.store, "inactive", None):
             ranges = module.store.active_spans()      # never-written spans (all zeros) are not worth exchanging
         if ranges is None:
@@ -86,6 +87,18 @@ def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
                 if n > 0:
                     dist.all_reduce(module.flat_grad[off:off + n], group=group)
     return world
+
+
+def _allreduce_range_guard(device, group=None):
+    """Every rank must take the same skip / update decision in the optimiser launch, or the replicas part for good: the fp16
+    range-guard word is MAX-reduced over the group wherever the gradients are exchanged (4 bytes, idempotent; a rank whose rays
+    tripped the guard makes every rank skip this step).  Eager only -- like the gradient exchange it sits between the captured
+    halves of a multi-rank step."""
+    if device.type != "cuda" or not ops.RANGE_GUARD or torch.cuda.is_current_stream_capturing():
+        return
+    flag, _ = ops.range_guard_words(device)
+    if flag is not None:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
 
 
 class GradClip:
@@ -226,6 +239,8 @@ class FusedAdam:
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
         if clip_sumsq is False and _step_multi([self], [lr], dynamic):         # norm + Adam of this module as two launches
             return
+        if clip_sumsq is False and _guard_on_fallback_path(g.device, dynamic):
+            return
         sumsq = self.clip.sumsq([self]) if clip_sumsq is False else clip_sumsq      # after the exchange: the norm of the SUMMED gradient
         if dynamic:
             p = self.module.flat_param
@@ -294,14 +309,36 @@ def _step_multi(opts, lrs, dynamic: bool) -> bool:
                 o.step_count -= 1
             return False
     dev = spans[0][0].device
+    guard = ops.range_guard_words(dev)       # with several ranks the word was MAX-reduced next to the gradients (allreduce_flat_grad)
     ops.adam_multi(spans, opts[0].step_count if not dynamic else 0, opts[0].betas[0], opts[0].betas[1], opts[0].eps, 1.0 / world,
-                   partial, clip.max_norm, ops.range_guard_words(dev))
+                   partial, clip.max_norm, guard)
     return True
 
 
-def range_skips(device) -> int:
-    """Number of optimiser steps the device-side range guard has skipped so far (one 4-byte read: poll it rarely)."""
-    return ops.range_skips(device)
+_GUARDLESS_WARNED = False
+
+
+def _guard_on_fallback_path(device, dynamic: bool) -> bool:
+    """The per-span Adam launches (hos_adam_step / hos_adam_step_dyn: > 8 spans, unaligned ranges, separate clip objects,
+    HOS_MULTI_ADAM=0) take no guard word.  Outside a graph capture the host reads the flag itself (one 4-byte read per step of this
+    rarely taken path) and returns True when the step must be skipped; under capture that is impossible and the guard is off for
+    this optimiser -- said once, not silently."""
+    global _GUARDLESS_WARNED
+    if not ops.RANGE_GUARD or not torch.cuda.is_available() or device.type != "cuda":
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        if not _GUARDLESS_WARNED:
+            import warnings
+            warnings.warn("optimizer step captured on the per-span Adam path: the fp16 range guard does not cover it "
+                          "(poll train.check_range from the loop)")
+            _GUARDLESS_WARNED = True
+        return False
+    return bool(ops.range_events(device, reset=True))
+
+
+def range_skips(device, since_last_poll: bool = False) -> int:
+    """Number of optimiser steps the device-side range guard has skipped (one 4-byte read: poll it rarely)."""
+    return ops.range_skips(device, since_last_poll)
 
 
 def _no_pending_decoder_backward(module):
@@ -330,6 +367,8 @@ def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
             allreduce_flat_grad(o.module, o.group)
         o.grad_is_reduced = False
     if _step_multi(opts, lrs, dynamic):
+        return
+    if _guard_on_fallback_path(opts[0].module.flat_param.device, dynamic):
         return
     clip = opts[0].clip
     shared = all(o.clip is clip for o in opts)
@@ -512,6 +551,11 @@ def _lpips_term(lpips, rgb, batch, w_lpips: float):
     return w_lpips * lpips.loss(rgb, batch["target_patches"], batch["patch_ray_idx"], batch["bgcolor"])
 
 
+def _lpips_named(term, w_lpips: float):
+    """The unweighted LPIPS value for the loss report (w_lpips = 0 switches the term off: report 0, do not divide)."""
+    return term.detach() / w_lpips if w_lpips != 0 else term.detach() * 0.0
+
+
 def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], w_mse: float = 0.2,
                   w_flow: float = 0.01, w_cycle: float = 0.01, lpips=None, w_lpips: float = 1.0):
     """M:1690-1716 `get_loss`: 0.2*MSE + 0.01*flow + 0.01*cycle (configs/default.yaml lossweights) -- one HIP launch
@@ -535,9 +579,13 @@ def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
         n_cyc_dev=out.get("cycle_count"), w_mse=w_mse, w_flow=w_flow, w_cycle=w_cycle)
     named = _loss_parts(parts)
     if lpips is not None:
+        if "patch_ray_idx" not in batch and not bool(batch["patch_masks"].all()):
+            # the stage-3 reference unpacks with a plain reshape (M:1673: rgbs.reshape([b, w, h, 3])), i.e. it assumes whole
+            # patches; the masked gather below equals it only then (checked once per item, outside a captured step)
+            raise ValueError("stage-3 LPIPS: patch_masks with holes -- the reference's stage-3 _unpack_imgs is a plain reshape")
         term = _lpips_term(lpips, rgb, batch, w_lpips)
         total = total + term
-        named["lpips"] = term.detach() / w_lpips
+        named["lpips"] = _lpips_named(term, w_lpips)
     return total, named
 
 
@@ -557,19 +605,21 @@ def stage2_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
     if lpips is not None:
         term = _lpips_term(lpips, out["rgb"], batch, w_lpips)
         total = total + term
-        named["lpips"] = term.detach() / w_lpips
+        named["lpips"] = _lpips_named(term, w_lpips)
     return total, named
 
 
 def check_range(modules, device) -> bool:
-    """Training-loop side of the fp16 range guard (ops.guarded_forward is the no-grad side): poll the device flag -- one
-    4-byte read, so every few hundred steps, not every step -- and switch the given modules to exact fp32 MFMA if a hidden
-    activation left the exactly-representable fp16 hi/lo range since the last poll.  Returns True if it switched."""
+    """Training-loop side of the fp16 range guard (ops.guarded_forward is the no-grad side): one or two 4-byte reads, so every few
+    hundred steps, not every step.  True -- and the given modules switched to exact fp32 MFMA -- if a hidden activation left the
+    exactly-representable fp16 hi/lo range since the last poll: either the flag is still set (a forward whose optimiser step has
+    not run yet) or the optimiser kernel skipped steps meanwhile (it skips exactly the offending steps and re-arms the word itself,
+    so a loop that never polls loses those steps, not the rest of the run)."""
     ops.arm_range_flag(device)
-    if not ops.range_events(device):
+    pending = ops.range_events(device)
+    skipped = ops.range_skips(device, since_last_poll=True)
+    if not pending and skipped <= 0:
         return False
-    # the optimiser kernel has been skipping every step since the flag fired (hos_adam_multi's guard): nothing saturated reached
-    # the parameters; from here on the modules run in exact fp32 MFMA and the re-armed flag lets the updates through again
     for m in modules:
         m.gemm_mode = ops.GEMM_FP32
     return True

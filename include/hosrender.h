@@ -213,6 +213,17 @@ int hos_linearp_fwd(const void* A, int lda, int K0, const void* A1, int lda1, in
 int hos_planes_rowdot(const void* A, int lda, int K, const float* w, const float* bias, float p0, int softplus, int64_t M,
                       float* out, hos_stream_t stream);
 
+/* Round 5: the same two calls with ONE activation format, bf16 planes, for layer stacks whose outputs are only rendered (the NeRF MLP,
+ * mipnerf360/model.py:354-362: no resampling depends on its densities).  A, A1, W and the plane output Y are bf16 planes; Y's ReLU
+ * bit mask (relu_bits) and Y itself are what hos_linearp_dgrad / hos_linearp_wgrad read, so the layer writes its output once
+ * (hos_linearp_fwd writes fp16 planes for the next layer AND bf16 planes for the weight gradient).  Products as in the backward
+ * kernels: a_hi b_hi + a_hi b_lo + a_lo b_hi on bf16 pairs (2^-17 per product, fp32 accumulation); no fp16 range to guard. */
+int hos_linearp_fwd_b(const void* A, int lda, int K0, const void* A1, int lda1, int K1, const void* W, int ldw,
+                      const float* bias, int M, int N, int relu, void* Y, int ldy, void* relu_bits,
+                      float* C, int ldc, int epilogue, float* aux, int aux_col, float p0, hos_stream_t stream);
+int hos_planes_rowdot_b(const void* A, int lda, int K, const float* w, const float* bias, float p0, int softplus, int64_t M,
+                        float* out, hos_stream_t stream);
+
 /* Data gradient: dX[M,K] = dZ[M,Npad] @ WT[K,Npad]^T (bf16 planes; WT = transposed weight planes), masked by the
  * ReLU bit mask hos_linearp_fwd wrote next to the layer input (mask_bits != NULL, ldmask = that input's ld; see
  * relu_bits there) or by the fp16 planes of the layer input themselves (hi > 0, mask != NULL); bf16 planes [M][lddx]. */
@@ -643,7 +654,9 @@ int hos_head_grad_padded(const float* g_density, const float* density, const flo
  * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 8 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
  * from device memory hyper[s] (graph replay) or, if NULL, from lr[s] / step; clip coefficient min(max_norm / (sqrt(sum partial) *
  * |grad_scale| + 1e-6), 1) when partial != NULL; guard (the word of hos_set_range_flag, NULL: off): non-zero -> no parameter is
- * touched and *skipped is incremented -- a forward whose activations left the exact fp16 hi/lo range never reaches Adam. */
+ * touched by THIS launch, skipped[0] is incremented and the word is cleared again (by the launch's last workgroup; skipped[1] is its
+ * ticket scratch, both words zero-initialised by the caller) -- a forward whose activations left the exact fp16 hi/lo range never
+ * reaches Adam, and the steps behind it are not lost.  With several ranks, MAX-reduce the word before this call. */
 int hos_sumsq_blocks(void);
 int hos_sumsq_partials(int n, const float* const* g, const long long* count, float* partial, hos_stream_t stream);
 int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,

@@ -242,7 +242,7 @@ def test_group_backward_entry_points_validate_without_gpu():
     """hos_mlp_chain_bwd* (round 4): configuration tables and argument checks, no launch."""
     from hosnerf_amd import _lib
     lib = _lib.load()
-    assert [lib.hos_mlp_chain_bwd_steps(c) for c in range(6)] == [2, 3, 3, 3, 4, 4] and lib.hos_mlp_chain_bwd_steps(6) == -1
+    assert [lib.hos_mlp_chain_bwd_steps(c) for c in range(4)] == [2, 3, 3, 3] and lib.hos_mlp_chain_bwd_steps(4) == -1
     # LDS images: (hi, lo) planes of [N_][K_ + 16] bf16, rounded up to whole 8 KB copy rounds
     assert lib.hos_mlp_chain_bwd_image_bytes(0, 0) == 24576 and lib.hos_mlp_chain_bwd_image_bytes(0, 1) == 73728
     assert lib.hos_mlp_chain_bwd_image_bytes(1, 0) == 40960 and lib.hos_mlp_chain_bwd_image_bytes(2, 5) == 0

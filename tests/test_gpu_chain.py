@@ -187,9 +187,8 @@ def test_folded_chain_backward_equals_the_row_form(net, P, n_live):
         assert e_fold < max(3.0 * e_rows, 1e-4), (k, e_fold, e_rows)
 
 
-@pytest.mark.parametrize("groups", [3, 2])
 @pytest.mark.parametrize("P,n_live", [(16384 + 77, None), (65536, None), (40000, 17777), (20000, 63), (20000, 0)])
-def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
+def test_group_backward_equals_the_layer_launches(net, P, n_live):
     """hos_mlp_chain_bwd (three group launches, dZ in LDS between the layers of a group) against the eight hos_linear_bwd_fused
     launches it replaces: d loss / d x and every parameter gradient.  Same arithmetic (bf16 pairs, same product order), so the
     input gradient must agree to rounding of the fp32 sums and the parameter gradients to the slab reduction's order."""
@@ -201,9 +200,9 @@ def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
     if n_live is not None:
         g[n:] = 0
     res = {}
-    prev = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS, ops.MLP_CHAIN_BWD_GROUPS
+    prev = ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS
     try:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD_MIN_ROWS, ops.MLP_CHAIN_BWD_GROUPS = True, 1, True, 1, groups
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD_MIN_ROWS = True, 1, True, 1
         for cb in (True, False):
             ops.MLP_CHAIN_BWD = cb
             net.zero_grad()
@@ -213,7 +212,7 @@ def test_group_backward_equals_the_layer_launches(net, P, n_live, groups):
             torch.cuda.synchronize()
             res[cb] = (xx.grad[:n].clone(), {k: v.grad.detach().clone() for k, v in net.named_parameters() if k.startswith("non_rigid_mlp.")})
     finally:
-        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS, ops.MLP_CHAIN_BWD_GROUPS = prev
+        ops.MLP_CHAIN, ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_FOLD, ops.MLP_CHAIN_BWD, ops.MLP_CHAIN_BWD_MIN_ROWS = prev
         net.zero_grad()
     gx, gx_ref = res[True][0], res[False][0]
     assert torch.isfinite(gx).all()

@@ -272,9 +272,24 @@ def test_forward_vs_golden(dev, net, tag):
         assert maxerr(out["z_vals"], hf[p + "z_vals"]) < 1e-6
 
 
-def test_gradients_vs_oracle(dev, net):
+@pytest.fixture(params=[False, True], ids=["layer_bwd", "group_bwd"])
+def group_bwd(request):
+    """True: the chain forward + the three-launch group backward (hos_mlp_chain_bwd) also below their row thresholds, i.e. the
+    path every full-size training step takes, so that the fp64-anchored bounds below are asserted on it."""
+    from hosnerf_amd import ops
+    prev = ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS
+    if request.param:
+        ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS = 1, 1
+    yield request.param
+    ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS = prev
+
+
+def test_gradients_vs_oracle(dev, net, group_bwd):
     """Backward of the whole human branch (LBS warp incl. grid gradients, embedders, MLP chains, prologue through
     torch autograd) against the oracle's autograd on the same random cotangents."""
+    from hosnerf_amd import ops
+    if group_bwd:
+        assert ops.MLP_CHAIN and ops.MLP_CHAIN_FOLD and ops.MLP_CHAIN_BWD and ops.FUSED_THIN_BWD, "group backward is the default path"
     b = synth.human_batch(8, seed=21, time=0.5, is_train=True, iter_val=3e5)
     sd = {k: v.clone().requires_grad_(True) for k, v in synth.human_state_dict(777, 2).items()}
     out_o = oh.human_forward(sd, b, transitions_times=[0.4])
@@ -314,7 +329,7 @@ def test_gradients_vs_oracle(dev, net):
     from tests._record import record
     w = max(worst)
     floor = max(e_hip for e_hip, e_ref, _, _ in worst if e_ref < 1e-5)       # parameters the fp32 oracle gets essentially exactly
-    record("human.gradients_vs_fp64[8 rays]", {"worst_param": w[3], "hip_rel_err": w[0], "fp32_oracle_rel_err": w[1], "params": len(worst),
+    record("human.gradients_vs_fp64[8 rays]" + ("[group_bwd]" if group_bwd else ""), {"worst_param": w[3], "hip_rel_err": w[0], "fp32_oracle_rel_err": w[1], "params": len(worst),
                                                "hip_rel_err_where_fp32_oracle_is_exact": floor})
     # Two effects, both measured and recorded above.  (1) The gradient GEMMs form bf16 hi/lo products (2^-17 relative; the fp32
     # oracle rounds at 2^-24), so an ill-conditioned gradient may sit 2^7 x further from the fp64 value than the fp32 oracle's --
@@ -322,7 +337,7 @@ def test_gradients_vs_oracle(dev, net):
     # rows: ONE hidden unit whose pre-activation lies within rounding of zero flips its ReLU and moves the sum by ~1e-3 of
     # its norm (3.3e-3 observed on parameters the fp32 oracle happens to get to 2e-7): a discrete floor, not a precision.
     wf = max(((e_hip - 5e-3) / max(e_ref, 1e-12), n) for e_hip, e_ref, _, n in worst)
-    record("human.gradients_vs_fp64[8 rays].worst_factor", {"factor": wf[0], "param": wf[1]})
+    record("human.gradients_vs_fp64[8 rays].worst_factor" + ("[group_bwd]" if group_bwd else ""), {"factor": wf[0], "param": wf[1]})
     for e_hip, e_ref, cos, n in worst:
         assert cos > 0.999 and e_hip <= 16.0 * e_ref + 5e-3, (n, cos, e_hip, e_ref)        # measured worst factor: 2.5 (round 4)
     net.zero_grad()

@@ -189,7 +189,18 @@ def test_stage2_vs_torch_rocm():
         # fixed bounds only where the graph is well conditioned; the decoder / pose-decoder gradients carry the fp32 noise
         # of the skinning normalisation (tests/test_gpu_conditioning.py and tests/test_gpu_stage2.py measure them against
         # fp64) and are recorded
-        bound = 1e-3 if name.startswith("cnl_mlp") or name.startswith("human_stateembeds") else (2e-2 if "non_rigid" in name else 0.5)
+        # round 5: every bound is 3 x the value measured on the group-backward path at this size (profiles/r04 record: backward
+        # non-rigid MLP 7.5e-3 / 4.8e-3, forward non-rigid MLP 5.2e-5 / 5.5e-7, decoder 7.1e-4 / 6.5e-4, pose decoder 8.0e-3)
+        if name.startswith("cnl_mlp") or name.startswith("human_stateembeds"):
+            bound = 1e-3
+        elif name.startswith("non_rigid_forward_mlp"):
+            bound = 2e-4
+        elif name.startswith("non_rigid_mlp"):
+            bound = 2.3e-2
+        elif name.startswith("mweight_vol_decoder"):
+            bound = 2.2e-3
+        else:
+            bound = 3e-2          # pose_decoder
         assert rel < bound, (name, rel, errs)
     _record("stage2_fullsize_parity", {"rays": B, "worst_relative_gradient_error": worst, **errs})
     del ref, got, hip_grads, sd

@@ -88,7 +88,18 @@ def _stage2_item(B, seed, n_patches=2, size=32):
     return b
 
 
-def test_stage2_step_vs_oracle(dev, net2):
+@pytest.fixture(params=[False, True], ids=["layer_bwd", "group_bwd"])
+def group_bwd(request):
+    """True: chain forward + group backward of the non-rigid MLPs below their row thresholds (the full-size training path)."""
+    from hosnerf_amd import ops
+    prev = ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS
+    if request.param:
+        ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS = 1, 1
+    yield request.param
+    ops.MLP_CHAIN_MIN_ROWS, ops.MLP_CHAIN_BWD_MIN_ROWS = prev
+
+
+def test_stage2_step_vs_oracle(dev, net2, group_bwd):
     """One stage-2 training step at a size the oracle finishes in seconds (96 rays in two 8x8 patches, partial masks):
     loss terms against the fp32 oracle, and EVERY parameter gradient against the oracle evaluated in float64 -- the bound is
     the fp32 oracle's own distance from float64 (parts of this graph are ill-conditioned in fp32 by construction, see
@@ -145,7 +156,7 @@ def test_stage2_step_vs_oracle(dev, net2):
     assert seen >= 70
     from tests._record import record
     w = max(ratios)
-    record("stage2.decoder_gradients_vs_fp64", {"bound_factor": DECODER_GRAD_FACTOR, "worst_factor": w[0], "worst_param": w[1],
+    record("stage2.decoder_gradients_vs_fp64" + ("[group_bwd]" if group_bwd else ""), {"bound_factor": DECODER_GRAD_FACTOR, "worst_factor": w[0], "worst_param": w[1],
                                                 "fp32_oracle_rel_err": w[2], "hip_rel_err": w[3]})
     net2.zero_grad()
 

@@ -36,6 +36,10 @@ def _variant(kind):
         # weights scaled down so the rest of the network sees ordinary magnitudes again
         sd["mlps.2.pts_linear.1.bias"] = sd["mlps.2.pts_linear.1.bias"] + 9.0e4
         sd["mlps.2.pts_linear.2.weight"] = sd["mlps.2.pts_linear.2.weight"] * 1e-4
+    elif kind == "bigact_prop":
+        # the same in the first proposal MLP, whose forward planes are fp16 in every mode (its densities steer the resampling)
+        sd["mlps.0.pts_linear.1.bias"] = sd["mlps.0.pts_linear.1.bias"] + 9.0e4
+        sd["mlps.0.pts_linear.2.weight"] = sd["mlps.0.pts_linear.2.weight"] * 1e-4
     elif kind == "tinyact":
         sd["mlps.2.pts_linear.1.weight"] = sd["mlps.2.pts_linear.1.weight"] * 1e-5        # activations ~1e-6 (fp16 subnormals)
         sd["mlps.2.pts_linear.2.weight"] = sd["mlps.2.pts_linear.2.weight"] * 1e5
@@ -83,10 +87,15 @@ def test_weights_x3_hold_the_tolerance(mode):
 
 
 @pytest.mark.parametrize("mode", [ops.GEMM_PLANES, ops.GEMM_BF16X3])
-@pytest.mark.parametrize("kind", ["bigact", "scale30"])
+@pytest.mark.parametrize("kind", ["bigact", "bigact_prop", "scale30"])
 def test_out_of_range_activations_fall_back_to_exact_fp32(kind, mode):
     err, m, warned, dmax = _run(kind, mode)
-    assert m.gemm_mode == ops.GEMM_FP32 and any("exact fp32" in s for s in warned), (kind, warned)
+    if kind == "bigact" and mode == ops.GEMM_PLANES:
+        # round 5: the NeRF MLP's planes are bf16 pairs (8-bit exponent): 9e4 is inside their range, nothing to guard, and the
+        # rendering still holds the tolerance
+        assert m.gemm_mode is None and not warned, (kind, warned)
+    else:
+        assert m.gemm_mode == ops.GEMM_FP32 and any("exact fp32" in s for s in warned), (kind, warned)
     assert err < 1e-4, (kind, err, dmax)
     # the module stays in exact-fp32 mode: the next call does not need the guard
     dev = torch.device("cuda")
