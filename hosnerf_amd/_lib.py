@@ -33,6 +33,8 @@ PROTOTYPES = {
     "hos_set_range_flag": [_P],
     "hos_linear_fwd": [_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _F, _F, _P, _P],
     "hos_linear_fwd_splitk": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "hos_linear_fwd_splitk_ws_floats": [_I, _I, _I],
+    "hos_linear_fwd_splitk_det": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _L, _P],
     "hos_linear_dgrad": [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_linear_wgrad": [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
     "hos_thin_linear_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -148,7 +150,8 @@ _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "ho
              "hos_pose_refine_saved_floats": c_int64, "hos_compact_workspace_ints": c_int64,
              "hos_pose_refine_workspace_floats": c_int64, "hos_mlp_chain_weight_bytes": c_int64,
              "hos_mlp_chain_aux_floats": c_int64, "hos_gemv_ws_floats": c_int64,
-             "hos_mlp_chain_bwd_image_bytes": c_int64, "hos_mlp_chain_bwd_ws_floats": c_int64}
+             "hos_mlp_chain_bwd_image_bytes": c_int64, "hos_mlp_chain_bwd_ws_floats": c_int64,
+             "hos_linear_fwd_splitk_ws_floats": c_int64}
 
 _lib = None
 

@@ -33,7 +33,11 @@ template <typename E> __device__ __forceinline__ void split_store(unsigned short
     P[o + 32] = __builtin_bit_cast(unsigned short, l);
 }
 // two adjacent columns (c even) of one row: the (hi, hi) and (lo, lo) pairs as one 4-byte store each -- half the store
-// instructions of the per-column form (the stores were a quarter of this kernel's time)
+// instructions of the per-column form (the stores were a quarter of this kernel's time).
+// Round 5, measured and dropped (profiles/r05_ab_encoder_output_stage.txt): staging 16 samples' rows as fp32 in LDS and writing
+// whole 128-byte plane lines with 16-byte stores (the planes GEMM's epilogue pattern): 420 vs 348 us per 262 144 samples with both
+// formats, 277 vs 220 us with one -- the kernel is bound by its 756 sinf / expf evaluations per sample (one format: 2.7 TB/s of
+// stores, two formats: 3.5), not by store issue, and the staging's barriers + 48 KB of LDS per workgroup cost occupancy.
 template <typename E> __device__ __forceinline__ void split_store2(unsigned short* __restrict__ P, size_t o, float x0, float x1) {
     const E h0 = (E)hi_clamp<E>(x0), h1 = (E)hi_clamp<E>(x1);
     const E l0 = (E)(x0 - (float)h0), l1 = (E)(x1 - (float)h1);

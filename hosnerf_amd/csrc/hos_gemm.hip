@@ -196,9 +196,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const GemmArgs a) {
                 if (a.kt_per_split < a.nk) gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
                 else gemm_epilogue_tile<MODE_DGRAD>(a, acc[x][y], r0, c0, lane);
             } else {
-                // split-K FWD (hos_linear_fwd_splitk: small output, long reduction): partial tiles with atomics into a zeroed C
-                if (a.kt_per_split < a.nk) gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
-                else gemm_epilogue_tile<MODE>(a, acc[x][y], r0, c0, lane);
+                // split-K FWD (hos_linear_fwd_splitk*: small output, long reduction): partial tiles with atomics into a zeroed C,
+                // or -- deterministic form, a.aux = slab workspace [splits][M][aux_col] -- as plain stores into slab `split`,
+                // summed in a fixed order by splitk_reduce_kernel (round 5: LPIPS' deep convolutions; an atomic sum that lands
+                // a pre-activation on the other side of 0 flips a ReLU / pooling winner from run to run)
+                if (a.kt_per_split < a.nk) {
+                    if (a.aux != nullptr) {
+                        GemmArgs w = a;
+                        w.C = a.aux + (size_t)split * a.M * a.aux_col;
+                        w.ldc = a.aux_col; w.bias = nullptr; w.epi = HOS_EPI_NONE; w.mask = nullptr; w.aux = nullptr;
+                        gemm_epilogue_tile<MODE_FWD>(w, acc[x][y], r0, c0, lane);
+                    } else {
+                        gemm_epilogue_tile<MODE_WGRAD>(a, acc[x][y], r0, c0, lane);
+                    }
+                } else gemm_epilogue_tile<MODE>(a, acc[x][y], r0, c0, lane);
             }
         }
 
@@ -321,8 +332,54 @@ extern "C" int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1
 // C[M, N] = A[M, K] . W[N, K]^T in exact fp32 MFMA for a SMALL output with a LONG reduction (the input gradient of the volume
 // decoder's transposed convolutions: [M <= 4096, N <= 1024] from K = 1 728 .. 32 768, i.e. 8-64 output tiles): the reduction is
 // split over ~256 workgroups that add their partial tiles into the zeroed C with fp32 atomics.  No bias / epilogue.
-extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
-                                     hos_stream_t stream) {
+namespace {
+struct SplitKPlan { int tiles_m, tiles_n, splits, kt_per_split; bool few; };
+// 32-row tiles up to 64 rows and ~256 workgroups (round 3, scripts/bench_decoder.py: [64,512] from K = 16 384 39 -> 22 us,
+// [512,256] 71 -> 63 us, [4096,256] from K = 1 728 57 -> 54 us; 128 or 1024 workgroups are 25-50 % slower)
+inline SplitKPlan splitk_plan(int M, int N, int K) {
+    static const int few_max = getenv("HOS_SPLITK_FEW_M") ? atoi(getenv("HOS_SPLITK_FEW_M")) : 64;
+    static const int target = getenv("HOS_SPLITK_TARGET") ? atoi(getenv("HOS_SPLITK_TARGET")) : 256;
+    SplitKPlan p;
+    const int nk = K / BK;
+    p.few = M <= few_max;
+    p.tiles_m = hos_cdiv(M, p.few ? 32 : 128); p.tiles_n = hos_cdiv(N, 128);
+    int splits = hos_cdiv(target, p.tiles_m * p.tiles_n);
+    if (splits > nk / 4) splits = nk / 4 > 0 ? nk / 4 : 1;          // >= 4 K tiles per split
+    p.kt_per_split = hos_cdiv(nk, splits);
+    p.splits = hos_cdiv(nk, p.kt_per_split);
+    return p;
+}
+// C[m][n] = act( sum_s ws[s][m][n] + bias[n] ), slabs added in index order (bit-reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int N, int ld,
+                                                            const float* __restrict__ bias, int relu, float* __restrict__ C, int ldc) {
+    const int groups = ld >> 2;
+    const long total = (long)M * groups;
+    const size_t slab = (size_t)M * ld;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / groups), n = (int)(i % groups) * 4;
+        const float* p = ws + (size_t)m * ld + n;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = 0; j0 < splits; j0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (j0 + u < splits) ? *reinterpret_cast<const float4*>(p + (size_t)(j0 + u) * slab) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        const float vals[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (n + e < N) {
+                float v = vals[e] + (bias != nullptr ? bias[n + e] : 0.f);
+                if (relu) v = fmaxf(v, 0.f);
+                C[(size_t)m * ldc + n + e] = v;
+            }
+        }
+    }
+}
+int splitk_launch(const float* A, int lda, const float* W, int ldw, const float* bias, int relu, float* C, int ldc, int M, int N, int K,
+                  float* ws, long long ws_floats, bool want_det, hipStream_t s) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HOS_E_ARG;
     if (K % BK) return HOS_E_SHAPE;
     if ((lda & 3) || (ldw & 3) || !al16(A) || !al16(W)) return HOS_E_ALIGN;
@@ -330,22 +387,45 @@ extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, in
     a.A0 = A; a.lda0 = lda; a.kt0 = K / BK; a.B = W; a.ldb = ldw; a.C = C; a.ldc = ldc;
     a.M = M; a.N = N; a.Mload = M; a.Nload = N;
     a.nk = K / BK; a.red_limit = 0x7fffffff; a.epi = HOS_EPI_NONE;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // 32-row tiles up to 64 rows and ~256 workgroups (round 3, scripts/bench_decoder.py: [64,512] from K = 16 384 39 -> 22 us,
-    // [512,256] 71 -> 63 us, [4096,256] from K = 1 728 57 -> 54 us; 128 or 1024 workgroups are 25-50 % slower)
-    static const int few_max = getenv("HOS_SPLITK_FEW_M") ? atoi(getenv("HOS_SPLITK_FEW_M")) : 64;
-    static const int target = getenv("HOS_SPLITK_TARGET") ? atoi(getenv("HOS_SPLITK_TARGET")) : 256;
-    const bool few = M <= few_max;
-    a.tiles_m = hos_cdiv(M, few ? 32 : 128); a.tiles_n = hos_cdiv(N, 128);
-    int splits = hos_cdiv(target, a.tiles_m * a.tiles_n);
-    if (splits > a.nk / 4) splits = a.nk / 4 > 0 ? a.nk / 4 : 1;          // >= 4 K tiles per split
-    a.kt_per_split = hos_cdiv(a.nk, splits);
-    splits = hos_cdiv(a.nk, a.kt_per_split);
-    if (splits > 1) {
+    const SplitKPlan p = splitk_plan(M, N, K);
+    a.tiles_m = p.tiles_m; a.tiles_n = p.tiles_n; a.kt_per_split = p.kt_per_split;
+    const int ld = (N + 3) & ~3;
+    if (want_det) {
+        if (p.splits > 1) {
+            if (!ws || !al16(ws) || (long long)p.splits * M * ld > ws_floats) return HOS_E_ARG;
+            a.aux = ws; a.aux_col = ld;
+        } else {
+            a.bias = bias; a.epi = relu ? HOS_EPI_RELU : HOS_EPI_NONE;        // one split: the tile kernel's own epilogue
+        }
+    } else if (p.splits > 1) {
         const int rc = zero2d(C, ldc, M, N, s);
         if (rc != 0) return rc;
     }
-    return few ? launch<32, 128, MODE_FWD>(a, splits, s) : launch<128, 128, MODE_FWD>(a, splits, s);
+    const int rc = p.few ? launch<32, 128, MODE_FWD>(a, p.splits, s) : launch<128, 128, MODE_FWD>(a, p.splits, s);
+    if (rc != 0 || !want_det || p.splits <= 1) return rc;
+    const long total = (long)M * (ld >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, p.splits, M, N, ld, bias, relu, C, ldc);
+    return hos_launch_status();
+}
+}  // namespace
+
+extern "C" int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
+                                     hos_stream_t stream) {
+    return splitk_launch(A, lda, W, ldw, nullptr, 0, C, ldc, M, N, K, nullptr, 0, false, static_cast<hipStream_t>(stream));
+}
+
+// The same split, bit-reproducible: the partial tiles go to `ws` (>= hos_linear_fwd_splitk_ws_floats(M, N, K) floats, 16-byte aligned,
+// caller-owned scratch) with plain stores and a second launch adds them in slab order, then bias (may be NULL) and ReLU (relu != 0).
+extern "C" long long hos_linear_fwd_splitk_ws_floats(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK)) return 0;
+    const SplitKPlan p = splitk_plan(M, N, K);
+    return p.splits > 1 ? (long long)p.splits * M * ((N + 3) & ~3) : 0;
+}
+extern "C" int hos_linear_fwd_splitk_det(const float* A, int lda, const float* W, int ldw, const float* bias, int relu, float* C, int ldc,
+                                         int M, int N, int K, float* ws, long long ws_floats, hos_stream_t stream) {
+    return splitk_launch(A, lda, W, ldw, bias, relu, C, ldc, M, N, K, ws, ws_floats, true, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int hos_linear_dgrad(const float* dY, int lddy, const float* W, int ldw, int Npad,

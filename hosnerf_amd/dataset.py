@@ -146,6 +146,56 @@ class SceneItems:
         return item
 
 
+    # ------------------------------------------------------------------ full-frame evaluation items (stage 3)
+    def _frame_item(self, idx: int, K, E_smpl, E_colmap, newsmpl_to_scale_world, bg, with_targets: bool) -> Dict:
+        """The dict `eval.render_frame` consumes (keys of FreeviewDataset.__getitem__, freeview.py:284-335): full-image rays split by
+        the box test, the frame's pose, the per-subject constants; tensors on the device."""
+        name = self.frames[idx]
+        dev = self.device
+        img = self.images[idx].to(dev)
+        H, W = int(img.shape[0]), int(img.shape[1])
+        item = frame_rays(H, W, K, E_smpl, self.mesh_infos[name]["bbox"], E_colmap, device=dev)
+        if with_targets:
+            flat = img.reshape(-1, 3)
+            item["target_rgbs"], item["target_rgbs_bkg"] = flat[item["ray_mask"]], flat[item["ray_mask_bkg"]]
+        Rs, Ts, posevec = self._pose(name)
+        host = {"dst_Rs": Rs, "dst_Ts": Ts, "dst_posevec": posevec, "bgcolor": np.asarray(bg, dtype="float32"),
+                "newsmpl_to_scale_world": np.asarray(newsmpl_to_scale_world, dtype="float32"), **self._cnl}
+        item.update({k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in host.items()})
+        item["motion_weights_priors"] = self._prior
+        item.update(frame_name=name, time=float(self.times[idx]), is_train=False, iter_val=torch.full((1,), 1e7))
+        return item
+
+    def eval_frame(self, idx: int, bgcolor=(255.0, 255.0, 255.0)) -> Dict:
+        """Frame `idx` seen by its own camera, with the ground-truth pixels (`test_metrics`, model.py:884-1085)."""
+        if self.stage != 3:
+            raise ValueError("full-frame evaluation items are stage-3 items")
+        name = self.frames[idx]
+        cam = self.cameras[name]
+        K, E, newsmpl_to_smpl = self._camera(name)
+        A = np.asarray(cam["smpl_to_scale_world"], dtype=np.float64) @ newsmpl_to_smpl
+        return self._frame_item(idx, K, E, np.asarray(cam["scaleworld_to_camera"], dtype=np.float64), A, bgcolor, True)
+
+    def freeview_frame(self, idx: int, k: int, total_frames: int, inv_angle: bool = False, bgcolor=(255.0, 255.0, 255.0)) -> Dict:
+        """Camera k of the `total_frames`-camera turn about the subject of frame `idx` (FreeviewDataset.__getitem__,
+        freeview.py:199-337).  With T_smpl from `freeview.orbit_camera`:  the SMPL-space camera is E T_smpl, the same motion in
+        the scaled world is T_world = S T_smpl S^-1 (S = smpl_to_scale_world), so the background camera is
+        scaleworld_to_camera T_world and the body-frame -> scaled-world map becomes T_world^-1 S T_smpl [G | Th]."""
+        from .freeview import orbit_camera
+        if self.stage != 3:
+            raise ValueError("free-viewpoint items are stage-3 items")
+        name = self.frames[idx]
+        cam, m = self.cameras[name], self.mesh_infos[name]
+        K = np.array(cam["intrinsics"][:3, :3], dtype=np.float64)
+        K[:2] *= self.resize
+        E_k, T_smpl = orbit_camera(cam["smpl_to_camera"], k, total_frames, trans=m["Th"], inv_angle=inv_angle)
+        S = np.asarray(cam["smpl_to_scale_world"], dtype=np.float64)
+        T_world = S @ T_smpl @ np.linalg.inv(S)
+        E_colmap = np.asarray(cam["scaleworld_to_camera"], dtype=np.float64) @ T_world
+        S_k = np.linalg.inv(T_world) @ S @ T_smpl
+        E_new, newsmpl_to_smpl = smpl_frame_camera(E_k, m["Rh"], m["Th"])
+        return self._frame_item(idx, K, E_new, E_colmap, S_k @ newsmpl_to_smpl, bgcolor, True)
+
     def _item_stage2(self, idx: int, name: str, time: float, flow_on: bool, bg, img, H: int, W: int, K, E) -> Dict:
         """T2:460-658 with the per-pixel work on the device: composite, rays, box test, patch gather."""
         dev = self.device

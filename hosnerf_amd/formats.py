@@ -163,7 +163,7 @@ def load_scene(basedir: str, image_hw: Tuple[int, int], masks: Optional[np.ndarr
         with open(os.path.join(basedir, "cameras_scaleworld.pkl"), "wb") as f:
             pickle.dump(scaleworld, f)
     render_poses = pose_interp(extr, 2)
-    test_skip = n // 16
+    test_skip = max(1, n // 16)          # (short synthetic scenes: every frame; the reference needs >= 16 frames)
     i_test = np.arange(n)[::test_skip][:16]
     i_train = np.array([i for i in range(n) if i not in i_test])
     h, w, focal = poses[0, :3, -1]

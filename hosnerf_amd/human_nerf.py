@@ -60,6 +60,9 @@ def default_cfg(basedir: Optional[str] = None) -> Cfg:
                                  kick_in_iter=100000, full_band_iter=200000),
         non_rigid_forward_mlp=Cfg(condition_code_size=75, mlp_width=128, mlp_depth=6, skips=[4], multires=6, i_embed=0),
         pose_decoder=Cfg(embedding_size=75, mlp_width=256, mlp_depth=4, kick_in_iter=20000),
+        # data side (configs/default.yaml:121-146, adventure.yaml:41-42): read by the launcher's scene / evaluation modes
+        patch=Cfg(sample_subject_ratio=0.8, N_patches=2, size=32), freeview=Cfg(frame_idx=119), bbox_offset=0.6,
+        bgcolor=[255.0, 255.0, 255.0], resize_img_scale=1.0,
     )
 
 

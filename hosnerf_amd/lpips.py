@@ -16,7 +16,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import call, ptr
 
 VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]      # features[0:30] (P:105-114)
@@ -93,7 +93,6 @@ class LPIPS(nn.Module):
 
 
 def _lib_part(Np: int) -> int:
-    from . import _lib
     return _lib.load().hos_lpips_part_floats(Np)
 
 
@@ -119,9 +118,11 @@ def _vgg_forward(mod: LPIPS, x0: torch.Tensor, NI: int, P: int):
             M = NI * H * H
             if ((M + 127) // 128) * ((v + 127) // 128) < 64 and kpad >= 1152:
                 # few output tiles, long reduction (the 8 x 8 .. 2 x 2 feature maps): one tile kernel would walk 36-144 K tiles on
-                # 4-16 workgroups (205 us per layer); the reduction split over ~256 workgroups + a bias / ReLU pass
-                call("hos_linear_fwd_splitk", ptr(col), kpad, ptr(W), kpad, ptr(y), v, M, v, kpad)
-                call("hos_bias_relu", ptr(y), ptr(b), M, v)
+                # 4-16 workgroups (205 us per layer); the reduction is split over ~256 workgroups whose partial tiles are summed in a
+                # FIXED order (slabs; round 4 used atomics and the gradient changed from run to run) together with bias + ReLU
+                need = int(_lib.load().hos_linear_fwd_splitk_ws_floats(M, v, kpad))
+                ws = ops._bwd_workspace(dev, need=max(need, 4))
+                call("hos_linear_fwd_splitk_det", ptr(col), kpad, ptr(W), kpad, ptr(b), 1, ptr(y), v, M, v, kpad, ptr(ws), ws.numel())
             else:
                 ops.linear_fwd(col, kpad, W, b, v, y, ops.EPI_RELU)
             conv_in.append(h)

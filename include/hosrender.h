@@ -96,6 +96,13 @@ int hos_linear_fwd(const float* A0, int lda0, int K0, const float* A1, int lda1,
  * accumulate into the zeroed C with fp32 atomics (sums in a launch-dependent order).  Replaces a library GEMM call. */
 int hos_linear_fwd_splitk(const float* A, int lda, const float* W, int ldw, float* C, int ldc, int M, int N, int K,
                           hos_stream_t stream);
+/* Round 5: the same split with a FIXED summation order (bit-reproducible from call to call): partial tiles as plain stores into `ws`
+ * (>= hos_linear_fwd_splitk_ws_floats(M, N, K) floats, 16-byte aligned, caller-owned), summed in slab order by a second launch that
+ * also adds bias (may be NULL) and applies ReLU (relu != 0).  LPIPS' deep convolutions (third_parties/lpips/pretrained_networks.py:
+ * 105-131) use it: with atomics a pre-activation within rounding of 0 flipped a ReLU / pooling winner from run to run. */
+long long hos_linear_fwd_splitk_ws_floats(int M, int N, int K);
+int hos_linear_fwd_splitk_det(const float* A, int lda, const float* W, int ldw, const float* bias, int relu, float* C, int ldc,
+                              int M, int N, int K, float* ws, long long ws_floats, hos_stream_t stream);
 
 /* dX[M,K] = (dY[M,Npad] @ W[Npad,K]) (* (Xact[M,K] > 0) if Xact != NULL).
  * Npad (the reduction dim = padded layer width) multiple of 32; rows >= N of W must be zero.

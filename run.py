@@ -3,7 +3,10 @@
 3rd_Complete_HOSNeRF/run.py:75-292): `--ginc` / `--ginb` (gin files and bindings), `--scene_name`, `--seed`, `--logbase`,
 `--resume_training`, `--ckpt_path`, `--cfg`; `run.model_name` selects the stage (`state_mipnerf360 | state_humanobject |
 hosnerf`), `run.max_steps`, `run.grad_max_norm`, `run.bkgd_path` / `run.human_path` (stage-3 warm start, run.py:206-212),
-`run.run_train`.  The reference's .gin files parse unchanged (hosnerf_amd/gin_lite.py).
+`run.run_train`, `run.run_eval` (S3/run.py:224-231 -> `trainer.test`: the held-out frames rendered by their own cameras, PSNR,
+`test_metrics`, M:884-1085) and `run.run_render` (S3/run.py:233-239 -> `trainer.predict`: the free-viewpoint turn about the subject
+of `freeview.frame_idx`, `free_view`, M:1293-1494, cameras of core/utils/camera_util.py:106-131), both from `last.ckpt` (stage 3).
+The reference's .gin files parse unchanged (hosnerf_amd/gin_lite.py).
 
 What is NOT here: Lightning's Trainer (a plain loop drives `training_step` / `optimizer_step` / checkpoints the way the Trainer
 does; DDP = one process per GPU under torch.distributed.run, ray shards + one flat-gradient all-reduce per module), the
@@ -54,6 +57,12 @@ def parse_args(argv=None):
                    "enables the reference's LPIPS term (weight 1.0, configs/default.yaml:97-101) in stages 2 / 3")
     p.add_argument("--lpips_lin", type=str, default=None, help="the reference's third_parties/lpips/weights/v0.1/vgg.pth")
     p.add_argument("--rays", type=int, default=0, help="rays per step and GPU for synthetic items (default: the stage's reference batch)")
+    p.add_argument("--scene_dir", type=str, default=None, help="scene directory in the reference's on-disk formats (cameras.pkl / "
+                   "poses_bounds.npy, mesh_infos.pkl, canonical_joints.pkl, images/, masks/, images_flow/): training items, evaluation "
+                   "frames and free-viewpoint frames are built from it on the device (stages 2 / 3)")
+    p.add_argument("--eval_skip", type=int, default=0, help="run_eval: render every eval_skip-th frame of the scene (default: 8 frames spread over the sequence)")
+    p.add_argument("--render_frames", type=int, default=100, help="run_render: cameras per free-viewpoint turn (cfg.render_frames)")
+    p.add_argument("--render_limit", type=int, default=0, help="run_render: stop after this many cameras of the turn (0 = all)")
     return p.parse_args(argv)
 
 
@@ -204,6 +213,22 @@ def run(args, gin):
         lit.lpips = LPIPS.from_files(args.lpips_vgg16, args.lpips_lin, dev)          # M:582-584
         print(f"[run] LPIPS term enabled (weight 1.0): {args.lpips_vgg16}, {args.lpips_lin}")
     items = torch.load(args.items, weights_only=False) if args.items else None
+    scene = None
+    if args.scene_dir:
+        if model_name == "state_mipnerf360":
+            raise SystemExit("--scene_dir builds human-object items (stages 2 / 3); stage 1 takes --items or synthetic rays")
+        from hosnerf_amd import formats
+        from hosnerf_amd.dataset import SceneItems
+        from hosnerf_amd.freeview import load_scene_pixels
+        px = load_scene_pixels(args.scene_dir)
+        if not os.path.exists(os.path.join(args.scene_dir, "cameras_scaleworld.pkl")):     # what the stage-1 loader leaves behind
+            formats.load_scene(args.scene_dir, px["images"].shape[1:3], masks=px["alphas"], near=0.1, far=1e6)
+        scene = SceneItems(args.scene_dir, px["images"], px["alphas"], px["flows"], frames=px["frames"], device=dev, seed=args.seed + rank,
+                           stage=2 if model_name == "state_humanobject" else 3,
+                           n_patches=int(model_kw["cfg"].patch.N_patches), patch_size=int(model_kw["cfg"].patch.size),
+                           sample_subject_ratio=float(model_kw["cfg"].patch.sample_subject_ratio), bbox_offset=float(model_kw["cfg"].bbox_offset),
+                           resize_img_scale=float(model_kw["cfg"].resize_img_scale))
+        print(f"[run] scene {args.scene_dir}: {len(scene)} frames of {px['images'].shape[2]}x{px['images'].shape[1]}")
     run_train = bool(kw.get("run_train", True))
     log_every = int(kw.get("log_every_n_steps", 100))
     t0 = time.perf_counter()
@@ -219,7 +244,10 @@ def run(args, gin):
 
     if run_train:
         for step in range(step0, max_steps):
-            item = items[step % len(items)] if items else synthetic_item(model_name, rays, args.seed + 1000 * rank, step)
+            if scene is not None:
+                item = scene[int(torch.randint(len(scene), (1,)))] if len(scene) > 1 else scene[0]      # shuffled frames (DataLoader(shuffle=True))
+            else:
+                item = items[step % len(items)] if items else synthetic_item(model_name, rays, args.seed + 1000 * rank, step)
             if items and model_name != "state_mipnerf360" and "mse_count" not in item:
                 item = prepare_patch_targets(item)          # items straight from the reference's dataset: derive the patch-MSE constants
             batch = batch_to_device(item, dev) if model_name != "state_mipnerf360" else {k: v.to(dev) for k, v in item.items()}
@@ -236,10 +264,70 @@ def run(args, gin):
         if rank == 0 and bool(kw.get("save_last", True)):
             save_last(max_steps)
             print(f"[run] wrote {ckpt}")
+    result = {"exp_name": exp_name, "checkpoint": ckpt}
+    run_eval, run_render = bool(kw.get("run_eval", False)), bool(kw.get("run_render", False))
+    if run_eval or run_render:
+        result.update(evaluate_and_render(args, kw, lit, model_name, scene, ckpt, logdir, dev, rank, world, run_eval, run_render))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
-    return {"exp_name": exp_name, "checkpoint": ckpt}
+    return result
+
+
+def evaluate_and_render(args, kw, lit, model_name, scene, ckpt, logdir, dev, rank, world, run_eval: bool, run_render: bool):
+    """`trainer.test` / `trainer.predict` of the stage-3 launcher (S3/run.py:224-239) from `last.ckpt`: `test_metrics` over held-out
+    frames (PSNR against the frame's pixels, images under <logdir>/test_vis) and `free_view` over the orbit cameras of
+    `freeview.frame_idx` (images under <logdir>/freeview_vis_newtrans/view_<idx>), every frame through `eval.render_frame`; with
+    several ranks each frame's rays are split over the group.  Writes <logdir>/results.json."""
+    from hosnerf_amd import eval as ev, select_option
+    from hosnerf_amd.freeview import save_image
+    if model_name != "hosnerf":
+        raise SystemExit("run.run_eval / run.run_render: full-frame rendering is the stage-3 (`hosnerf`) launcher's; stages 1 / 2 report their training loss only")
+    if scene is None:
+        raise SystemExit("run.run_eval / run.run_render need --scene_dir (frames, cameras and SMPL fits to render)")
+    if not os.path.exists(ckpt):
+        raise SystemExit(f"run.run_eval / run.run_render: {ckpt} does not exist (train first, or pass --ckpt_path)")
+    select_option.load_checkpoint(lit, ckpt, strict=True)
+    hos = lit.net                                   # the composite renderer that owns `model` and `human`
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        group = dist.group.WORLD
+    chunk = int(lit.cfg.chunk_bkg)
+    bgc = tuple(float(c) for c in lit.cfg.bgcolor)
+    out = {}
+    if run_eval:
+        n = len(scene)
+        idxs = list(range(0, n, args.eval_skip)) if args.eval_skip > 0 else sorted({int(round(i * (n - 1) / 7.0)) for i in range(8)} if n > 1 else {0})
+        psnrs = {}
+        for i in idxs:
+            fr = scene.eval_frame(i, bgcolor=bgc)
+            rendered = ev.render_frame(hos, fr, chunk_bkg=chunk, randomized=False, group=group)
+            psnrs[fr["frame_name"]] = ev.psnr_metric(rendered, ev.truth_frame(fr))
+            if rank == 0:
+                save_image(os.path.join(logdir, "test_vis", fr["frame_name"] + ".png"), rendered, int(fr["img_height"]), int(fr["img_width"]))
+        out["test"] = {"psnr": float(sum(psnrs.values()) / len(psnrs)), "frames": psnrs}
+        if rank == 0:
+            print(f"[run] Test PSNR is {out['test']['psnr']:.4f} over {len(psnrs)} frames")
+    if run_render:
+        fidx = min(int(lit.cfg.freeview.frame_idx), len(scene) - 1)
+        total = int(args.render_frames)
+        count = min(total, args.render_limit) if args.render_limit > 0 else total
+        psnrs = []
+        for k in range(count):
+            fr = scene.freeview_frame(fidx, k, total, bgcolor=bgc)
+            rendered = ev.render_frame(hos, fr, chunk_bkg=chunk, randomized=False, group=group)
+            psnrs.append(ev.psnr_metric(rendered, ev.truth_frame(fr)))          # the reference reports it against the training frame too (M:1462)
+            if rank == 0:
+                save_image(os.path.join(logdir, "freeview_vis_newtrans", f"view_{fidx:05d}", f"image-{k:05d}.jpg"), rendered,
+                           int(fr["img_height"]), int(fr["img_width"]))
+        out["freeview"] = {"frame_idx": fidx, "frames": count, "of": total, "psnr_vs_training_frame": float(sum(psnrs) / len(psnrs))}
+        if rank == 0:
+            print(f"[run] Freeview: {count} of {total} cameras about frame {fidx} written to {os.path.join(logdir, 'freeview_vis_newtrans')}")
+    if rank == 0:
+        with open(os.path.join(logdir, "results.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    return {"results": out}
 
 
 def main(argv=None):

@@ -23,17 +23,13 @@ def net():
     return LPIPS().load_vgg16_features(vgg16_features_state(), DEV).load_lin(G["lin"], DEV)
 
 
-def _close_but_for_discrete_events(g, ref):
-    """Two fp32 evaluations of this network that sum in a different order (the deep convolutions split their reduction over ~256
-    workgroups and add with atomics) agree to rounding EXCEPT where a pre-activation within rounding of zero takes the other ReLU
-    branch or two equal values of a pooling window swap.  Such an event in a 4 x 4 or 2 x 2 feature map moves the gradient of
-    every pixel of that patch a little (observed: one event in fixture `b`, 13 % of the values off by more than 2e-5 of the
-    largest gradient, none by more than 8e-3 of it, relative L2 distance 2e-3); without an event every value is at 1e-6 of it."""
+def _close(g, ref, tol=1e-5):
+    """Round 5: the deep convolutions sum their split reduction in a FIXED order (hos_linear_fwd_splitk_det), so the gradient is a
+    deterministic function of the inputs and is held to 1e-5 of the largest gradient.  (Round 4 summed with atomics: a
+    pre-activation within rounding of zero flipped a ReLU / pooling winner from run to run and the test tolerated 5e-2.)"""
     err, scale = np.abs(g - ref), np.abs(ref).max()
     assert np.isfinite(g).all()
-    assert np.median(err) < 2e-5 * scale, (np.median(err), scale)
-    assert np.linalg.norm(g - ref) < 2e-2 * np.linalg.norm(ref), (np.linalg.norm(g - ref), np.linalg.norm(ref))
-    assert err.max() < 5e-2 * scale, (err.max(), scale)
+    assert err.max() < tol * scale, (err.max(), scale, float(np.mean(err > tol * scale)))
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -46,8 +42,23 @@ def test_value_and_gradient_vs_the_reference_class(net, tag):
     loss.backward()
     torch.cuda.synchronize()
     assert abs(float(loss) - float(G[f"{tag}_loss"])) < 2e-6 * max(1.0, abs(float(G[f"{tag}_loss"]))), (float(loss), float(G[f"{tag}_loss"]))
-    g, ref = rgb.grad.cpu().numpy().reshape(G[f"{tag}_grad"].shape), G[f"{tag}_grad"]
-    _close_but_for_discrete_events(g, ref)
+    g, ref, ref64 = rgb.grad.cpu().numpy().reshape(G[f"{tag}_grad"].shape), G[f"{tag}_grad"], G[f"{tag}_grad64"]
+    # against the reference class evaluated in float64 (the yardstick): always tight
+    _close(g, ref64.astype(np.float32))
+    # against its float32 evaluation: tight where that one is itself at rounding distance from the float64 value (`a`, `c`); in
+    # fixture `b` the reference's OWN float32 run takes the other branch of one ReLU than the exact value does (7.4e-3 of the
+    # largest gradient, 13.8 % of the values) -- there the HIP gradient must simply be no further from it than float64 is
+    ref_gap = np.abs(ref - ref64).max() / np.abs(ref).max()
+    if ref_gap < 1e-5:
+        _close(g, ref)
+    else:
+        assert tag == "b" and np.abs(g - ref).max() <= 1.01 * np.abs(ref64 - ref).max() + 1e-5 * np.abs(ref).max()
+    # bit-reproducible: a second evaluation gives the same gradient word for word
+    rgb2 = pred.reshape(-1, 3).to(DEV).requires_grad_(True)
+    loss2 = net.loss(rgb2, targ.to(DEV), idx, torch.zeros(3, device=DEV))
+    loss2.backward()
+    torch.cuda.synchronize()
+    assert float(loss2) == float(loss) and torch.equal(rgb2.grad, rgb.grad)
 
 
 def test_patches_cut_by_the_box_vs_oracle(net):
@@ -76,7 +87,7 @@ def test_patches_cut_by_the_box_vs_oracle(net):
     loss.backward()
     torch.cuda.synchronize()
     assert abs(float(loss) - float(lo)) < 2e-6 * max(1.0, abs(float(lo)))
-    _close_but_for_discrete_events(rg.grad.cpu().numpy(), r64.grad.numpy())
+    _close(rg.grad.cpu().numpy(), r64.grad.numpy())
 
 
 def test_unloaded_module_raises():

@@ -119,3 +119,84 @@ def test_scene_directory_to_stage2_items_and_steps(tmp_path):
         torch.cuda.synchronize()
         assert torch.isfinite(loss) and all(torch.isfinite(v) for v in parts.values())
     assert torch.isfinite(net.flat_param).all()
+
+
+def _line_offset(item, z):
+    """Relative distance of the body-frame ray point at depth z, carried into the scaled world, from the background ray of its pixel."""
+    o, d = item["rays"][0].double(), item["rays"][1].double()
+    A = item["newsmpl_to_scale_world"].double()
+    pw = (o + z * d) @ A[:3, :3].T + A[:3, 3]
+    rel = pw - item["rays_o_bkg"].double()
+    dirb = item["rays_d_bkg"].double()
+    t = (rel * dirb).sum(-1, keepdim=True) / (dirb * dirb).sum(-1, keepdim=True)
+    return float(((rel - t * dirb).norm(dim=-1) / rel.norm(dim=-1)).max())
+
+
+def test_freeview_and_eval_frames_are_consistent(tmp_path):
+    """`SceneItems.eval_frame` / `freeview_frame` (freeview.py:199-337): camera 0 of the turn IS the frame's own camera; for every
+    camera of the turn the human-branch rays and the background rays describe the same pixels (what the z-merge relies on), the box
+    stays in view, and the camera keeps its distance to the subject."""
+    from hosnerf_amd import formats, synth
+    from hosnerf_amd.dataset import SceneItems
+    dev = torch.device("cuda")
+    scene = str(tmp_path / "scene")
+    H = W = 64
+    px = synth.write_scene_dir(scene, 8, H, W, seed=4)
+    formats.load_scene(scene, (H, W), masks=px["alphas"], near=0.1, far=1e6)
+    ds = SceneItems(scene, px["images"], px["alphas"], px["flows"], n_patches=2, patch_size=16, device=dev, seed=5)
+    ev = ds.eval_frame(5)
+    f0 = ds.freeview_frame(5, 0, 40)
+    for k in ("rays", "near", "far", "rays_o_bkg", "rays_d_bkg", "radii", "ray_mask", "newsmpl_to_scale_world", "target_rgbs"):
+        assert torch.allclose(ev[k].float(), f0[k].float(), atol=1e-5), k
+    assert ev["is_train"] is False and ev["time"] == float(ds.times[5]) and int(ev["ray_mask"].sum()) + int(ev["ray_mask_bkg"].sum()) == H * W
+    n0 = int(f0["ray_mask"].sum())
+    c0 = None
+    for k in (0, 7, 20, 33):
+        fr = ds.freeview_frame(5, k, 40)
+        n = int(fr["ray_mask"].sum())
+        assert 0.3 * n0 < n < 3.0 * n0, (k, n, n0)                           # the subject's box stays in the picture
+        for z in (float(fr["near"].mean()), float(fr["far"].mean())):
+            assert _line_offset(fr, z) < 1e-4, (k, z)
+        A = fr["newsmpl_to_scale_world"].double()
+        cam_world = fr["rays_o_bkg"][0].double()                              # all background rays start at the camera centre
+        subj_world = A[:3, 3]                                                 # the body frame's origin (= Th in SMPL space) in the scaled world
+        dist = float((cam_world - subj_world).norm())
+        c0 = dist if c0 is None else c0
+        assert abs(dist - c0) < 1e-4 * c0, (k, dist, c0)
+
+
+def test_launcher_trains_evaluates_and_renders_from_a_scene_directory(tmp_path):
+    """run.py end to end on a scene DIRECTORY (images/, masks/, images_flow/ decoded by the launcher): two stage-3 optimiser steps,
+    `run.run_eval` -> one held-out frame + PSNR, `run.run_render` -> two cameras of the free-viewpoint turn, all from last.ckpt."""
+    import json
+    from hosnerf_amd import synth
+    from hosnerf_amd.freeview import write_scene_pixels
+    scene = str(tmp_path / "scene")
+    H = W = 64
+    px = synth.write_scene_dir(scene, 6, H, W, seed=9)
+    write_scene_pixels(scene, px)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("patch:\n  N_patches: 2\n  size: 16\nfreeview:\n  frame_idx: 3\n")
+    logs = str(tmp_path / "logs")
+    cmd = [sys.executable, os.path.join(ROOT, "run.py"), "--ginc", os.path.join(ROOT, "configs", "hosnerf_backpack.gin"),
+           "--ginb", "run.max_steps=2", "--ginb", "run.log_every_n_steps=1", "--ginb", f'run.datadir="{scene}"', "--ginb", 'run.human_path=""',
+           "--ginb", 'run.bkgd_path=""', "--ginb", "run.run_eval=True", "--ginb", "run.run_render=True", "--logbase", logs,
+           "--scene_name", "synthetic", "--scene_dir", scene, "--cfg", str(cfg), "--eval_skip", "100", "--render_frames", "40", "--render_limit", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-4000:])
+    assert len([l for l in r.stdout.splitlines() if l.startswith("[run] step")]) == 2 and "Test PSNR" in r.stdout and "Freeview" in r.stdout
+    logdir = [os.path.join(logs, d) for d in os.listdir(logs)][0]
+    res = json.load(open(os.path.join(logdir, "results.json")))
+    assert list(res["test"]["frames"]) == ["frame_000000"] and np.isfinite(res["test"]["psnr"]) and 0.0 < res["test"]["psnr"] < 60.0
+    assert res["freeview"] == {"frame_idx": 3, "frames": 2, "of": 40, "psnr_vs_training_frame": res["freeview"]["psnr_vs_training_frame"]}
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(logdir, "test_vis", "frame_000000.png")))
+    assert img.shape == (H, W, 3) and img.std() > 0
+    for k in (0, 1):
+        assert os.path.exists(os.path.join(logdir, "freeview_vis_newtrans", "view_00003", f"image-{k:05d}.jpg"))
+    # the modes also run WITHOUT training, from the checkpoint the first call wrote
+    cmd2 = cmd + ["--ginb", "run.run_train=False", "--ginb", "run.run_render=False"]          # later bindings win
+    r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r2.returncode == 0 and "[run] step" not in r2.stdout and "Test PSNR" in r2.stdout, (r2.stdout[-2000:], r2.stderr[-3000:])
+    res2 = json.load(open(os.path.join(logdir, "results.json")))
+    assert abs(res2["test"]["psnr"] - res["test"]["psnr"]) < 1e-3 and "freeview" not in res2
