@@ -185,15 +185,43 @@ def _human_item(rays, rank, stage):
     return b, prepare_patch_targets(b)
 
 
+_HOSCOMM = {}
+
+
+def hoscomm(rank, world):
+    """HOS_HOSCOMM=1 (opt-in; no N > 1 RCCL run has been possible on the build hardware): the step's collectives go through
+    libhoscomm.so (include/hoscomm.h) on the capture stream, so a rank's WHOLE data-parallel step -- forward, backward, gradient
+    exchange, decoder backward, clip + Adam -- is ONE hipGraph replay instead of two or three graphs with eager torch.distributed
+    collectives in between.  Returns the communicator (created once per process) or None."""
+    if os.environ.get("HOS_HOSCOMM", "0") != "1":
+        return None
+    if "c" not in _HOSCOMM:
+        from hosnerf_amd import comm, train
+        _HOSCOMM["c"] = comm.HosComm(rank, world)
+        train.use_hoscomm(_HOSCOMM["c"])
+    return _HOSCOMM["c"]
+
+
+def _maybe_shard_decoder(net, rank, world):
+    """HOS_SHARD_DECODER=1 (opt-in, N > 1): the volume decoder's first three transposed convolutions sharded over the ranks by input
+    channel (`Network.shard_decoder`; their collectives through libhoscomm when HOS_HOSCOMM=1, else torch.distributed -- then the
+    step cannot be captured and runs eagerly).  Must run before the optimiser is built."""
+    if world > 1 and os.environ.get("HOS_SHARD_DECODER", "0") == "1":
+        from hosnerf_amd.train import ShardComm
+        net.shard_decoder(ShardComm(rank, world, hos=hoscomm(rank, world)))
+
+
 def _reduce_human(net, opt, static_g=None):
     """The human network's exchange: the volume gradient (3.5 MB) + every parameter outside the volume decoder (4.3 MB).
     `static_g`: the volume-gradient tensor of a captured step (its address is fixed by the graph's memory pool)."""
     import torch.distributed as dist
-    from hosnerf_amd.train import allreduce_flat_grad
+    from hosnerf_amd import train
     g = static_g if static_g is not None else net.pending_volume_grad()
-    if g is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(opt.group) > 1:
+    if g is not None and train._HOS_COMM is not None:
+        train._HOS_COMM.all_reduce(g, average=False)
+    elif g is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(opt.group) > 1:
         dist.all_reduce(g, group=opt.group)
-    allreduce_flat_grad(net, opt.group, net.reduce_ranges())
+    train.allreduce_flat_grad(net, opt.group, net.reduce_ranges())
 
 
 def _reduce_human_begin(net, opt, static_g=None):
@@ -224,6 +252,7 @@ class Stage2(Workload):
         self.net = Network(cfg, stage=2)
         self.net.load_state_dict(synth.human_state_dict(777, 2), strict=True)
         self.net = self.net.to(dev)
+        _maybe_shard_decoder(self.net, rank, world)
         self.host_item, prepared = _human_item(self.rays_local, rank, 2)
         self.batch = batch_to_device(prepared, dev)      # control scalars (time, iter_val) stay on the host
         self.opt = FusedAdam(self.net, lr=6.667e-4, lr_ranges=human_lr_ranges(self.net, 6.667e-4, 6.667e-5), max_grad_norm=GRAD_MAX_NORM)
@@ -288,6 +317,7 @@ class Stage3(Workload):
         self.hos.model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
         self.hos.human.load_state_dict(synth.human_state_dict(777, 2), strict=True)
         self.hos = self.hos.to(dev)
+        _maybe_shard_decoder(self.hos.human, rank, world)
         self.host_item, prepared = _human_item(self.rays_local, rank, 3)
         self.batch = batch_to_device(prepared, dev)
         clip = GradClip(GRAD_MAX_NORM)      # ONE norm over both modules: the reference has a single Adam over both (optimizer.py:19-60)
@@ -440,7 +470,10 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
     barrier()
     f_cyc = wl.f_cyc() if args.warmup > 0 else None          # read once, after warm-up, before anything is captured or timed
     graph, graph2, graph3, static_loss, launch, overlap = None, None, None, None, "eager", False
-    full_graph = world == 1        # RCCL stays outside the captured region: two graphs with the eager collectives in between
+    # torch.distributed's collectives stay outside the captured region (two or three graphs with the eager collectives in between);
+    # through libhoscomm (HOS_HOSCOMM=1) they are stream work like any kernel and the whole step is one graph
+    in_graph_comm = world > 1 and hoscomm(rank, world) is not None
+    full_graph = world == 1 or in_graph_comm
     second_half = None
     if not args.no_graph:
         # N > 1: first the overlapped second half (async collectives), then the sequential one, then eager launches
@@ -464,6 +497,8 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                 with torch.cuda.graph(graph, capture_error_mode=mode):
                     static_loss = wl.fwd_bwd(args.warmup)
                     if full_graph:
+                        if in_graph_comm:
+                            wl.reduce()                    # RCCL on the capture stream (libhoscomm)
                         wl.finish(args.warmup, True)
                 overlap = try_overlap
                 if not full_graph:
@@ -503,7 +538,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                     if not full_graph:
                         second_half()
                 torch.cuda.synchronize()
-                launch = ("hipGraph replay" if full_graph else
+                launch = ("hipGraph replay (collectives inside the graph: libhoscomm / RCCL)" if in_graph_comm else "hipGraph replay" if full_graph else
                           "hipGraph replay (fwd+bwd) + async all-reduces + hipGraph replay (decoder bwd, under the exchange) + hipGraph replay (Adam)" if overlap else
                           "hipGraph replay (fwd+bwd) + eager all-reduce + hipGraph replay (decoder bwd + Adam)")
                 break

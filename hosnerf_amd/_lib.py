@@ -64,6 +64,8 @@ PROTOTYPES = {
     "hos_rays_aabb": [_P, _P, _L, _P, _P, _P, _P, _P],
     "hos_deconv3d_col2im": [_P, _P, _I, _I, _F, _I, _P, _P],
     "hos_deconv3d_im2col": [_P, _I, _I, _P, _P],
+    "hos_bias_lrelu": [_P, _P, _L, _I, _F, _I, _P],
+    "hos_shard_interleave": [_P, _I, _I, _I, _P, _P],
     "hos_deconv3d_dpre": [_P, _P, _L, _I, _F, _I, _P, _P, _P],
     "hos_gemv_ws_floats": [_I, _I],
     "hos_gemv_rowvec": [_P, _P, _I, _I, _I, _P, _I, _F, _I, _P, _P, _P],
@@ -137,6 +139,7 @@ PROTOTYPES = {
     "hos_volume_channel_last": [_P, _I, _L, _P, _P],
     "hos_volume_pair_bwd": [_P, _P, _I, _I, _L, _P, _P],
     "hos_copy_or_zero_n": [_I, _P, _P, _P, _P],
+    "hos_debug_stamp": [_P, _I, _P],
     "hos_add_n": [_I, _P, _L, _P, _P],
     "hos_any_abs_below": [_P, _L, _F, _P, _P],
     "hos_state_embed_grad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],

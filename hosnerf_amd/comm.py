@@ -28,6 +28,7 @@ PROTOTYPES = {
     "hos_comm_rank": [c_void_p, c_void_p],
     "hos_allreduce_sum_f32": [c_void_p, c_void_p, c_int64, c_void_p],
     "hos_allreduce_avg_f32": [c_void_p, c_void_p, c_int64, c_void_p],
+    "hos_allreduce_max_u32": [c_void_p, c_void_p, c_int64, c_void_p],
     "hos_allgather_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "hos_allreduce_avg_f32_spans": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
 }
@@ -96,6 +97,13 @@ class HosComm:
         """In place on the current stream (capturable): sum, or sum / world."""
         fn = load().hos_allreduce_avg_f32 if average else load().hos_allreduce_sum_f32
         _check(fn(self._h, _f32(t), t.numel(), stream_ptr()), "hos_allreduce")
+        return t
+
+    def all_reduce_max_u32(self, t: torch.Tensor):
+        """In place MAX of a contiguous int32 / uint32 HIP tensor (the range-guard word)."""
+        if not (t.is_cuda and t.is_contiguous() and t.element_size() == 4 and not t.is_floating_point()):
+            raise HosLibraryError("all_reduce_max_u32 takes a contiguous 32-bit integer HIP tensor")
+        _check(load().hos_allreduce_max_u32(self._h, t.data_ptr(), t.numel(), stream_ptr()), "hos_allreduce_max_u32")
         return t
 
     def all_reduce_spans(self, flat: torch.Tensor, spans: List):

@@ -233,6 +233,47 @@ extern "C" int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, 
     return hos_launch_status();
 }
 
+// ---- round 5: pieces of the volume decoder sharded over the data-parallel ranks by INPUT channel ------------------------
+// A rank multiplies its rows [c0, c1) of a layer's weight: the forward's partial pre-activations are summed over the ranks (after
+// the linear col2im), then bias + LeakyReLU are applied here; the backward's input-gradient slices are gathered rank after rank
+// and interleaved into channel order here.
+namespace {
+__global__ __launch_bounds__(256) void bias_lrelu_kernel(float* __restrict__ y, const float* __restrict__ bias, long total, int N, float slope, int leaky) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        float v = y[e] + (bias ? bias[e % N] : 0.f);
+        if (leaky && v < 0.f) v *= slope;
+        y[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void shard_interleave_kernel(const float* __restrict__ parts, int world, int M, int cs, float* __restrict__ out) {
+    const long total = (long)world * M * cs;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % cs);
+        const int m = (int)((e / cs) % M);
+        const int r = (int)(e / ((long)cs * M));
+        out[(size_t)m * ((size_t)world * cs) + (size_t)r * cs + c] = parts[e];
+    }
+}
+}  // namespace
+// y [M, N] = LeakyReLU?(y + bias [N]) in place (bias may be NULL)
+extern "C" int hos_bias_lrelu(float* y, const float* bias, long long M, int N, float leaky_slope, int leaky, hos_stream_t stream) {
+    if (!y || M <= 0 || N <= 0) return HOS_E_ARG;
+    const long total = (long)M * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bias_lrelu_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias, total, N, leaky_slope, leaky);
+    return hos_launch_status();
+}
+// out [M, world * cs] with out[m][r * cs + c] = parts[r][m][c] (parts [world, M, cs]: what an all-gather of per-rank [M, cs] slices returns)
+extern "C" int hos_shard_interleave(const float* parts, int world, int M, int cs, float* out, hos_stream_t stream) {
+    if (!parts || !out || world <= 0 || M <= 0 || cs <= 0) return HOS_E_ARG;
+    const long total = (long)world * M * cs;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(shard_interleave_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), parts, world, M, cs, out);
+    return hos_launch_status();
+}
+
 extern "C" int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream) {
     if (!dpre || !dycol || D <= 0 || Cout <= 0) return HOS_E_ARG;
     const long total = (long)D * D * D * Cout * 64;

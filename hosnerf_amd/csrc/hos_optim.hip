@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // ---- round 4: ONE norm launch + ONE update launch per training step, whatever the number of flat buffers / learning-rate ranges,
 // and the fp16 range guard consumed on the device.
-constexpr int OPT_SPANS = 8;
+constexpr int OPT_SPANS = 16;      // (round 5: 8 -> 16; a rank that owns a SHARD of the volume decoder has a few more active spans)
 constexpr int SUMSQ_BLOCKS = 1024;
 struct SumsqSpans { const float* g[OPT_SPANS]; long start4[OPT_SPANS + 1]; int count; };      // spans in float4 units (n % 4 == 0)
 
@@ -209,7 +209,7 @@ extern "C" int hos_sumsq_partials(int n, const float* const* g, const long long*
     return hos_launch_status();
 }
 
-// torch.optim.Adam over n <= 8 spans of flat buffers in ONE launch (M1:536-569, optimizer.py:19-60: the reference's per-parameter
+// torch.optim.Adam over n <= 16 spans of flat buffers in ONE launch (M1:536-569, optimizer.py:19-60: the reference's per-parameter
 // groups are contiguous ranges here).  Span s: p/g/m/v[s][0 .. count[s]) with count % 4 == 0; its step scalars come from device
 // memory (hyper[s] = {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}, graph replay) or, where hyper[s] is NULL, from lr[s] and `step`.
 // partial (NULL: no clipping): hos_sumsq_partials' output, summed here; coefficient min(max_norm / (sqrt(sum) * |grad_scale| + 1e-6), 1).

@@ -126,3 +126,15 @@ extern "C" int hos_state_embed_grad(const float* db, const float* W, int ldw, in
     hipLaunchKernelGGL(state_embed_grad_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), db, W, ldw, c0, N, E, gb, g_embed);
     return hos_launch_status();
 }
+
+// Diagnostics: buf[slot] = the constant 100 MHz counter when this point of the stream is reached (one thread).  A kernel node like
+// any other, so it can sit inside a captured step: the un-profiled timeline of the two-stream step (scripts/diag_overlap.py;
+// rocprofv3's per-node interception stretches the host-side replay and with it the picture).
+namespace {
+__global__ void debug_stamp_kernel(long long* __restrict__ buf, int slot) { buf[slot] = (long long)wall_clock64(); }
+}
+extern "C" int hos_debug_stamp(long long* buf, int slot, hos_stream_t stream) {
+    if (!buf || slot < 0) return HOS_E_ARG;
+    hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), buf, slot);
+    return hos_launch_status();
+}

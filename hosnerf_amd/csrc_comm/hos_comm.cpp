@@ -51,6 +51,12 @@ static int allreduce(hos_comm_t comm, float* buf, int64_t count, ncclRedOp_t op,
 extern "C" int hos_allreduce_sum_f32(hos_comm_t comm, float* buf, int64_t count, void* stream) { return allreduce(comm, buf, count, ncclSum, stream); }
 extern "C" int hos_allreduce_avg_f32(hos_comm_t comm, float* buf, int64_t count, void* stream) { return allreduce(comm, buf, count, ncclAvg, stream); }
 
+// in-place MAX over the ranks of `count` unsigned 32-bit words (the fp16 range-guard word: every rank must take the same decision)
+extern "C" int hos_allreduce_max_u32(hos_comm_t comm, unsigned int* buf, int64_t count, void* stream) {
+    if (!comm || !buf || count <= 0) return -1;
+    return rc_of(ncclAllReduce(buf, buf, (size_t)count, ncclUint32, ncclMax, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)));
+}
+
 extern "C" int hos_allgather_f32(hos_comm_t comm, const float* send, float* recv, int64_t count_per_rank, void* stream) {
     if (!comm || !send || !recv || count_per_rank <= 0) return -1;
     return rc_of(ncclAllGather(send, recv, (size_t)count_per_rank, ncclFloat32, static_cast<ncclComm_t>(comm), static_cast<hipStream_t>(stream)));

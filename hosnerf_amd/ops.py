@@ -693,6 +693,119 @@ def deconv3d_first(x: torch.Tensor, wc: torch.Tensor, gwc: torch.Tensor, bias: t
     return _Deconv3dFirst.apply(x, wc, gwc, bias, leaky)
 
 
+# ---- round 5: the same two layers with the weight SHARDED over the data-parallel ranks by input channel -------------------------
+# The volume decoder sees no ray (its input is a learned constant), so under DDP every rank used to stream the same 136 MB of
+# weights forward, the same again twice backward and 253 MB of Adam state -- ~1.1 ms of a 6 ms 512-ray step that does not shrink
+# with the ray count.  Rank r owns rows [c0, c1) of a layer's [Cin, Cout * 64] weight (a CONTIGUOUS range of the flat buffer, so
+# the optimiser spans stay ranges): forward  = partial product of its input columns, col2im (linear), SUM over the ranks, bias +
+# LeakyReLU;  backward = bias gradient / LeakyReLU mask / im2col on the full (already rank-summed) output gradient (replicated,
+# small), its rows of the weight gradient (complete: no reduction), its columns of the input gradient, all-gathered.  Per
+# sharded layer and step: one all-reduce of [(2D)^3, Cout] and one all-gather of [D^3, Cin] floats (<= 512 KB).  `comm` is a
+# train.ShardComm (RCCL through libhoscomm inside a captured graph, or torch.distributed).
+class _Deconv3dSharded(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, D, leaky, comm):
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        cs = Cin // comm.world
+        c0 = comm.rank * cs
+        M = D * D * D
+        x = x.contiguous()
+        Wm = weight.detach().view(Cin, Cout * 64)
+        ycol = torch.empty(M, Cout * 64, device=x.device)
+        with gemm_mode(GEMM_FP32):          # ycol = x[:, c0:c1] @ Wm[c0:c1]  (the column slice of x by pointer + row stride)
+            call("hos_linear_dgrad", ptr(x) + 4 * c0, x.stride(0), ptr(Wm[c0:c0 + cs]), Wm.stride(0), cs, None, 0,
+                 ptr(ycol), ycol.stride(0), M, Cout * 64, 0)
+        out = torch.empty(8 * M, Cout, device=x.device)
+        call("hos_deconv3d_col2im", ptr(ycol), None, D, Cout, 0.2, 0, ptr(out))
+        comm.all_reduce_sum(out)
+        call("hos_bias_lrelu", ptr(out), ptr(bias.detach()), 8 * M, Cout, 0.2, int(leaky))
+        ctx.save_for_backward(x, weight, bias, out)
+        ctx.D, ctx.leaky, ctx.comm = D, leaky, comm
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, bias, out = ctx.saved_tensors
+        D, leaky, comm = ctx.D, ctx.leaky, ctx.comm
+        Cin, Cout = weight.shape[0], weight.shape[1]
+        cs = Cin // comm.world
+        c0 = comm.rank * cs
+        M = D * D * D
+        g = g.contiguous()
+        if not (weight.grad is not None and weight.grad.is_contiguous() and bias.grad is not None and bias.grad.is_contiguous()):
+            raise _lib.HosLibraryError("sharded decoder layers accumulate into the flat gradient buffer (FlatStore-bound parameters)")
+        dpre = torch.empty_like(g) if leaky else g
+        call("hos_deconv3d_dpre", ptr(g), ptr(out), 8 * M, Cout, 0.2, int(leaky), ptr(dpre) if leaky else None, ptr(bias.grad))
+        dycol = torch.empty(M, Cout * 64, device=g.device)
+        call("hos_deconv3d_im2col", ptr(dpre), D, Cout, ptr(dycol))
+        Wm = weight.detach().view(Cin, Cout * 64)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            mine = torch.empty(M, cs, device=g.device)
+            call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(Wm[c0:c0 + cs]), Wm.stride(0), ptr(mine), cs, M, cs, Cout * 64)
+            parts = comm.all_gather(mine)                       # [world, M, cs]
+            dx = torch.empty(M, Cin, device=g.device)
+            call("hos_shard_interleave", ptr(parts), comm.world, M, cs, ptr(dx))
+        gW = weight.grad.view(Cin, Cout * 64)
+        with gemm_mode(GEMM_FP32):
+            if M <= 8:
+                call("hos_outer_accum", ptr(x) + 4 * c0, x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW[c0:c0 + cs]), gW.stride(0), M, cs, Cout * 64)
+            else:                           # gW[c0:c1] += x[:, c0:c1]^T @ dycol
+                call("hos_linear_wgrad", ptr(x) + 4 * c0, x.stride(0), ptr(dycol), dycol.stride(0), ptr(gW[c0:c0 + cs]), gW.stride(0),
+                     None, M, cs, Cout * 64, 0)
+        return dx, None, None, None, None, None
+
+
+def deconv3d_sharded(x, weight, bias, D: int, leaky: bool, comm) -> torch.Tensor:
+    return _Deconv3dSharded.apply(x, weight, bias, D, leaky, comm)
+
+
+class _Deconv3dFirstSharded(torch.autograd.Function):
+    """`_Deconv3dFirst` (one input voxel, live taps [Cin, 8 * Cout]) with the rows [c0, c1) of this rank."""
+
+    @staticmethod
+    def forward(ctx, x, wc, gwc, bias, leaky, comm):
+        Cin, N8 = wc.shape
+        Cout = N8 // 8
+        cs = Cin // comm.world
+        c0 = comm.rank * cs
+        x = x.contiguous()
+        out = torch.empty(8, Cout, device=x.device)
+        ws = torch.empty(int(_lib.load().hos_gemv_ws_floats(cs, N8)), device=x.device)
+        call("hos_gemv_rowvec", ptr(x) + 4 * c0, ptr(wc[c0:c0 + cs]), wc.stride(0), cs, N8, None, Cout, 0.2, 0, ptr(ws), ptr(out))
+        comm.all_reduce_sum(out)
+        call("hos_bias_lrelu", ptr(out), ptr(bias.detach()), 8, Cout, 0.2, int(leaky))
+        ctx.save_for_backward(x, bias, out)
+        ctx.wc, ctx.gwc, ctx.leaky, ctx.comm = wc, gwc, leaky, comm
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, out = ctx.saved_tensors
+        wc, gwc, comm = ctx.wc, ctx.gwc, ctx.comm
+        Cin, N8 = wc.shape
+        Cout = N8 // 8
+        cs = Cin // comm.world
+        c0 = comm.rank * cs
+        g = g.contiguous()
+        if not (bias.grad is not None and bias.grad.is_contiguous()):
+            raise _lib.HosLibraryError("sharded decoder layers accumulate into the flat gradient buffer (FlatStore-bound parameters)")
+        dpre = torch.empty_like(g) if ctx.leaky else g
+        call("hos_deconv3d_dpre", ptr(g), ptr(out), 8, Cout, 0.2, int(ctx.leaky), ptr(dpre) if ctx.leaky else None, ptr(bias.grad))
+        dycol = dpre.view(1, N8)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            mine = torch.empty(1, cs, device=g.device)
+            call("hos_linear_fwd_splitk", ptr(dycol), dycol.stride(0), ptr(wc[c0:c0 + cs]), wc.stride(0), ptr(mine), cs, 1, cs, N8)
+            dx = comm.all_gather(mine).reshape(1, Cin)           # one row: rank order IS channel order
+        call("hos_outer_accum", ptr(x) + 4 * c0, x.stride(0), ptr(dycol), dycol.stride(0), ptr(gwc[c0:c0 + cs]), gwc.stride(0), 1, cs, N8)
+        return dx, None, None, None, None, None
+
+
+def deconv3d_first_sharded(x, wc, gwc, bias, leaky: bool, comm) -> torch.Tensor:
+    return _Deconv3dFirstSharded.apply(x, wc, gwc, bias, leaky, comm)
+
+
 DECODER_HEAD_INPLACE = True      # the training step's loss.backward(); set False around torch.autograd.grad / gradcheck of this node
 
 

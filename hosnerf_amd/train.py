@@ -66,13 +66,41 @@ def allreduce_flat_grad_async(module: FlatModule, group=None, ranges=None) -> li
     return [dist.all_reduce(module.flat_grad[off:off + n], group=group, async_op=True) for off, n in ranges if n > 0]
 
 
-def allreduce_flat_grad(module: FlatModule, group=None, ranges=None) -> int:
+_HOS_COMM = None
+
+
+def use_hoscomm(hos):
+    """Route the gradient exchange (`allreduce_flat_grad`, the range-guard word) through a `comm.HosComm` communicator -- RCCL
+    called from libhoscomm.so on the CURRENT stream, i.e. capturable: with it the whole data-parallel step (forward, backward,
+    collectives, optimiser) is ONE hipGraph per rank instead of two or three graphs with eager torch.distributed collectives in
+    between (bench.py, HOS_HOSCOMM=1).  `None` restores torch.distributed.  Returns the previous communicator."""
+    global _HOS_COMM
+    prev, _HOS_COMM = _HOS_COMM, hos
+    return prev
+
+
+def allreduce_flat_grad(module: FlatModule, group=None, ranges=None, hos=None) -> int:
     """Sum the flat gradient over the data-parallel group (RCCL on MI355X, gloo in the CPU tests) and return
     the world size; the 1/world averaging is folded into the Adam kernel's grad_scale.
     ONE collective per step over the whole gradient: xGMI is point-to-point, so a single large message keeps
     every link busy (DDP's default 25 MB buckets would split the 38 MB stage-1 gradient in two).
     `ranges` [(offset, numel), ...] restricts the exchange to those spans (the human network's volume decoder is reduced at
-    its 3.5 MB output instead of its 253 MB of parameters, Network.decoder_backward)."""
+    its 3.5 MB output instead of its 253 MB of parameters, Network.decoder_backward).
+    `hos` (default: the communicator set by `use_hoscomm`): the same sums through libhoscomm.so on the current stream."""
+    hos = _HOS_COMM if hos is None else hos
+    if getattr(module, "decoder_shard", None) is not None and ranges is None:
+        raise RuntimeError("this module's volume decoder is sharded over the ranks: exchange `module.reduce_ranges()` only "
+                           "(train.backward_human / finish_backward_human do), never the whole flat gradient")
+    if hos is not None:
+        if ranges is None:
+            ranges = module.store.active_spans() if getattr(module.store, "inactive", None) else [(0, module.flat_grad.numel())]
+        flag, _ = ops.range_guard_words(module.flat_grad.device) if ops.RANGE_GUARD else (None, None)
+        if flag is not None and hos.world > 1:
+            hos.all_reduce_max_u32(flag)
+        for off, n in ranges:
+            if n > 0:
+                hos.all_reduce(module.flat_grad[off:off + n], average=False)
+        return hos.world
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
@@ -101,6 +129,59 @@ def _allreduce_range_guard(device, group=None):
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
 
 
+class ShardComm:
+    """The collectives of a module whose parameters are SHARDED over the data-parallel ranks (the human network's volume decoder,
+    `Network.shard_decoder`): sum-all-reduce and all-gather of small fp32 tensors on the current stream.  With `hos` (a
+    `comm.HosComm`: RCCL through libhoscomm.so) the calls are plain stream work and may sit inside a captured hipGraph -- the
+    decoder's forward is the first thing of the human branch, i.e. in the middle of the captured step; without it they go through
+    torch.distributed (`group`; any backend, eager only -- the CPU-side harness of the tests runs two ranks on one GPU over gloo)."""
+
+    def __init__(self, rank: int, world: int, group=None, hos=None):
+        self.rank, self.world, self.group, self.hos = int(rank), int(world), group, hos
+        if hos is not None and (hos.rank != self.rank or hos.world != self.world):
+            raise ValueError("ShardComm: the HosComm communicator has another rank / size")
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        if self.hos is not None:
+            return self.hos.all_reduce(t, average=False)
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def all_gather(self, send: torch.Tensor) -> torch.Tensor:
+        """[world, *send.shape]: rank r's tensor at index r."""
+        send = send.contiguous()
+        if self.world == 1:
+            return send.unsqueeze(0)
+        if self.hos is not None:
+            return self.hos.all_gather(send)
+        recv = torch.empty((self.world,) + tuple(send.shape), device=send.device, dtype=send.dtype)
+        dist.all_gather(list(recv.unbind(0)), send, group=self.group)
+        return recv
+
+
+def _shard_norm_correction(opts, target: torch.Tensor):
+    """A rank that owns a SHARD of some parameters has only that shard's gradient: its local sum of squares is R + s_r (R: the
+    replicated parameters, identical on every rank; s_r: its shard).  The norm the reference clips by is over ALL parameters,
+    R + sum_r s_r: add (sum_r s_r - s_r) to the first element of `target` (the partial-sum array / the scalar the Adam launch
+    adds up).  One 4-byte all-reduce per step; a no-op without sharded modules."""
+    for o in opts:
+        comm = getattr(o.module, "decoder_shard", None)
+        if comm is None or comm.world == 1:
+            continue
+        g = o.module.flat_grad
+        bufs = getattr(o.module, "_shard_norm_bufs", None)
+        if bufs is None or bufs.device != g.device:
+            bufs = o.module._shard_norm_bufs = torch.zeros(2, device=g.device)
+        ops.zero_(bufs)
+        for off, n in o.module.decoder_shard_spans():
+            ops.sumsq(g[off:off + n], bufs[0:1])
+        ops.copy_or_zero_n([bufs[1:2]], [bufs[0:1]])
+        comm.all_reduce_sum(bufs[1:2])
+        target[0:1].add_(bufs[1:2] - bufs[0:1])
+
+
 class GradClip:
     """`Trainer(gradient_clip_val=max_norm, gradient_clip_algorithm="norm")` of the reference's launchers (S1/run.py:155,
     2nd_.../run.py:185-186, 3rd_.../run.py:188-189; every Backpack.gin binds `run.grad_max_norm = 0.001`): Lightning calls
@@ -125,6 +206,7 @@ class GradClip:
             g = o.module.flat_grad
             for off, n in o.module.store.active_spans():          # the whole buffer unless the module has inactive spans
                 ops.sumsq(g[off:off + n], self._buf)
+        _shard_norm_correction(opts, self._buf)
         return self._buf
 
     def partials(self, opts) -> Optional[torch.Tensor]:
@@ -136,12 +218,13 @@ class GradClip:
         for o in opts:
             g = o.module.flat_grad
             spans += [g[off:off + n] for off, n in o.module.store.active_spans()]
-        if len(spans) > 8 or any((t.numel() % 4) or (t.data_ptr() % 16) for t in spans):
+        if len(spans) > 16 or any((t.numel() % 4) or (t.data_ptr() % 16) for t in spans):
             return None
         dev = spans[0].device
         if getattr(self, "_partials", None) is None or self._partials.device != dev:
             self._partials = torch.empty(ops.sumsq_blocks(), device=dev)
         ops.sumsq_partials(spans, self._partials)
+        _shard_norm_correction(opts, self._partials)
         return self._partials
 
 
@@ -219,6 +302,8 @@ class FusedAdam:
         self.module.store.zero_grad()
 
     def world_size(self) -> int:
+        if _HOS_COMM is not None:
+            return _HOS_COMM.world
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     @property
@@ -275,7 +360,7 @@ def _step_multi(opts, lrs, dynamic: bool) -> bool:
     """The whole optimiser step of `opts` (already reduced gradients) as TWO launches: the joint gradient norm of every active span
     (hos_sumsq_partials) and torch.optim.Adam over every learning-rate range of every module (hos_adam_multi), which also
     consumes the fp16 range-guard word: a step whose forward left the exact hi/lo range updates nothing (train.range_skips counts).
-    Returns False when the step does not fit that form (CPU tensors, > 8 spans, unaligned ranges, separate clip objects)."""
+    Returns False when the step does not fit that form (CPU tensors, > 16 spans, unaligned ranges, separate clip objects)."""
     if not MULTI_ADAM or not opts or not opts[0].module.flat_param.is_cuda:
         return False
     clip = opts[0].clip
@@ -296,7 +381,7 @@ def _step_multi(opts, lrs, dynamic: bool) -> bool:
                 return False
             spans.append((p[off:off + n], g[off:off + n], o.exp_avg[off:off + n], o.exp_avg_sq[off:off + n],
                           o._hyper[r] if dynamic else None, float(l) * mult))
-    if len(spans) > 8 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
+    if len(spans) > 16 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
         return False
     partial = clip.partials(opts)
     if clip.max_norm > 0 and partial is None:
@@ -319,7 +404,7 @@ _GUARDLESS_WARNED = False
 
 
 def _guard_on_fallback_path(device, dynamic: bool) -> bool:
-    """The per-span Adam launches (hos_adam_step / hos_adam_step_dyn: > 8 spans, unaligned ranges, separate clip objects,
+    """The per-span Adam launches (hos_adam_step / hos_adam_step_dyn: > 16 spans, unaligned ranges, separate clip objects,
     HOS_MULTI_ADAM=0) take no guard word.  Outside a graph capture the host reads the flag itself (one 4-byte read per step of this
     rarely taken path) and returns True when the step must be skipped; under capture that is impossible and the guard is off for
     this optimiser -- said once, not silently."""

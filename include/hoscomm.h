@@ -37,6 +37,9 @@ int hos_comm_rank(hos_comm_t comm, int* rank);
  * size; _avg: sum / nranks in the same pass (ncclAvg) -- what `allreduce_flat_grad` needs for the flat gradient buffers. */
 int hos_allreduce_sum_f32(hos_comm_t comm, float* buf, int64_t count, void* stream);
 int hos_allreduce_avg_f32(hos_comm_t comm, float* buf, int64_t count, void* stream);
+/* In-place MAX of `count` unsigned 32-bit words: the fp16 range-guard word of the optimiser launch (hosrender.h: hos_adam_multi) --
+ * a rank whose rays tripped the guard makes every rank skip the step, or the replicas would part for good. */
+int hos_allreduce_max_u32(hos_comm_t comm, unsigned int* buf, int64_t count, void* stream);
 /* recv [nranks * count_per_rank] <- every rank's send [count_per_rank] in rank order (inference: a frame's ray shards). */
 int hos_allgather_f32(hos_comm_t comm, const float* send, float* recv, int64_t count_per_rank, void* stream);
 /* Several spans in ONE RCCL group call (the human network's exchange: the volume gradient + the parameter spans outside the

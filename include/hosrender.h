@@ -274,6 +274,12 @@ int hos_deconv3d_col2im(const float* ycol, const float* bias, int D, int Cout, f
 /* dycol[D^3][Cout*64] = gather of dpre[(2D)^3][Cout] (gradient w.r.t. the pre-activation output); zeros where a tap
  * leaves the output volume. */
 int hos_deconv3d_im2col(const float* dpre, int D, int Cout, float* dycol, hos_stream_t stream);
+/* Round 5, volume decoder sharded over the data-parallel ranks by INPUT channel (deconv_vol_decoder.py:17-42 replicated in the
+ * reference, run.py:173-190 DDP): hos_bias_lrelu: y [M, N] = LeakyReLU?(y + bias [N]) in place, behind the all-reduce of the ranks'
+ * partial pre-activations; hos_shard_interleave: out [M, world * cs], out[m][r * cs + c] = parts[r][m][c] -- the all-gathered
+ * per-rank input-gradient slices in channel order. */
+int hos_bias_lrelu(float* y, const float* bias, long long M, int N, float leaky_slope, int leaky, hos_stream_t stream);
+int hos_shard_interleave(const float* parts, int world, int M, int cs, float* out, hos_stream_t stream);
 
 /* Backward of the block's LeakyReLU and its bias gradient in one pass over the output gradient g [R, C] (channel-last, R =
  * (2D)^3): dpre = g * (out > 0 ? 1 : leaky_slope) if leaky != 0 (else g is already the pre-activation gradient and dpre is not
@@ -640,6 +646,9 @@ int hos_volume_pair_bwd(const float* g_vol, const float* g_cl, int C, int Kb, lo
 /* n <= 8 buffers in one launch: dst[s][0 .. count[s]) = src[s] (src == NULL or src[s] == NULL: zeros).  Fills of accumulation
  * targets, stacks of per-frame tensors.  The tables are read during the call.  (plumbing; no reference counterpart) */
 int hos_copy_or_zero_n(int n, float* const* dst, const float* const* src, const long long* count, hos_stream_t stream);
+/* Diagnostics: buf[slot] = the constant 100 MHz device counter (s_memrealtime) when this point of the stream is reached; a kernel
+ * node, so it can be captured inside a step's graph (scripts/diag_overlap.py: the un-profiled timeline of the two-stream step). */
+int hos_debug_stamp(long long* buf, int slot, hos_stream_t stream);
 /* out[i] = sum_k src[k][i], n <= 8: the gradient of a tensor that feeds several consumers in one pass. */
 int hos_add_n(int n, const float* const* src, long long count, float* out, hos_stream_t stream);
 /* flag[0] = any |x[i]| < thr (M:1526, the tiny-direction test of the stage-3 re-projection, kept on the device). */
@@ -656,9 +665,9 @@ int hos_embed_bwd_res(const float* x, const float* band_w, int num_freqs, int id
 int hos_head_grad_padded(const float* g_density, const float* density, const float* g_rgb, const float* rgb, int P, float rgb_padding,
                          float* dz_density, int ld_dd, int col_dd, float* dz_rgb, int ld_dr, hos_stream_t stream);
 /* Gradient norm + Adam of a whole training step in TWO launches, whatever the number of flat buffers / learning-rate ranges.
- * hos_sumsq_partials: partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 8 spans (count % 4 == 0), fixed order,
+ * hos_sumsq_partials: partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 16 spans (count % 4 == 0), fixed order,
  * nothing to zero first (`Trainer(gradient_clip_val=..., "norm")`, S1/run.py:155, 3rd_.../run.py:188-189).
- * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 8 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
+ * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 16 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
  * from device memory hyper[s] (graph replay) or, if NULL, from lr[s] / step; clip coefficient min(max_norm / (sqrt(sum partial) *
  * |grad_scale| + 1e-6), 1) when partial != NULL; guard (the word of hos_set_range_flag, NULL: off): non-zero -> no parameter is
  * touched by THIS launch, skipped[0] is incremented and the word is cleared again (by the launch's last workgroup; skipped[1] is its

@@ -206,6 +206,15 @@ def run(args, gin):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     lit = lit.to(dev)
+    if world > 1 and bool(kw.get("shard_decoder", False)) and hasattr(lit, "human"):
+        # `run.shard_decoder = True` (this build's addition; the reference replicates the module under DDP): the volume decoder's
+        # first three layers sharded over the ranks (Network.shard_decoder); the optimiser is rebuilt on the remaining active spans
+        from hosnerf_amd.train import ShardComm
+        lit.human.shard_decoder(ShardComm(rank, world))
+        opt = lit.configure_optimizers()
+        if args.resume_training and os.path.exists(ckpt):
+            select_option.load_optimizer_states(ckpt, opt)
+        print(f"[run] volume decoder sharded over {world} ranks: this rank owns {sum(n for _, n in lit.human.decoder_shard_spans()) / 1e6:.2f} M of its parameters")
     if args.lpips_vgg16 or args.lpips_lin:
         if not (args.lpips_vgg16 and args.lpips_lin) or not hasattr(lit, "human"):
             raise SystemExit("--lpips_vgg16 and --lpips_lin go together and apply to the stages that own the human-object network")
@@ -255,12 +264,17 @@ def run(args, gin):
             loss = lit.training_step(batch, step)
             lit.backward(loss)           # human stages: volume decoder reduced at its 3.5 MB output gradient (train.backward_human)
             lit.optimizer_step(0, step, opt)
-            if save_every > 0 and (step + 1) % save_every == 0 and step + 1 < max_steps and rank == 0:
-                save_last(step + 1)
+            if save_every > 0 and (step + 1) % save_every == 0 and step + 1 < max_steps:
+                if getattr(getattr(lit, "human", None), "decoder_shard", None) is not None:
+                    lit.human.gather_decoder_shards()        # collective: every rank's flat buffer is complete before rank 0 writes it
+                if rank == 0:
+                    save_last(step + 1)
             if (step + 1) % log_every == 0 and rank == 0:
                 dt = time.perf_counter() - t0
                 print(f"[run] step {step + 1}/{max_steps} loss {float(loss):.5f} lr {opt.param_groups[0]['lr']:.3e} "
                       f"{(step + 1 - step0) * rays * world / dt:.0f} rays/s")
+        if getattr(getattr(lit, "human", None), "decoder_shard", None) is not None:
+            lit.human.gather_decoder_shards()
         if rank == 0 and bool(kw.get("save_last", True)):
             save_last(max_steps)
             print(f"[run] wrote {ckpt}")

@@ -84,10 +84,15 @@ def test_bench_two_ranks_share_one_gpu_strong_scaling():
     assert d["launch"].startswith("hipGraph replay (fwd+bwd)") and "all-reduce" in d["launch"], d["launch"]
 
 
-def test_two_rank_step_equals_gradient_averaging(tmp_path):
+@pytest.mark.parametrize("shard", [False, True], ids=["replicated_decoder", "sharded_decoder"])
+def test_two_rank_step_equals_gradient_averaging(tmp_path, shard):
     """Data-parallel correctness of the human network's exchange (3.5 MB volume gradient + 4.3 MB of other parameters, decoder
     backward on the SUM): two ranks, each on its own item, take two optimiser steps; the parameters equal those of one process
-    that accumulates the plain (un-split) backward of both items, halves the gradient and steps -- the definition of DDP."""
+    that accumulates the plain (un-split) backward of both items, halves the gradient and steps -- the definition of DDP.
+    `sharded_decoder` (round 5): the same with the volume decoder's first three transposed convolutions SHARDED over the two ranks
+    by input channel (`Network.shard_decoder`: partial forward products summed, input-gradient slices gathered, each rank's Adam
+    on its rows only, the clip norm completed with the other rank's shard) -- the parameters after two clipped steps, gathered
+    back from their owners, must be the replicated ones."""
     import torch
     sys.path.insert(0, ROOT)
     import bench
@@ -95,8 +100,10 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
     e = _env()
     e["HOS_BENCH_ONE_GPU"] = "1"
     e["HOS_DP_OUT"] = str(tmp_path / "dp.pt")
+    if shard:
+        e["HOS_SHARD_DECODER"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "tests", "_dp_worker.py")]
+           "--master-port", "29548" if shard else "29547", os.path.join(ROOT, "tests", "_dp_worker.py")]
     r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     got = torch.load(e["HOS_DP_OUT"])
@@ -106,6 +113,7 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
     assert got["rays_local"] == A.rays_local == W.RAYS // 2
     from hosnerf_amd.train import stage2_losses
     p0 = A.net.store.param.detach().clone()
+    sumsq0 = None
     for i in range(W.STEPS):
         A.opt.zero_grad()
         A.net.split_decoder_backward = False
@@ -114,6 +122,8 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
             loss, _ = stage2_losses(A.net(static_cycle=True, **item), item)
             loss.backward()                       # accumulates into the flat gradient
         A.net.store.ensure_bound()
+        if i == 0:
+            sumsq0 = float((A.net.store.grad.double() ** 2).sum())        # of the SUMMED gradient, like the ranks' clip kernels see it
         A.net.store.grad.mul_(0.5)
         A.opt.step(A.lr(i))
     want = A.net.store.param.detach().cpu()
@@ -125,7 +135,22 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
     # bounded loosely, the bulk tightly)
     frac_close = float(((got["param"] - want).abs() < 1e-3 * moved).float().mean())
     from tests._record import record
-    record("dist.two_rank_step_vs_gradient_averaging[stage 2, 2 x 256 rays, 2 steps]",
+    record("dist.two_rank_step_vs_gradient_averaging[stage 2, 2 x 256 rays, 2 steps]" + ("[sharded decoder]" if shard else ""),
            {"max_param_step": moved, "max_abs_diff": err, "fraction_within_1e-3_of_a_step": frac_close})
-    assert err < 0.1 * moved, (err, moved)
-    assert frac_close > 0.999, frac_close
+    # the gradient norm both ranks clip by: every shard's share is in it (`train._shard_norm_correction`)
+    assert got.get("sumsq_step0") is not None and abs(got["sumsq_step0"] - sumsq0) < 1e-3 * sumsq0, (got.get("sumsq_step0"), sumsq0)
+    if not shard:
+        assert err < 0.1 * moved, (err, moved)
+        assert frac_close > 0.999, frac_close
+        return
+    # Sharded: the decoder's forward sums its input channels in another order (two partial products + an all-reduce), so the
+    # volume differs from the replicated one at fp32 rounding (asserted below).  The DECODER's parameters must still come out
+    # as if it were replicated; downstream of the volume the warp's x / max(sum w, 1e-4) and the 2^9-frequency Fourier features
+    # amplify that rounding (tests/test_gpu_conditioning.py), and Adam turns a few-per-cent change of a 1e-7 gradient element
+    # into a few per cent of a step: those parameters are bounded in units of the step, bulk and worst element.
+    assert got["volume_rel_err"] < 2e-6, got["volume_rel_err"]
+    off, n = A.net.decoder_span()
+    d = (got["param"] - want).abs()
+    assert float(d[off:off + n].max()) < 1e-2 * moved and float((d[off:off + n] < 1e-3 * moved).float().mean()) > 0.9995, \
+        (float(d[off:off + n].max()), moved)
+    assert err < 0.25 * moved and frac_close > 0.995, (err, moved, frac_close)
