@@ -40,6 +40,9 @@
 #ifndef HOS_ABLATE_DMA
 #define HOS_ABLATE_DMA 0
 #endif
+#ifndef HOS_MFMA_ORDER
+#define HOS_MFMA_ORDER 0
+#endif
 // Round 5: FWD / DGRAD launches of the 256-wide tile are PERSISTENT -- one workgroup per CU walks the output tiles and the K
 // pipeline (LDS-DMA two tiles ahead) runs straight across tile boundaries, so a tile has no prologue: its first two K tiles
 // are requested while the previous tile still multiplies, and its epilogue's stores drain under the next tile's K loop.
@@ -383,6 +386,15 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // while the matrix pipe is busy.  Eight back-to-back global_load_lds stalled a wave for 600-1900 cycles
     // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once).
     constexpr int NM = 3 * TM * TH;
+    // order of the NM MFMAs of a quarter (timing experiment HOS_MFMA_ORDER; 0 = product-major, the three products of one
+    // accumulator four MFMAs apart; 1 = A fragment stationary: hi.lo, hi.hi, lo.hi per row block; 2 = B fragment stationary)
+#if HOS_MFMA_ORDER == 1
+#define HOS_ORDER_DECODE(i) const int x = (i) / (3 * TH), pj_ = ((i) % (3 * TH)) / TH, pr = pj_ == 0 ? 1 : (pj_ == 1 ? 2 : 0), y = (i) % TH
+#elif HOS_MFMA_ORDER == 2
+#define HOS_ORDER_DECODE(i) const int y = (i) / (3 * TM), pj_ = ((i) % (3 * TM)) / TM, pr = pj_ == 0 ? 2 : (pj_ == 1 ? 0 : 1), x = (i) % TM
+#else
+#define HOS_ORDER_DECODE(i) const int pr = (i) / (TM * TH), x = ((i) % (TM * TH)) / TH, y = (i) % TH
+#endif
 #define HOS_GROUP(AH, AL, BH, BL, YH, FILL)                                                               \
     do {                                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         if (YH == 0) db_acc(AH, AL);                                                                      \
         __builtin_amdgcn_s_setprio(1);                                                                    \
         _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                  \
-            const int pr = i / (TM * TH), x = (i % (TM * TH)) / TH, y = i % TH;                           \
+            HOS_ORDER_DECODE(i);                                                                          \
             if (!HOS_ABLATE_MFMA) {                                                                       \
                 if (pr == 0)      acc[x][(YH) * TH + y] = pmfma(AL[x].v, BH[y].v, acc[x][(YH) * TH + y]); \
                 else if (pr == 1) acc[x][(YH) * TH + y] = pmfma(AH[x].v, BL[y].v, acc[x][(YH) * TH + y]); \
@@ -456,11 +468,19 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
         const bool more1 = kt + 1 < kt_end;
         const int dstage = so ? 1 : 0;
         // K tile v+1 / v+2 of this workgroup's stream: inside this output tile, or the first / second of the next one
-        const bool w1 = kt + 1 >= kt_end, w2 = kt + 2 >= kt_end;
-        const bool dma1 = !w1 || has_next, dma2 = !w2 || has_next;
-        const int kt1 = w1 ? kt + 1 - kt_end : kt + 1, row1 = w1 ? n_row0 : g_row0;
-        const int kt2 = w2 ? kt + 2 - kt_end : kt + 2, row2 = w2 ? n_row0 : g_row0;
-        const bool b_issue = !HOS_ABLATE_DMA && isB && dma1 && !(first_tile && kt == kt_begin);     // (the prologue requested tile 1)
+        // (the one-tile form keeps kt + 1 / kt + 2 as plain induction values: with the selects below in the address arithmetic
+        // of every request the WGRAD launch was 5 % slower, 669 -> 706 us at [1024,1024,131072], same box)
+        bool dma1, dma2; int kt1, row1, kt2, row2;
+        if constexpr (PERSIST) {
+            const bool w1 = kt + 1 >= kt_end, w2 = kt + 2 >= kt_end;
+            dma1 = !w1 || has_next; dma2 = !w2 || has_next;
+            kt1 = w1 ? kt + 1 - kt_end : kt + 1; row1 = w1 ? n_row0 : g_row0;
+            kt2 = w2 ? kt + 2 - kt_end : kt + 2; row2 = w2 ? n_row0 : g_row0;
+        } else {
+            dma1 = kt + 1 < kt_end; dma2 = kt + 2 < kt_end;
+            kt1 = kt + 1; kt2 = kt + 2; row1 = row2 = g_row0;
+        }
+        const bool b_issue = !HOS_ABLATE_DMA && isB && dma1 && (PERSIST ? !(first_tile && kt == kt_begin) : kt > kt_begin);     // (the prologue requested tile 1)
         const bool a_issue = !HOS_ABLATE_DMA && !isB && dma2;
         HOS_STAMP(0);
         auto fill1 = [&](int i) {                // under (A0,B0): B1 = (s0, yh1); B waves: the DMA of tile v+1
@@ -716,6 +736,7 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
 #undef HOS_WSTAMP
 #undef HOS_ASTAMP
 #undef HOS_GROUP
+#undef HOS_ORDER_DECODE
 #undef HOS_STAMP
 #undef HOS_READ_A
 #undef HOS_READ_A1
@@ -764,7 +785,8 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     a.total = a.tiles_m * a.tiles_n * splits;
     if constexpr (!TR && BN == 256 && HOS_GEMMP_PERSIST && (EPI == PEPI_PLANES_FWD || EPI == PEPI_PLANES_DGRAD)) {
         static const int env_persist = getenv("HOS_GEMMP_PERSIST") ? atoi(getenv("HOS_GEMMP_PERSIST")) : 1;
-        const int cus = cu_count();
+        static const int env_grid = getenv("HOS_GEMMP_GRID") ? atoi(getenv("HOS_GEMMP_GRID")) : 0;      // timing experiment: fewer workgroups than CUs
+        const int cus = env_grid > 0 ? env_grid : cu_count();
         const bool legacy_mask = EPI == PEPI_PLANES_DGRAD && a.bits == nullptr && a.mask != nullptr;
         if (env_persist && a.nk >= 2 && a.total > cus && !legacy_mask) return launchp_impl<BN, EPI, EIN, TR, true>(a, cus, stream);
     }
@@ -901,7 +923,9 @@ inline int wgrad_splits(int tiles, int nk, int requested) {
     static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
     int splits = env_splits > 0 ? env_splits : requested;
     if (splits <= 0) {
-        splits = 256 / tiles > 0 ? 256 / tiles : 1;       // never more workgroups than CUs: one over costs a whole second round
+        static const int env_target = getenv("HOS_GEMMP_GRID") ? atoi(getenv("HOS_GEMMP_GRID")) : 0;    // (timing experiment, as in launchp)
+        const int target = env_target > 0 ? env_target : 256;
+        splits = target / tiles > 0 ? target / tiles : 1; // never more workgroups than CUs: one over costs a whole second round
         if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
     }
     if (splits > nk) splits = nk;

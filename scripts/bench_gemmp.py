@@ -9,6 +9,8 @@ dev = torch.device("cuda")
 g = torch.Generator(device="cuda").manual_seed(0)
 X = torch.randn(M, K, device=dev, generator=g); W = torch.randn(N, K, device=dev, generator=g) / K**0.5
 b = torch.randn(N, device=dev, generator=g); dYf = torch.randn(M, N, device=dev, generator=g)
+if os.environ.get("GZERO"):     # DVFS evidence: the same binary on zero-filled operands (no bit toggling in the MFMA / LDS data paths)
+    X.zero_(); W.zero_(); b.zero_(); dYf.zero_()
 X16, Xb = ops.split_planes2(X)
 W16, _ = ops.split_planes(W, dtype=torch.float16)
 _, WTb = ops.split_planes(W, dtype=torch.bfloat16, transposed=True, row_major=False)      # [K][N]
