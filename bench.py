@@ -209,6 +209,29 @@ def _maybe_shard_decoder(net, rank, world):
     if world > 1 and os.environ.get("HOS_SHARD_DECODER", "0") == "1":
         from hosnerf_amd.train import ShardComm
         net.shard_decoder(ShardComm(rank, world, hos=hoscomm(rank, world)))
+    elif world == 1 and model_shard() > 1:
+        net.shard_decoder(_ModelComm(model_shard()))
+
+
+def model_shard() -> int:
+    """HOS_MODEL_SHARD=N on ONE GPU: a TIMING MODEL of rank 0's share of an N-rank step with the sharded volume decoder -- this
+    process computes 1/N of the decoder's first three layers and updates 1/N of their parameters, and the two collectives of the
+    sharded decoder are replaced by identities (so the rendered values are NOT the model's: the line is labelled and never the
+    headline).  What it shows: the per-rank work of the strong-scaling point without the communication."""
+    return int(os.environ.get("HOS_MODEL_SHARD", "0") or 0)
+
+
+class _ModelComm:
+    """rank 0 of `world`, no peers: all_reduce_sum = identity, all_gather = this rank's piece repeated (timing model only)."""
+
+    def __init__(self, world):
+        self.rank, self.world, self.group, self.hos = 0, int(world), None, None
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def all_gather(self, send):
+        return send.contiguous().unsqueeze(0).expand(self.world, *send.shape).contiguous()
 
 
 def _reduce_human(net, opt, static_g=None):
@@ -619,7 +642,7 @@ def roofline_of(table, gemm):
     dom = max(table, key=lambda r: r["total_ms"])
     traffic = None
     # the newest committed PMC pass whose kernel sources are the ones this library was built from
-    for tname in ("r04_pmc_gemmp_traffic.json", "r03_pmc_gemmp_traffic.json"):
+    for tname in ("r05_pmc_gemmp_traffic.json", "r04_pmc_gemmp_traffic.json", "r03_pmc_gemmp_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tpath) or traffic is not None:
             continue
@@ -723,6 +746,19 @@ def _time_steps(step, warm, budget_s, max_n, sync=None):
     return (time.perf_counter() - t0) / n, n
 
 
+def _median_step(step, warm, n):
+    """`warm` untimed steps, then the MEDIAN of `n` individually timed steps (seconds)."""
+    for _ in range(warm):
+        step()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts
+
+
 def cpu_baseline(stage: str, device=None, rays: int = 0):
     """THE BASELINE LEG -- the only place this file touches oracle/: the oracle (torch fp32 restatement of the reference's op
     graph, autograd backward, torch Adam) timed as the reference would run,
@@ -751,10 +787,11 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
     if not on_gpu:
         sweep, cores = {}, 1
         tb = synth.add_patch_supervision(synth.human_batch(64, seed=778, time=0.5, is_train=True, iter_val=3e5), 1, 32, 778)
-        # (all 256 hardware threads of this pool's host were tried once: 0.3 rays/s against 110 at 16 -- torch's intra-op pool
-        # oversubscribes; the sweep stops at 64)
-        # (8 and 64 threads were tried through the round: 89 and 34-40 rays/s against 99-110 at 16 -- the sweep keeps the two contenders)
-        for th in sorted({min(host_threads, c) for c in (16, 32)}):
+        # Thread sweep 8 ... 64 in every run; 128 and ALL hardware threads only with HOS_CPU_SWEEP_ALL=1: at 256 threads torch's
+        # intra-op pool oversubscribes so badly (0.3 rays/s against 110 at 16, measured in round 4) that the one 64-ray step of the
+        # sweep takes minutes, which the default run (a few minutes in total) cannot afford.
+        counts = (8, 16, 32, 64) + ((128, host_threads) if os.environ.get("HOS_CPU_SWEEP_ALL") else ())
+        for th in sorted({min(host_threads, c) for c in counts}):
             torch.set_num_threads(th)
             if stage == "stage1":
                 st = osteps.stage1_step(synth.background_state_dict(777, 2), synth.stage1_batch(64, seed=778), device="cpu")
@@ -776,12 +813,15 @@ def cpu_baseline(stage: str, device=None, rays: int = 0):
         torch.cuda.empty_cache()
         return {"value": rays / dt, "unit": "rays/s", "rays": rays, "steps": n,
                 "what": "the reference's op graph (oracle restatement) as PyTorch-ROCm ops on the same GPU: fp32 rocBLAS, autograd, torch Adam"}
-    dt, n = _time_steps(step, 1, 8.0, 4)
+    dt, ts = _median_step(step, 1, 5)
+    n = len(ts)
     full = {"stage1": 1024, "stage2": 2048, "stage3": GLOBAL_RAYS_S3}[stage]
     return {"value": rays / dt, "unit": "rays/s", "cores": cores, "kind": "port", "workload": stage,
             "cpu_model": cpu_model(), "host_threads": host_threads, "thread_sweep_rays_per_s": sweep,
-            "sample": f"{n} timed step(s) of {rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads = the fastest of "
-                      f"the thread counts tried on a 64-ray item, rays/s per count: {sweep}).  The full {full}-ray item was not run: at "
+            "step_seconds": [round(t, 3) for t in ts],
+            "sample": f"1 warm-up + MEDIAN of {n} timed steps of {rays} rays (same model/losses/optimizer, torch CPU fp32, {cores} threads = the fastest of "
+                      f"the thread counts tried on a 64-ray item, rays/s per count: {sweep}; all {host_threads} hardware threads: 0.3 rays/s, "
+                      f"measured in round 4, re-measured with HOS_CPU_SWEEP_ALL=1).  The full {full}-ray item was not run: at "
                       f"this rate one step of it takes about {dt * full / rays:.0f} s (per-ray cost constant; its per-step work -- volume "
                       f"decoder, Adam over all parameters -- is already inside every timed sample step)"}
 
@@ -882,7 +922,8 @@ def main():
             torch.cuda.synchronize()
     if rank == 0:
         out = {
-            "metric": f"train rays/sec ({args.primary}: forward + losses + backward + gradient all-reduce + Adam)",
+            "metric": f"train rays/sec ({args.primary}: forward + losses + backward + gradient all-reduce + Adam"
+                      + ("; LPIPS term OFF in this line -- stages.stage3_with_lpips carries it" if args.primary == "stage3" else "") + ")",
             "value": prim["value"], "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None,
             "dtype": "f32" if args.gemm == "fp32" else "f32 (fp16/bf16 hi-lo split MFMA x3, fp32 accumulate)",
@@ -895,6 +936,9 @@ def main():
             "step": f"forward + losses + backward + all-reduce + ONE gradient-norm clip (max_norm {GRAD_MAX_NORM}, the Trainer's "
                     "gradient_clip_val of the reference's Backpack.gin) + Adam",
         }
+        if model_shard() > 1:
+            out["metric"] += f" -- ONE-GPU TIMING MODEL of rank 0 of {model_shard()} with the sharded volume decoder, collectives replaced by identities"
+            out["model_shard"] = model_shard()
         if "h2d_bytes_per_step" in prim:       # --h2d: the PCIe-inclusive variant, labelled so that it is never read as the headline
             out["metric"] += " + per-step host-to-device upload of the item"
             out["h2d_bytes_per_step"] = prim["h2d_bytes_per_step"]

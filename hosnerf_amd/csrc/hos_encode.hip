@@ -13,6 +13,12 @@
 // from the reference by up to 2.4e-4, more than the whole parity budget).
 #include "hos_common.h"
 
+#ifndef HOS_ENC_FAST
+#define HOS_ENC_FAST 0
+#endif
+#ifndef HOS_ENC_OWN_SIN
+#define HOS_ENC_OWN_SIN 0
+#endif
 namespace {
 
 constexpr int NDIR = 21;
@@ -22,6 +28,36 @@ constexpr int NEMB = 64;
 constexpr int SB = 64;                  // samples per workgroup
 constexpr float EPS = 1.1920929e-07f;
 constexpr float HALF_PI = 1.57079637050628662109375f;   // float32(0.5*pi)
+
+// sin(x) for the encoder's argument range: 2^l * (contracted mean . unit basis vector) (+ pi/2), |x| <= ~4100.  The library's sinf is
+// branch-free Payne-Hanek on this target (30 v_mad_u64_u32 per loop iteration of the feature loop, 638 instructions for 4 sines +
+// 2 exponentials); here: k = rint(x * 2/pi), three fused Cody-Waite steps with pi/2 = A + B + C (72 bits), the Cephes single-precision
+// kernels on [-pi/4, pi/4].  Checked against double precision over the range (oracle/.. tests/test_encoder_sine_cpu.py restates it):
+// <= 1.56 ulp, 9.3e-8 absolute.  Arguments beyond 2^15 (never produced by the model; a caller's free basis could) take the library path,
+// decided per wave.
+__device__ __forceinline__ float enc_sin(float x) {
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(fabsf(x) > 32768.f) != 0, 0)) return sinf(x);
+    const float kf = __builtin_rintf(x * 0x1.45f306p-1f);
+    float r = __builtin_fmaf(kf, -0x1.921fb6p+0f, x);
+    r = __builtin_fmaf(kf, 0x1.777a5cp-25f, r);
+    r = __builtin_fmaf(kf, 0x1.ee59dap-50f, r);
+    const int k = (int)kf;
+    const float z = r * r;
+    float sp = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611e-1f);
+    sp = __builtin_fmaf(sp * z, r, r);
+    float cp = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827e-2f);
+    cp = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    const float v = (k & 1) ? cp : sp;
+    return (k & 2) ? -v : v;
+}
+// exp(x), x <= 0: 2^(x log2 e) with the rounding error of the product carried into a first-order correction
+__device__ __forceinline__ float enc_exp(float x) {
+    const float t = x * 0x1.715476p+0f;
+    const float e = __builtin_fmaf(x, 0x1.715476p+0f, -t) + x * 0x1.4ae0cp-26f;
+    return __builtin_amdgcn_exp2f(t) * __builtin_fmaf(e, 0.69314718f, 1.0f);
+}
 
 // (hi, lo) split of one value for the interleaved-planes layout of hos_gemmp.hip: fp16 hi saturates at +-65504
 template <typename E> __device__ __forceinline__ float hi_clamp(float x) { return x; }
@@ -149,8 +185,16 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
         const float sc = (float)(1 << lvl);
         const float sm = s_lm[s][j] * sc;
         const float sv = s_lv[s][j] * (sc * sc);
+#if HOS_ENC_FAST   // timing experiment (results NOT to parity): hardware sine / exp2
+        const float damp = __expf(-0.5f * sv);
+        v0 = damp * __sinf(sm); v1 = damp * __sinf(sm + HALF_PI);
+#elif HOS_ENC_OWN_SIN
+        const float damp = HOS_ENC_OWN_SIN == 2 ? enc_exp(-0.5f * sv) : expf(-0.5f * sv);
+        v0 = damp * enc_sin(sm); v1 = damp * enc_sin(sm + HALF_PI);
+#else
         const float damp = expf(-0.5f * sv);
         v0 = damp * sinf(sm); v1 = damp * sinf(sm + HALF_PI);
+#endif
     };
     if constexpr (!PLANES) {
         for (int it = t; it < SB * HALF; it += 256) {

@@ -40,9 +40,6 @@
 #ifndef HOS_ABLATE_DMA
 #define HOS_ABLATE_DMA 0
 #endif
-#ifndef HOS_MFMA_ORDER
-#define HOS_MFMA_ORDER 0
-#endif
 // Round 5: FWD / DGRAD launches of the 256-wide tile are PERSISTENT -- one workgroup per CU walks the output tiles and the K
 // pipeline (LDS-DMA two tiles ahead) runs straight across tile boundaries, so a tile has no prologue: its first two K tiles
 // are requested while the previous tile still multiplies, and its epilogue's stores drain under the next tile's K loop.
@@ -386,15 +383,9 @@ __global__ __launch_bounds__(PNT, 2) void gemmp_kernel(const PArgs a) {
     // while the matrix pipe is busy.  Eight back-to-back global_load_lds stalled a wave for 600-1900 cycles
     // (the CU's vector-memory path takes ~16 cycles per request and all eight waves queue up at once).
     constexpr int NM = 3 * TM * TH;
-    // order of the NM MFMAs of a quarter (timing experiment HOS_MFMA_ORDER; 0 = product-major, the three products of one
-    // accumulator four MFMAs apart; 1 = A fragment stationary: hi.lo, hi.hi, lo.hi per row block; 2 = B fragment stationary)
-#if HOS_MFMA_ORDER == 1
-#define HOS_ORDER_DECODE(i) const int x = (i) / (3 * TH), pj_ = ((i) % (3 * TH)) / TH, pr = pj_ == 0 ? 1 : (pj_ == 1 ? 2 : 0), y = (i) % TH
-#elif HOS_MFMA_ORDER == 2
-#define HOS_ORDER_DECODE(i) const int y = (i) / (3 * TM), pj_ = ((i) % (3 * TM)) / TM, pr = pj_ == 0 ? 2 : (pj_ == 1 ? 0 : 1), x = (i) % TM
-#else
+    // (Round 5, measured and dropped -- profiles/r05_gemmp_order_ablation.txt: an A-fragment-stationary and a B-fragment-stationary
+    // order of the NM MFMAs changed nothing, 752 / 745 / 683-687 us against 753 / 742 / 683 for fwd / dgrad / wgrad.)
 #define HOS_ORDER_DECODE(i) const int pr = (i) / (TM * TH), x = ((i) % (TM * TH)) / TH, y = (i) % TH
-#endif
 #define HOS_GROUP(AH, AL, BH, BL, YH, FILL)                                                               \
     do {                                                                                                  \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                \
@@ -785,8 +776,7 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     a.total = a.tiles_m * a.tiles_n * splits;
     if constexpr (!TR && BN == 256 && HOS_GEMMP_PERSIST && (EPI == PEPI_PLANES_FWD || EPI == PEPI_PLANES_DGRAD)) {
         static const int env_persist = getenv("HOS_GEMMP_PERSIST") ? atoi(getenv("HOS_GEMMP_PERSIST")) : 1;
-        static const int env_grid = getenv("HOS_GEMMP_GRID") ? atoi(getenv("HOS_GEMMP_GRID")) : 0;      // timing experiment: fewer workgroups than CUs
-        const int cus = env_grid > 0 ? env_grid : cu_count();
+        const int cus = cu_count();
         const bool legacy_mask = EPI == PEPI_PLANES_DGRAD && a.bits == nullptr && a.mask != nullptr;
         if (env_persist && a.nk >= 2 && a.total > cus && !legacy_mask) return launchp_impl<BN, EPI, EIN, TR, true>(a, cus, stream);
     }
@@ -923,9 +913,7 @@ inline int wgrad_splits(int tiles, int nk, int requested) {
     static const int env_splits = getenv("HOS_WGRAD_SPLITS") ? atoi(getenv("HOS_WGRAD_SPLITS")) : 0;
     int splits = env_splits > 0 ? env_splits : requested;
     if (splits <= 0) {
-        static const int env_target = getenv("HOS_GEMMP_GRID") ? atoi(getenv("HOS_GEMMP_GRID")) : 0;    // (timing experiment, as in launchp)
-        const int target = env_target > 0 ? env_target : 256;
-        splits = target / tiles > 0 ? target / tiles : 1; // never more workgroups than CUs: one over costs a whole second round
+        splits = 256 / tiles > 0 ? 256 / tiles : 1;       // never more workgroups than CUs: one over costs a whole second round
         if (splits > nk / 8) splits = nk / 8 > 0 ? nk / 8 : 1;
     }
     if (splits > nk) splits = nk;

@@ -40,6 +40,10 @@ run("(warm-up line)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, Yb
 run("fwd(2fmt)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb))
 run("fwd(2fmt,nobits)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, Yb))
 run("fwd(f16)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, Yn, None))
+# round 5: the NeRF MLP's one-format layer (bf16 planes in, bf16 planes + ReLU bits out)
+Wb, _ = ops.split_planes(W, dtype=torch.bfloat16)
+Ybb = ops.Planes.empty(M, N, torch.bfloat16, dev, relu_bits=True)
+run("fwd(bf16)", lambda: ops.linearp_fwd(Xb, K, Wb, b, M, N, True, None, Ybb))
 run("fwd(f32out)", lambda: ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU))
 def relu_bits(Xf):
     """The ReLU bit mask of include/hosrender.h (hos_linearp_fwd, relu_bits) built with torch ops: int32 [M/32, K/64, 64]."""
@@ -74,6 +78,8 @@ ops.linearp_fwd(X16, K, W16, b, M, N, True, Y, Yb)
 ref = torch.relu(X[:512].double() @ W.double().T + b.double())
 print("fwd err fp16 planes", (Y.float()[:512].double() - ref).abs().max().item(), "bf16 planes", (Yb.float()[:512].double() - ref).abs().max().item())
 ops.linearp_fwd(X16, K, W16, b, M, N, True, None, None, C=C, epilogue=ops.EPI_RELU)
+ops.linearp_fwd(Xb, K, Wb, b, M, N, True, None, Ybb)
+print("fwd err bf16 one-format layer", (Ybb.float()[:512].double() - ref).abs().max().item())
 print("fwd err fp32 out", (C[:512].double() - ref).abs().max().item())
 ops.linearp_dgrad(dZ, WTb, N, M, K, mask=X16, dX=dX)
 dX1 = dX.float().clone()
