@@ -13,12 +13,6 @@
 // from the reference by up to 2.4e-4, more than the whole parity budget).
 #include "hos_common.h"
 
-#ifndef HOS_ENC_FAST
-#define HOS_ENC_FAST 0
-#endif
-#ifndef HOS_ENC_OWN_SIN
-#define HOS_ENC_OWN_SIN 0
-#endif
 namespace {
 
 constexpr int NDIR = 21;
@@ -34,9 +28,8 @@ constexpr float HALF_PI = 1.57079637050628662109375f;   // float32(0.5*pi)
 // 2 exponentials); here: k = rint(x * 2/pi), three fused Cody-Waite steps with pi/2 = A + B + C (72 bits), the Cephes single-precision
 // kernels on [-pi/4, pi/4].  Checked against double precision over the range (oracle/.. tests/test_encoder_sine_cpu.py restates it):
 // <= 1.56 ulp, 9.3e-8 absolute.  Arguments beyond 2^15 (never produced by the model; a caller's free basis could) take the library path,
-// decided per wave.
+// decided once per workgroup from the lifted means (a test per sine cost as much as the library's reduction saved).
 __device__ __forceinline__ float enc_sin(float x) {
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(fabsf(x) > 32768.f) != 0, 0)) return sinf(x);
     const float kf = __builtin_rintf(x * 0x1.45f306p-1f);
     float r = __builtin_fmaf(kf, -0x1.921fb6p+0f, x);
     r = __builtin_fmaf(kf, 0x1.777a5cp-25f, r);
@@ -96,11 +89,13 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
     __shared__ float s_lv[SB][NDIR];
     __shared__ float s_basis[3][NDIR];
     __shared__ float s_embed[NEMB];
+    __shared__ int s_big;              // some |2^11 * lifted mean| of this block is beyond enc_sin's range: library sinf for the block
 
     const int t = threadIdx.x;
     const long P = (long)B * S;
     const long p0 = (long)blockIdx.x * SB;
     if (t < 3 * NDIR) s_basis[t / NDIR][t % NDIR] = basis[t];
+    if (t == 255) s_big = 0;
     if (t >= 64 && t < 64 + NEMB) s_embed[t - 64] = embed[t - 64];
 
     if (t < SB && p0 + t < P) {
@@ -170,7 +165,9 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
     for (int it = t; it < SB * NDIR; it += 256) {
         const int s = it / NDIR, j = it % NDIR;
         const float b0 = s_basis[0][j], b1 = s_basis[1][j], b2 = s_basis[2][j];
-        s_lm[s][j] = s_mean[s][0] * b0 + s_mean[s][1] * b1 + s_mean[s][2] * b2;
+        const float lm = s_mean[s][0] * b0 + s_mean[s][1] * b1 + s_mean[s][2] * b2;
+        s_lm[s][j] = lm;
+        if (!(fabsf(lm) * 2048.f < 32000.f)) s_big = 1;        // (also NaN; same value from every writer)
         const float* c = s_cov[s];
         const float c0 = c[0] * b0 + c[1] * b1 + c[2] * b2;
         const float c1 = c[3] * b0 + c[4] * b1 + c[5] * b2;
@@ -180,21 +177,15 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
     __syncthreads();
     // IPE features (H:78-89, H:104-105): col = level*21 + dir ; second half = +pi/2
     constexpr int HALF = NDIR * NLVL;   // 252
+    const bool big = __builtin_amdgcn_readfirstlane(s_big) != 0;        // block-uniform, in a scalar register
     auto feat = [&](int s, int c, float& v0, float& v1) {
         const int lvl = c / NDIR, j = c % NDIR;
         const float sc = (float)(1 << lvl);
         const float sm = s_lm[s][j] * sc;
         const float sv = s_lv[s][j] * (sc * sc);
-#if HOS_ENC_FAST   // timing experiment (results NOT to parity): hardware sine / exp2
-        const float damp = __expf(-0.5f * sv);
-        v0 = damp * __sinf(sm); v1 = damp * __sinf(sm + HALF_PI);
-#elif HOS_ENC_OWN_SIN
-        const float damp = HOS_ENC_OWN_SIN == 2 ? enc_exp(-0.5f * sv) : expf(-0.5f * sv);
-        v0 = damp * enc_sin(sm); v1 = damp * enc_sin(sm + HALF_PI);
-#else
-        const float damp = expf(-0.5f * sv);
-        v0 = damp * sinf(sm); v1 = damp * sinf(sm + HALF_PI);
-#endif
+        const float damp = enc_exp(-0.5f * sv);
+        if (big) { v0 = damp * sinf(sm); v1 = damp * sinf(sm + HALF_PI); }
+        else     { v0 = damp * enc_sin(sm); v1 = damp * enc_sin(sm + HALF_PI); }
     };
     if constexpr (!PLANES) {
         for (int it = t; it < SB * HALF; it += 256) {
@@ -207,16 +198,37 @@ __global__ __launch_bounds__(256) void encode_ipe_kernel(
             row[c + HALF] = v1;
         }
     } else {
-        // a thread owns two adjacent columns (c even; c and c + 252 are both even and pairs never straddle a 32-column block)
-        for (int it = t; it < SB * (HALF / 2); it += 256) {
-            const int s = it / (HALF / 2), c = (it % (HALF / 2)) * 2;
-            if (p0 + s >= P) break;
-            float a0, a1, b0, b1;
-            feat(s, c, a0, a1);
-            feat(s, c + 1, b0, b1);
-            const size_t o0 = plane_off(p0 + s, c, ldx), o1 = plane_off(p0 + s, c + HALF, ldx);
-            if (p16 != nullptr) { split_store2<_Float16>(p16, o0, a0, b0); split_store2<_Float16>(p16, o1, a1, b1); }
-            if (pb != nullptr) { split_store2<__bf16>(pb, o0, a0, b0); split_store2<__bf16>(pb, o1, a1, b1); }
+        // A thread owns two adjacent columns (c even; c and c + 252 are both even and pairs never straddle a 32-column block) of
+        // every second sample of the block: 252 of the 256 threads = 126 column pairs x 2 sample parities.  (level, direction) of
+        // its columns, their scales and their offsets inside a plane row are then loop invariants -- the per-item form
+        // (it -> sample, column by division) spent ~100 of its ~256 instructions per item on index arithmetic, and the kernel is
+        // bound by VALU issue.  Round 5, same box, per 262 144 / 131 072 / 4 194 304 samples, one plane format
+        // (profiles/r05_encoder_variants.txt): per-item loop + library sinf / expf 226 / 114 / 3025 us; this loop + library 189 / 89 /
+        // 2533; + enc_sin 181 / 81 / 2379; + enc_exp 169 / 76 / 2284 (kept); hardware v_sin / v_exp (NOT to parity) 149 / 58 / 2214.
+        if (t < 2 * (HALF / 2)) {
+            const int q = t % (HALF / 2), sub = t / (HALF / 2);
+            const int c = 2 * q;
+            const int j0 = c % NDIR, j1 = (c + 1) % NDIR;
+            const float sc0 = (float)(1 << (c / NDIR)), sc1 = (float)(1 << ((c + 1) / NDIR));
+            const float sq0 = sc0 * sc0, sq1 = sc1 * sc1;
+            const int co0 = (c >> 5) * 64 + (c & 31), co1 = ((c + HALF) >> 5) * 64 + ((c + HALF) & 31);
+            const size_t pitch = (size_t)2 * ldx;
+            const int n_s = (int)((P - p0) < (long)SB ? (P - p0) : (long)SB);
+            auto one = [&](float lm, float lv, float sc, float sq, float& v0, float& v1) {      // == feat()
+                const float sm = lm * sc;
+                const float sv = lv * sq;
+                const float damp = enc_exp(-0.5f * sv);
+                if (big) { v0 = damp * sinf(sm); v1 = damp * sinf(sm + HALF_PI); }
+                else     { v0 = damp * enc_sin(sm); v1 = damp * enc_sin(sm + HALF_PI); }
+            };
+            size_t row = (size_t)(p0 + sub) * pitch;
+            for (int s = sub; s < n_s; s += 2, row += 2 * pitch) {
+                float a0, a1, b0, b1;
+                one(s_lm[s][j0], s_lv[s][j0], sc0, sq0, a0, a1);
+                one(s_lm[s][j1], s_lv[s][j1], sc1, sq1, b0, b1);
+                if (p16 != nullptr) { split_store2<_Float16>(p16, row + co0, a0, b0); split_store2<_Float16>(p16, row + co1, a1, b1); }
+                if (pb != nullptr) { split_store2<__bf16>(pb, row + co0, a0, b0); split_store2<__bf16>(pb, row + co1, a1, b1); }
+            }
         }
     }
     const int tail = ldx - NIPE;   // embedding + zero pad (even: ldx % 32 == 0, NIPE = 504)
