@@ -267,3 +267,60 @@ def test_lpips_entry_points_validate_without_gpu():
     assert lib.hos_lpips_finish(0, 2, 0, 0) == -1
     assert sum(1 for v in VGG16_CFG if v != "M") == 13 and TAP_AFTER_CONV == (1, 3, 6, 9, 12)
     assert not LPIPS().ready()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_decoder_spans_partition_the_layers(world):
+    """`Network.shard_decoder` (round 5) on the host: over the ranks the owned rows of every sharded layer are disjoint,
+    contiguous and cover the layer; a rank's active spans + its inactive spans are the whole flat buffer; the rows a rank does not
+    own are exactly what it marks inactive; sharding twice raises.  No kernel runs: this is the bookkeeping the optimiser spans,
+    the gradient-norm completion and `gather_decoder_shards` rely on."""
+    from hosnerf_amd.human_nerf import Network, default_cfg
+
+    class Comm:                     # what shard_decoder reads of a train.ShardComm
+        def __init__(self, rank):
+            self.rank, self.world = rank, world
+
+    owned, layers = [], None
+    for rank in range(world):
+        net = Network(default_cfg(_basedir()))
+        before = list(net.store.inactive)
+        net.shard_decoder(Comm(rank))
+        spans = net.decoder_shard_spans()
+        assert len(spans) == 3                                                 # the first three transposed convolutions
+        rows = [net._shard_rows(n) for n in range(3)]                          # (offset, floats per input-channel row, Cin)
+        layers = layers or rows
+        assert rows == layers
+        for (off, n), (loff, row, cin) in zip(spans, rows):
+            cs = cin // world
+            assert n == cs * row and off == loff + rank * cs * row            # a contiguous range of input-channel rows
+        owned.append(spans)
+        # active + inactive = the whole buffer, no overlap
+        act = net.store.active_spans()
+        ina = sorted(net.store.inactive)
+        covered = sorted(act + ina)
+        pos = 0
+        for off, n in covered:
+            assert off >= pos
+            pos = max(pos, off + n)
+        assert pos == net.store.size and sum(n for _, n in act) + sum(n for _, n in _merge(ina)) == net.store.size
+        # the new inactive spans are the other ranks' rows of the three layers
+        new = sum(n for _, n in _merge(sorted(set(ina) - set(before))))
+        assert new == sum(row * cin for _, row, cin in rows) - sum(n for _, n in spans)
+        with pytest.raises(RuntimeError):
+            net.shard_decoder(Comm(rank))
+    for k, (loff, row, cin) in enumerate(layers):                             # over the ranks: disjoint cover of each layer
+        pieces = sorted(owned[r][k] for r in range(world))
+        assert pieces[0][0] == loff and pieces[-1][0] + pieces[-1][1] == loff + row * cin
+        for (o0, n0), (o1, _) in zip(pieces, pieces[1:]):
+            assert o0 + n0 == o1
+
+
+def _merge(spans):
+    out = []
+    for off, n in sorted(spans):
+        if out and off <= out[-1][0] + out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], off + n - out[-1][0]))
+        else:
+            out.append((off, n))
+    return out
