@@ -949,6 +949,11 @@ def main():
                    "two branches concurrently on two streams); the rocprofv3 --kernel-trace --stats summary of the replayed graph "
                    "is under profiles/")
             roof["measured"] = "eager post-pass"
+            if args.gemm == "planes":
+                roof["note"] = ("peak = 2.5 PF dense 16-bit MFMA / 3 products at the 2.4 GHz nominal clock; the same binary on zero-filled operands "
+                                "reaches 0.62-0.66 of it, and by counter the launch takes the same ~1.2 M cycles per XCD at 1.5-1.8 GHz on random data "
+                                "against 2.1-2.3 GHz on zeros (profiles/r05_pmc_gemmp_clock.json, DESIGN 3.1): the kernel is held by the "
+                                "power-limited clock, not by its schedule")
             out["roofline"] = roof
             out["kernels"] = table[:16]
             out["kernels_source"] = src
