@@ -282,9 +282,11 @@ def test_sharded_decoder_spans_partition_the_layers(world):
             self.rank, self.world = rank, world
 
     owned, layers = [], None
+    net = Network(default_cfg(_basedir()))
+    before = list(net.store.inactive)
     for rank in range(world):
-        net = Network(default_cfg(_basedir()))
-        before = list(net.store.inactive)
+        net.store.inactive[:] = before                     # (one module, re-sharded as every rank in turn: construction is the slow part)
+        net.decoder_shard, net._shard_layers = None, ()
         net.shard_decoder(Comm(rank))
         spans = net.decoder_shard_spans()
         assert len(spans) == 3                                                 # the first three transposed convolutions
