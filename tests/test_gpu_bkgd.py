@@ -232,6 +232,33 @@ def test_encode_ipe(dev, hv):
     assert torch.all(Xv[:, :256] == -7.0) and float(Xv[:, 283:].abs().max()) == 0
 
 
+def test_encode_ipe_beyond_the_own_sine_range(dev, hv):
+    """Round 5: the encoder's own sine covers |2^l x lifted mean| <= 2^15 (the model: <= 4100); a workgroup whose lifted means leave that
+    range takes the library's sinf for all its samples.  A caller's free basis can get there: the same rays with the basis scaled by 40
+    (|2^11 x mean . b| up to ~1.6e5) against the oracle on the same scaled basis, tolerance scaled with the argument (an fp32 rounding
+    of the lifted mean is amplified by 2^l x 40), finite everywhere, embedding columns untouched -- and the in-range basis still takes
+    the fast path bit for bit next to it (two launches, same inputs, same outputs)."""
+    from hosnerf_amd import ops
+    tdist, o, d, radii = (T(hv[k], dev) for k in ("cast_tdist", "cast_o", "cast_d", "cast_radii"))
+    embed = torch.arange(64, dtype=torch.float32, device=dev)
+    B, S = tdist.shape[0], tdist.shape[1] - 1
+    scale = 40.0
+    basis = T(hv["basis"]) * scale
+    X = ops.encode_ipe(tdist, o, d, radii, basis.to(dev), embed, 576).view(B, S, 576)
+    assert torch.isfinite(X).all()
+    want = ob.encode_samples(T(hv["cast_means"]), T(hv["cast_covs"]), basis)
+    for half in (0, 252):
+        for lvl in range(12):
+            sl = slice(half + lvl * 21, half + (lvl + 1) * 21)
+            tol = 2e-6 + (2.0 ** lvl) * 1.5e-6 * scale
+            assert maxerr(X[..., sl], want[..., sl]) < tol, lvl
+    assert float(maxerr(X[..., :63], want[..., :63])) < 4e-4                     # levels 0-2: tight enough to tell a wrong quadrant (errors of order 1)
+    assert torch.equal(X[..., 504:568].cpu(), embed.cpu().expand(B, S, 64))
+    a = ops.encode_ipe(tdist, o, d, radii, T(hv["basis"], dev), embed, 576)
+    b = ops.encode_ipe(tdist, o, d, radii, T(hv["basis"], dev), embed, 576)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("tag,opq", [("opq", True), ("nopq", False)])
 def test_alpha_weights_volrender(dev, hv, tag, opq):
     from hosnerf_amd import ops
