@@ -498,7 +498,12 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
     in_graph_comm = world > 1 and hoscomm(rank, world) is not None
     full_graph = world == 1 or in_graph_comm
     second_half = None
-    if not args.no_graph:
+    # a decoder sharded over torch.distributed has its per-layer collectives INSIDE the forward: nothing to capture (HOS_HOSCOMM=1 moves
+    # them onto the stream and the whole step into one graph)
+    shard_eager = world > 1 and os.environ.get("HOS_SHARD_DECODER", "0") == "1" and not in_graph_comm
+    if shard_eager:
+        launch = "eager (volume decoder sharded over torch.distributed: its collectives sit inside the forward; HOS_HOSCOMM=1 captures them)"
+    if not args.no_graph and not shard_eager:
         # N > 1: first the overlapped second half (async collectives), then the sequential one, then eager launches
         want_overlap = (not full_graph) and wl.overlap and os.environ.get("HOS_BENCH_OVERLAP", "1") == "1"
         for try_overlap in ([True, False] if want_overlap else [False]):
@@ -570,6 +575,7 @@ def run_workload(wl, args, dev, rank, world, dist, want_events):
                       + ("retrying without the overlapped exchange" if try_overlap else "running eagerly"), file=sys.stderr)
                 graph, launch = None, "eager"
                 torch.cuda.synchronize()
+                ops.clear_last_error()          # the invalidated capture's sticky error must not be reported by the next (eager) launch
     h2d, h2d_bytes = None, 0
     if getattr(args, "h2d", False):
         # the item as a data loader hands it over: pinned host tensors, copied into the (static) device batch every step

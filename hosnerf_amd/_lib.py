@@ -140,6 +140,7 @@ PROTOTYPES = {
     "hos_volume_pair_bwd": [_P, _P, _I, _I, _L, _P, _P],
     "hos_copy_or_zero_n": [_I, _P, _P, _P, _P],
     "hos_debug_stamp": [_P, _I, _P],
+    "hos_clear_last_error": [],
     "hos_add_n": [_I, _P, _L, _P, _P],
     "hos_any_abs_below": [_P, _L, _F, _P, _P],
     "hos_state_embed_grad": [_P, _P, _I, _I, _I, _I, _P, _P, _P],

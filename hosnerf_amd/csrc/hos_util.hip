@@ -133,6 +133,8 @@ extern "C" int hos_state_embed_grad(const float* db, const float* W, int ldw, in
 namespace {
 __global__ void debug_stamp_kernel(long long* __restrict__ buf, int slot) { buf[slot] = (long long)wall_clock64(); }
 }
+extern "C" int hos_clear_last_error(void) { return static_cast<int>(hipGetLastError()); }
+
 extern "C" int hos_debug_stamp(long long* buf, int slot, hos_stream_t stream) {
     if (!buf || slot < 0) return HOS_E_ARG;
     hipLaunchKernelGGL(debug_stamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), buf, slot);

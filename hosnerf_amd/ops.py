@@ -147,6 +147,12 @@ def _table(ptrs, ctype=None):
     return (ctype * len(ptrs))(*ptrs)
 
 
+def clear_last_error() -> int:
+    """Return and clear the runtime's sticky last-error code (hos_clear_last_error): call once after recovering from a failed hipGraph
+    capture, before launching eagerly -- otherwise the next launch of this library reports the capture's error as its own."""
+    return int(_lib.load().hos_clear_last_error())
+
+
 def copy_or_zero_n(dsts, srcs=None):
     """dsts[i][...] = srcs[i] (None: zeros) for up to 8 contiguous fp32 tensors per launch (hos_copy_or_zero_n): fills of
     accumulation targets, stacks of small per-frame tensors -- one launch per group instead of one torch launch per tensor."""

@@ -649,6 +649,11 @@ int hos_copy_or_zero_n(int n, float* const* dst, const float* const* src, const 
 /* Diagnostics: buf[slot] = the constant 100 MHz device counter (s_memrealtime) when this point of the stream is reached; a kernel
  * node, so it can be captured inside a step's graph (scripts/diag_overlap.py: the un-profiled timeline of the two-stream step). */
 int hos_debug_stamp(long long* buf, int slot, hos_stream_t stream);
+/* Returns AND CLEARS the runtime's sticky last-error code (0 = none).  Every entry point reports a launch through hipGetLastError(), so
+ * an error left behind by somebody else's failed call on this thread -- a hipGraph capture that was invalidated by an operation that
+ * cannot be captured (a torch.distributed collective, an allocation) -- would be reported by the NEXT launch of this library although
+ * that launch succeeded.  A caller that recovers from a failed capture calls this once before it goes on eagerly.  (plumbing) */
+int hos_clear_last_error(void);
 /* out[i] = sum_k src[k][i], n <= 8: the gradient of a tensor that feeds several consumers in one pass. */
 int hos_add_n(int n, const float* const* src, long long count, float* out, hos_stream_t stream);
 /* flag[0] = any |x[i]| < thr (M:1526, the tiny-direction test of the stage-3 re-projection, kept on the device). */
