@@ -198,13 +198,19 @@ def run(args, gin):
 
     if not torch.cuda.is_available():
         raise SystemExit("run.py needs an MI355X for training / rendering (there is no CPU renderer); use --cpu for the plumbing check")
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # HOS_BENCH_ONE_GPU=1 (testing only, as in bench.py): all ranks share cuda:0 and exchange through gloo, so that the multi-rank
+    # launcher path -- shards of rays / frames, gradient exchange, sharded decoder, checkpoint of rank 0 -- runs on a one-GPU box
+    one_gpu = os.environ.get("HOS_BENCH_ONE_GPU") == "1"
+    local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     lit = lit.to(dev)
     if world > 1 and bool(kw.get("shard_decoder", False)) and hasattr(lit, "human"):
         # `run.shard_decoder = True` (this build's addition; the reference replicates the module under DDP): the volume decoder's
@@ -278,6 +284,9 @@ def run(args, gin):
         if rank == 0 and bool(kw.get("save_last", True)):
             save_last(max_steps)
             print(f"[run] wrote {ckpt}")
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()              # the other ranks' evaluation reads the checkpoint rank 0 has just written
     result = {"exp_name": exp_name, "checkpoint": ckpt}
     run_eval, run_render = bool(kw.get("run_eval", False)), bool(kw.get("run_render", False))
     if run_eval or run_render:
