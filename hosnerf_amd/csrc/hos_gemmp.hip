@@ -40,12 +40,16 @@
 #ifndef HOS_ABLATE_DMA
 #define HOS_ABLATE_DMA 0
 #endif
-// Round 5: FWD / DGRAD launches of the 256-wide tile are PERSISTENT -- one workgroup per CU walks the output tiles and the K
-// pipeline (LDS-DMA two tiles ahead) runs straight across tile boundaries, so a tile has no prologue: its first two K tiles
-// are requested while the previous tile still multiplies, and its epilogue's stores drain under the next tile's K loop.
-// 0 = one workgroup per output tile (the round 1-4 launch), kept for same-box A/B.
+// Round 5, built, measured and compiled OUT by default (-DHOS_GEMMP_PERSIST=1 builds it in; scripts/build_variant.sh): PERSISTENT FWD /
+// DGRAD launches of the 256-wide tile -- one workgroup per CU walks the output tiles and the K pipeline (LDS-DMA two tiles ahead) runs
+// straight across tile boundaries, so a tile has no prologue: its first two K tiles are requested while the previous tile still
+// multiplies, and its epilogue's stores drain under the next tile's K loop.  Isolated launch at [131072,1024,1024]: 0-2 % (706 -> 691 us
+// forward, dgrad equal).  In the steps it LOSES: two-stream stage 3 31.93 vs 31.29 ms, one stream 33.03 vs 32.97, stage 1 6.42 vs 6.39,
+// the 1080p frame 3958 vs 3936-3951 ms (three / two alternations on one box, profiles/r05_persist_step_ab.txt) -- one workgroup per tile
+// lets the other stream's kernels take CUs tile by tile and lets the dispatcher balance the tail, a persistent launch holds its CUs
+// from its first tile to its last.
 #ifndef HOS_GEMMP_PERSIST
-#define HOS_GEMMP_PERSIST 1
+#define HOS_GEMMP_PERSIST 0
 #endif
 
 namespace {
@@ -775,7 +779,7 @@ int launchp(PArgs& a, int splits, hipStream_t stream) {
     }
     a.total = a.tiles_m * a.tiles_n * splits;
     if constexpr (!TR && BN == 256 && HOS_GEMMP_PERSIST && (EPI == PEPI_PLANES_FWD || EPI == PEPI_PLANES_DGRAD)) {
-        static const int env_persist = getenv("HOS_GEMMP_PERSIST") ? atoi(getenv("HOS_GEMMP_PERSIST")) : 1;
+        static const int env_persist = getenv("HOS_GEMMP_PERSIST") ? atoi(getenv("HOS_GEMMP_PERSIST")) : 1;      // (only in a -DHOS_GEMMP_PERSIST=1 build)
         const int cus = cu_count();
         const bool legacy_mask = EPI == PEPI_PLANES_DGRAD && a.bits == nullptr && a.mask != nullptr;
         if (env_persist && a.nk >= 2 && a.total > cus && !legacy_mask) return launchp_impl<BN, EPI, EIN, TR, true>(a, cus, stream);
