@@ -13,10 +13,13 @@
 #include "hos_common.h"
 
 #include <cstdlib>
-// workgroups of the persistent backward kernels (they keep per-block partial sums in LDS and flush them once)
+// workgroups of the persistent backward kernels (they keep per-block partial sums in LDS and flush them once).  768 = three 256-thread
+// workgroups per CU: these kernels are gather-bound (26 x 8 taps per point out of L2) and one wave per SIMD hides little of that
+// latency.  Round 5, step level, three alternations on one box (profiles/r05_persist_grid_sweep.txt): stage 2 8.13-8.18 ms at 256,
+// 8.02-8.05 at 384, 7.99-8.03 at 512, 7.99-8.00 at 768; stage 3 31.33-31.36 -> 31.29-31.31; 512-ray step equal.
 static inline long persist_grid() {
-    static const long g = getenv("HOS_PERSIST_GRID") ? atol(getenv("HOS_PERSIST_GRID")) : 256;
-    return g > 0 ? g : 256;
+    static const long g = getenv("HOS_PERSIST_GRID") ? atol(getenv("HOS_PERSIST_GRID")) : 768;
+    return g > 0 ? g : 768;
 }
 
 namespace {
