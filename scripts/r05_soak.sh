@@ -8,4 +8,4 @@ done | tee $O/soak.txt
 timeout 900 python scripts/soak_graph.py 3 1500 2048 2>&1 | tail -2 | tee -a $O/soak.txt
 timeout 900 python scripts/soak_poison.py 2 300 2>&1 | tail -2 | tee -a $O/soak.txt
 timeout 900 python scripts/soak_poison.py 3 200 2>&1 | tail -2 | tee -a $O/soak.txt
-HOS_POISON=1 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -3 | tee -a $O/soak.txt
+HOS_POISON=1 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed" | tail -2 | sed "s/^/HOS_POISON=1 pytest -m gpu: /" | tee -a $O/soak.txt
