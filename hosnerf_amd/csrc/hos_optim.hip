@@ -102,11 +102,16 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
                                                          const unsigned int* __restrict__ guard, unsigned int* __restrict__ skipped) {
     // fp16 range guard: a hidden activation of this step's forward left the exact hi/lo range (the forward epilogues OR the word):
     // THIS step must not reach the parameters -- and only this one (round 5; the word used to stay set until a host poll, so a loop
-    // that never polled lost every later step).  Every workgroup reads the word when it starts; the LAST one to finish (ticket
-    // counter skipped[1], self-resetting, so a replayed graph behaves the same) counts the skip in skipped[0] and clears the word:
-    // by then every workgroup has read it, and the next step's forward epilogues are behind this launch in stream order.
-    const bool skip = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    if (skip) {
+    // that never polled lost every later step).  The decision is BLOCK-UNIFORM (round 6): thread 0 alone reads the word and
+    // hands it to the workgroup through LDS behind a barrier; only then does it take its ticket.  The LAST ticket holder (counter
+    // skipped[1], self-resetting, so a replayed graph behaves the same) counts the skip in skipped[0] and clears the word: by then
+    // thread 0 of every workgroup has read it -- no wave of any workgroup reads the word itself, so none can see the cleared value
+    // and run Adam (or reach the clip barrier below without its wave 0) -- and the next step's forward epilogues are behind this
+    // launch in stream order.  `skipped == nullptr`: the word is left set (an earlier launch of a step that issues several).
+    __shared__ unsigned int guard_word;
+    if (threadIdx.x == 0) guard_word = guard != nullptr ? __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    __syncthreads();
+    if (guard_word != 0u) {
         if (threadIdx.x == 0 && skipped != nullptr) {
             const unsigned ticket = atomicAdd(skipped + 1, 1u);
             if (ticket == gridDim.x - 1) {

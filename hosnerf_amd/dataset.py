@@ -196,7 +196,21 @@ class SceneItems:
         E_new, newsmpl_to_smpl = smpl_frame_camera(E_k, m["Rh"], m["Th"])
         return self._frame_item(idx, K, E_new, E_colmap, S_k @ newsmpl_to_smpl, bgcolor, True)
 
-    def _item_stage2(self, idx: int, name: str, time: float, flow_on: bool, bg, img, H: int, W: int, K, E) -> Dict:
+    def eval_frame_stage2(self, idx: int, bgcolor=(255.0, 255.0, 255.0)) -> Dict:
+        """Stage 2's full-frame evaluation item (the 'image' ray-shoot mode of the stage-2 dataset, T2:437-455 / :585-586, which its
+        `progress` / `test_metrics` loops render): EVERY ray that hits the subject's box, the frame composited over `bgcolor`,
+        `target_rgbs` = the composited pixels of those rays, no flow supervision (`is_train=False`)."""
+        if self.stage != 2:
+            raise ValueError("eval_frame_stage2 is a stage-2 item (stage 3: eval_frame)")
+        name = self.frames[idx]
+        img = self.images[idx].to(self.device)
+        K, E, _ = self._camera(name)
+        item = self._item_stage2(idx, name, float(self.times[idx]), False, np.asarray(bgcolor, dtype="float32"), img,
+                                 int(img.shape[0]), int(img.shape[1]), K, E, full_frame=True)
+        item.update(is_train=False, iter_val=torch.full((1,), 1e7))
+        return item
+
+    def _item_stage2(self, idx: int, name: str, time: float, flow_on: bool, bg, img, H: int, W: int, K, E, full_frame: bool = False) -> Dict:
         """T2:460-658 with the per-pixel work on the device: composite, rays, box test, patch gather."""
         dev = self.device
         alpha = self.alphas[idx].to(dev)
@@ -209,13 +223,16 @@ class SceneItems:
                 "near": near[:, None], "far": far[:, None], "ray_img": img.reshape(-1, 3)[rm]}
         if flow_on:
             item["ray_grid"] = pixel_flow_grid(self.flows[idx].to(dev))[rm]
-        item = rays_mod.sample_patch_rays(item, img, alpha > 0.0, self.n_patches, self.patch_size, self.subject_ratio, self.rng,
-                                          cut_by_box=True)
-        item.pop("ray_img", None)
-        # constants of the patch MSE (`train.prepare_patch_targets`, M2:41-50): the cut pixels are filled with the background colour
-        pm, tp = item["patch_masks"], item["target_patches"]
-        item["mse_const"] = float((((bgc.expand(tp.shape) - tp) ** 2)[~pm]).sum())
-        item["mse_count"] = float(tp.numel())
+        if full_frame:
+            item["target_rgbs"] = item.pop("ray_img")
+        else:
+            item = rays_mod.sample_patch_rays(item, img, alpha > 0.0, self.n_patches, self.patch_size, self.subject_ratio, self.rng,
+                                              cut_by_box=True)
+            item.pop("ray_img", None)
+            # constants of the patch MSE (`train.prepare_patch_targets`, M2:41-50): the cut pixels are filled with the background colour
+            pm, tp = item["patch_masks"], item["target_patches"]
+            item["mse_const"] = float((((bgc.expand(tp.shape) - tp) ** 2)[~pm]).sum())
+            item["mse_count"] = float(tp.numel())
         Rs, Ts, posevec = self._pose(name)
         host = {"dst_Rs": Rs, "dst_Ts": Ts, "dst_posevec": posevec, "bgcolor": bg, **self._cnl}
         if time > 0.005:

@@ -416,17 +416,25 @@ class Network(FlatModule):
         return out
 
     @torch.no_grad()
-    def gather_decoder_shards(self):
+    def gather_decoder_shards(self, optimizer=None):
         """Collective (every rank calls it): each sharded layer's rows are fetched from their owners, so that the flat parameter
-        buffer -- and with it `state_dict()` -- is complete and identical on every rank again.  The Adam moments stay sharded."""
+        buffer -- and with it `state_dict()` -- is complete and identical on every rank again.  `optimizer` (the FusedAdam of this
+        module, or an object with a `.fused` list that contains it): its two moment buffers -- same flat layout -- are completed the
+        same way, so that the optimiser state rank 0 writes into a checkpoint is the state of ALL rows and a resumed run continues
+        every shard's Adam where it stopped (without it the rows of ranks >= 1 restart with m = v = 0 at step t)."""
         comm = self.decoder_shard
         if comm is None:
             return
+        flats = [self.flat_param]
+        for f in (getattr(optimizer, "fused", None) or ([optimizer] if optimizer is not None else [])):
+            if getattr(f, "module", None) is self:
+                flats += [f.exp_avg, f.exp_avg_sq]
         for n in self._shard_layers:
             off, row, cin = self._shard_rows(n)
             cs = cin // comm.world
-            mine = self.flat_param[off + comm.rank * cs * row: off + (comm.rank + 1) * cs * row]
-            self.flat_param[off: off + cin * row].copy_(comm.all_gather(mine).reshape(-1))
+            for flat in flats:
+                mine = flat[off + comm.rank * cs * row: off + (comm.rank + 1) * cs * row]
+                flat[off: off + cin * row].copy_(comm.all_gather(mine).reshape(-1))
 
     # ------------------------------------------------------------------ data-parallel backward of the volume decoder
     # The motion-weight volume decoder (63.4 M of the 64.7 M parameters, 253 MB of gradient) sees no ray: its input is a learned

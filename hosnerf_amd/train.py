@@ -59,11 +59,15 @@ def allreduce_flat_grad_async(module: FlatModule, group=None, ranges=None) -> li
     the volume decoder's backward under the gradient exchange of the other parameters (bench.py, N > 1)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return []
+    # every rank must take the same skip / update decision (ADVICE r5): the range-guard word travels with the gradients here too
+    # (4 bytes, MAX, idempotent -- a second exchange of the same step reduces an already agreed word)
+    guard = _allreduce_range_guard(module.flat_grad.device, group, async_op=True)
+    handles = [guard] if guard is not None else []
     if ranges is None and getattr(module.store, "inactive", None):
         ranges = module.store.active_spans()
     if ranges is None:
-        return [dist.all_reduce(module.flat_grad, group=group, async_op=True)]
-    return [dist.all_reduce(module.flat_grad[off:off + n], group=group, async_op=True) for off, n in ranges if n > 0]
+        return handles + [dist.all_reduce(module.flat_grad, group=group, async_op=True)]
+    return handles + [dist.all_reduce(module.flat_grad[off:off + n], group=group, async_op=True) for off, n in ranges if n > 0]
 
 
 _HOS_COMM = None
@@ -117,16 +121,17 @@ def allreduce_flat_grad(module: FlatModule, group=None, ranges=None, hos=None) -
     return world
 
 
-def _allreduce_range_guard(device, group=None):
+def _allreduce_range_guard(device, group=None, async_op: bool = False):
     """Every rank must take the same skip / update decision in the optimiser launch, or the replicas part for good: the fp16
     range-guard word is MAX-reduced over the group wherever the gradients are exchanged (4 bytes, idempotent; a rank whose rays
     tripped the guard makes every rank skip this step).  Eager only -- like the gradient exchange it sits between the captured
-    halves of a multi-rank step."""
+    halves of a multi-rank step.  `async_op`: returns the work handle (None when there is nothing to reduce)."""
     if device.type != "cuda" or not ops.RANGE_GUARD or torch.cuda.is_current_stream_capturing():
-        return
+        return None
     flag, _ = ops.range_guard_words(device)
     if flag is not None:
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        return dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+    return None
 
 
 class ShardComm:
@@ -310,10 +315,13 @@ class FusedAdam:
     def max_grad_norm(self) -> float:
         return self.clip.max_norm
 
-    def step(self, lr: Optional[float] = None, dynamic: bool = False, reduced: bool = False, clip_sumsq=False):
+    def step(self, lr: Optional[float] = None, dynamic: bool = False, reduced: bool = False, clip_sumsq=False, clear_guard: bool = True):
         """`reduced=True`: the caller already all-reduced the flat gradient (e.g. overlapped with other work); only the
         1/world scaling is applied here.  `clip_sumsq`: the joint sum of squares `step_all` formed over every optimiser of
-        the step (a device scalar, or None = no clipping); left at False this optimiser clips by its own norm."""
+        the step (a device scalar, or None = no clipping); left at False this optimiser clips by its own norm.
+        `clear_guard=False`: this is NOT the last optimiser launch of the training step -- the fp16 range-guard word is consumed
+        (a poisoned step is skipped) but left set for the launches that follow (`step_all` passes it).  A loop that
+        steps several optimisers itself must do the same, or call `step_all`."""
         self.module.store.ensure_bound()          # torch autograd's prologue gradients must have landed in the flat buffer
         _no_pending_decoder_backward(self.module)
         reduced, self.grad_is_reduced = reduced or self.grad_is_reduced, False
@@ -322,7 +330,7 @@ class FusedAdam:
             self.exp_avg, self.exp_avg_sq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device)
             self._hyper = None
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
-        if clip_sumsq is False and _step_multi([self], [lr], dynamic):         # norm + Adam of this module as two launches
+        if clip_sumsq is False and _step_multi([self], [lr], dynamic, clear_guard):         # norm + Adam of this module as two launches
             return
         if clip_sumsq is False and _guard_on_fallback_path(g.device, dynamic):
             return
@@ -356,7 +364,7 @@ class FusedAdam:
 MULTI_ADAM = __import__("os").environ.get("HOS_MULTI_ADAM", "1") != "0"     # A/B switch: 0 = one norm / Adam launch per span (round 3)
 
 
-def _step_multi(opts, lrs, dynamic: bool) -> bool:
+def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
     """The whole optimiser step of `opts` (already reduced gradients) as TWO launches: the joint gradient norm of every active span
     (hos_sumsq_partials) and torch.optim.Adam over every learning-rate range of every module (hos_adam_multi), which also
     consumes the fp16 range-guard word: a step whose forward left the exact hi/lo range updates nothing (train.range_skips counts).
@@ -395,6 +403,8 @@ def _step_multi(opts, lrs, dynamic: bool) -> bool:
             return False
     dev = spans[0][0].device
     guard = ops.range_guard_words(dev)       # with several ranks the word was MAX-reduced next to the gradients (allreduce_flat_grad)
+    if not clear_guard:                      # an earlier launch of a multi-launch step: skip on the word, leave it (and the count) alone
+        guard = (guard[0], None)
     ops.adam_multi(spans, opts[0].step_count if not dynamic else 0, opts[0].betas[0], opts[0].betas[1], opts[0].eps, 1.0 / world,
                    partial, clip.max_norm, guard)
     return True
@@ -463,7 +473,7 @@ def step_all(opts, lr=None, dynamic: bool = False, reduced=False):
                 ss = clip.sumsq(opts)
             o.step(l, dynamic=dynamic, reduced=True, clip_sumsq=ss)
         else:
-            o.step(l, dynamic=dynamic, reduced=True)
+            o.step(l, dynamic=dynamic, reduced=True, clear_guard=o is opts[-1])     # ONE skip decision per training step
 
 
 class FusedAdamOptimizer(torch.optim.Optimizer):

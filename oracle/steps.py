@@ -125,3 +125,49 @@ def stage3_step(bsd, hsd, batch, device="cpu", lr: float = 6.667e-5, transitions
         return loss.detach()
 
     return step
+
+
+# ------------------------------------------------------------------ trainers over CHANGING items (tests/test_gpu_convergence.py)
+def stage1_trainer(sd, device="cpu", transitions=(0.4,), grad_max_norm: float = GRAD_MAX_NORM, near: float = 0.1, far: float = 1e6):
+    """The stage-1 loop of the reference (M1:491-514 training_step, M1:536-569 Adam + per-step learning rate, run.py:155 norm
+    clip) over a stream of batches: returns (params, step) with `step(batch, lr, train_frac, jitters) -> loss`.  `batch` holds
+    device tensors (`rays_o`, `rays_d`, `viewdirs`, `radii`, `times`, `target`); `jitters` are the per-level per-ray draws."""
+    p = _params(sd, device)
+    opt = torch.optim.Adam(list(p.values()), lr=1.0)
+
+    def step(batch, lr: float, train_frac: float, jitters=None):
+        for g in opt.param_groups:                       # M1:551-567: optimizer_step rewrites every group's lr each step
+            g["lr"] = lr
+        opt.zero_grad()
+        rend, hist = ob.mipnerf360_forward(p, batch, train_frac, True, near, far, transitions_times=list(transitions), jitters=jitters)
+        loss, _ = ob.stage1_loss(rend[-1]["rgb"], batch["target"], hist)
+        loss.backward()
+        if grad_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(list(p.values()), grad_max_norm)
+        opt.step()
+        return loss.detach()
+
+    return p, step
+
+
+def stage2_trainer(sd, device="cpu", lr: float = 6.667e-4, transitions=(0.4,), grad_max_norm: float = GRAD_MAX_NORM):
+    """The stage-2 loop (M2:571-634 + the per-parameter groups of optimizer.py:19-60) over a stream of items: returns
+    (params, step) with `step(item, t_rand, lr_scale=1.0) -> loss`.  `item`: a stage-2 dataset item with device tensors."""
+    p = _params(sd, device)
+    groups = _human_groups(p, lr)
+    base = [g["lr"] for g in groups]
+    opt = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.999))
+
+    def step(item, t_rand, lr_scale: float = 1.0):
+        for g, b0 in zip(opt.param_groups, base):        # M2:606-634: every group's lr = its base * decay(step)
+            g["lr"] = b0 * lr_scale
+        opt.zero_grad()
+        out = oh.human_forward(p, item, transitions_times=list(transitions), t_rand=t_rand, stage=2)
+        loss, _ = ol.stage2_losses(out, item, float(item["time"]))
+        loss.backward()
+        if grad_max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([v for v in p.values() if v.grad is not None], grad_max_norm)
+        opt.step()
+        return loss.detach()
+
+    return p, step

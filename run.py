@@ -272,7 +272,7 @@ def run(args, gin):
             lit.optimizer_step(0, step, opt)
             if save_every > 0 and (step + 1) % save_every == 0 and step + 1 < max_steps:
                 if getattr(getattr(lit, "human", None), "decoder_shard", None) is not None:
-                    lit.human.gather_decoder_shards()        # collective: every rank's flat buffer is complete before rank 0 writes it
+                    lit.human.gather_decoder_shards(opt)        # collective: every rank's flat buffer is complete before rank 0 writes it
                 if rank == 0:
                     save_last(step + 1)
             if (step + 1) % log_every == 0 and rank == 0:
@@ -280,7 +280,7 @@ def run(args, gin):
                 print(f"[run] step {step + 1}/{max_steps} loss {float(loss):.5f} lr {opt.param_groups[0]['lr']:.3e} "
                       f"{(step + 1 - step0) * rays * world / dt:.0f} rays/s")
         if getattr(getattr(lit, "human", None), "decoder_shard", None) is not None:
-            lit.human.gather_decoder_shards()
+            lit.human.gather_decoder_shards(opt)
         if rank == 0 and bool(kw.get("save_last", True)):
             save_last(max_steps)
             print(f"[run] wrote {ckpt}")

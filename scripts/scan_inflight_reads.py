@@ -56,6 +56,7 @@ def scan_kernel(lines, start, end, stop_at_loop_exit=False):
 def assemble(src):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",          # the Makefile's flags: the scan must see the shipped allocation
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "hosnerf_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return out
@@ -87,3 +88,48 @@ if __name__ == "__main__":
             print("   +%d  %s   | outstanding: %s" % f)
         bad += len(found)
     sys.exit(1 if bad else 0)
+
+
+def scan_untracked_global_loads(src, kernels):
+    """destinations of INLINE-ASM `global_load_dword` (hos_gemmp.hip: the epilogue operands bias_r[] / bw[][] requested
+    before the K loop, `"=v"` outputs the compiler believes are defined when the asm statement ends).  Between such a load and the
+    first `s_waitcnt vmcnt(0)` behind it NO instruction may name its destination VGPR -- neither a read (stale value) nor a write
+    or copy (the late-arriving data would land in a re-used register).  Loads the compiler emitted itself are tracked by its own
+    waits and are not looked at (inline asm is bracketed by `;;#ASMSTART` / `;;#ASMEND` in the -S output).
+    Returns {kernel: (number of asm loads seen, [hazards])}."""
+    lines = [l.rstrip() for l in open(assemble(src))]
+    report = {}
+    for name in kernels:
+        for st in [i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(name) + r"\S*:", l)]:
+            end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
+            pending, found, seen, in_asm = [], [], 0, False
+            for i in range(st, end):
+                t = lines[i].strip()
+                if t.startswith(";;#ASMSTART"):
+                    in_asm = True
+                    continue
+                if t.startswith(";;#ASMEND"):
+                    in_asm = False
+                    continue
+                if not t or t[0] in ";." or t.endswith(":"):
+                    continue
+                op = t.split()[0]
+                toks = re.findall(r"v\[\d+:\d+\]|v\d+", t)
+                if in_asm and op == "global_load_dword" and toks:
+                    pending.append((regs(toks[0]), i))
+                    seen += 1
+                    used = set()
+                    for tk in toks[1:]:
+                        used |= regs(tk)
+                elif op == "s_waitcnt" and re.search(r"vmcnt\(0\)", t):
+                    pending = []
+                    continue
+                else:
+                    used = set()
+                    for tk in toks:
+                        used |= regs(tk)
+                for dst, li in pending:
+                    if li != i and used & dst:
+                        found.append((i - st, t[:80], lines[li].strip()[:60]))
+            report[lines[st][:-1]] = (seen, found)
+    return report

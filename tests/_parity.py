@@ -1,0 +1,154 @@
+"""Full-size parity tables shared by tests/test_gpu_selfnoise.py (random-init weights) and tests/test_gpu_convergence.py (TRAINED
+weights): the reference's arithmetic -- the oracle -- evaluated in fp32 on the host cores, in fp32 on the MI355X and in float64, and
+the HIP path, on the same rays, weights and draws; the statistics the north-star is read against (1e-4 RGB L-inf on rays whose
+discrete decisions agree, counts and bounds for the others) are taken between every pair.  TEST INFRASTRUCTURE."""
+import json
+import os
+import tempfile
+
+import torch
+
+import oracle.background as ob
+import oracle.human as oh
+
+
+def basedir(transitions=(0.4,)):
+    d = tempfile.mkdtemp(prefix="hos_parity_")
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({f"f{i}": {"time": float(t)} for i, t in enumerate(transitions)}, f)
+    return d
+
+
+def cast(d, device, dtype):
+    return {k: (v.detach().to(device=device, dtype=dtype if v.is_floating_point() else None) if isinstance(v, torch.Tensor) else v)
+            for k, v in d.items()}
+
+
+PAIRS = (("oracle_fp32_cpu", "oracle_fp64"), ("oracle_fp32_rocm", "oracle_fp64"), ("oracle_fp32_cpu", "oracle_fp32_rocm"),
+         ("hip", "oracle_fp64"), ("hip", "oracle_fp32_rocm"), ("hip", "oracle_fp32_cpu"))
+
+
+# ------------------------------------------------------------------------------------------ stage 1
+def stage1_pair(a, b):
+    """a, b: (rgb [B,3], [tdist per level]) as float64 CPU tensors.  Rays whose 160 interval edges agree to 1e-4 relative /
+    the others; worst RGB difference on each class; rays over the north-star tolerance."""
+    moved = torch.zeros(a[0].shape[0], dtype=torch.bool)
+    for ta, tb in zip(a[1], b[1]):
+        moved |= ((ta - tb).abs() / tb.abs()).max(-1).values > 1e-4
+    diff = (a[0] - b[0]).abs().max(-1).values
+    return {"rays_with_moved_samples": int(moved.sum()), "rays_over_1e-4": int((diff > 1e-4).sum()),
+            "rgb_linf_same_samples": float(diff[~moved].max()), "rgb_linf_moved_samples": float(diff[moved].max()) if bool(moved.any()) else 0.0}
+
+
+def stage1_tables(sd, batch, jit, dev, train_frac: float = 0.5, transitions=(0.4,), model=None):
+    """`sd`: background state dict (CPU), `batch`: stage-1 rays (CPU tensors, `times` a float or tensor), `jit`: three [B] draws.
+    Returns {"x vs y": stage1_pair}.  `model`: an already built MipNeRF360 on `dev` holding `sd` (else one is built)."""
+    from hosnerf_amd.mipnerf360 import MipNeRF360
+    B = batch["rays_o"].shape[0]
+
+    def oracle(device, dtype):
+        with torch.no_grad():
+            rend, hist = ob.mipnerf360_forward(cast(sd, device, dtype), cast(batch, device, dtype), train_frac, True, 0.1, 1e6,
+                                               transitions_times=list(transitions), jitters=[j.view(B, 1) for j in jit])
+        return rend[-1]["rgb"].double().cpu(), [h["tdist"].double().cpu() for h in hist]
+
+    ev = {"oracle_fp32_cpu": oracle("cpu", torch.float32), "oracle_fp32_rocm": oracle(dev, torch.float32), "oracle_fp64": oracle(dev, torch.float64)}
+    if model is None:
+        model = MipNeRF360(basedir(transitions), opaque_background=True)
+        model.load_state_dict(sd, strict=False)
+        model = model.to(dev)
+    hb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    hb["times"] = float(torch.as_tensor(batch["times"]).reshape(-1)[0])
+    with torch.no_grad():
+        rend, hist = model(hb, train_frac, True, True, 0.1, 1e6, jitters=[j.to(dev) for j in jit])
+    # (a no-grad forward that leaves the exact fp16 hi/lo range re-runs in exact fp32 and pins the module there, ops.guarded_forward)
+    assert model.gemm_mode is None, "the HIP forward left the exact fp16 hi/lo range on these weights (module switched to fp32)"
+    ev["hip"] = (rend[-1]["rgb"].double().cpu(), [h["tdist"].double().cpu() for h in hist])
+    return {f"{x} vs {y}": stage1_pair(ev[x], ev[y]) for x, y in PAIRS}
+
+
+def assert_stage1(pairs):
+    """The HIP path's counts against a small multiple of the oracle-vs-oracle counts; 1e-4 on sample-identical rays."""
+    ref = [pairs[k] for k in pairs if not k.startswith("hip")]
+    noise_moved = max(r["rays_with_moved_samples"] for r in ref)
+    noise_over = max(r["rays_over_1e-4"] for r in ref)
+    noise_rgb = max(r["rgb_linf_moved_samples"] for r in ref)
+    for k in ("hip vs oracle_fp64", "hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
+        h = pairs[k]
+        assert h["rgb_linf_same_samples"] < 1e-4, (k, h)                                         # the north-star tolerance, identical samples
+        assert h["rays_with_moved_samples"] <= 1.5 * noise_moved + 8, (k, h, noise_moved)
+        assert h["rays_over_1e-4"] <= noise_over + 3, (k, h, noise_over)
+        assert h["rgb_linf_moved_samples"] <= 2 * noise_rgb + 1e-4, (k, h, noise_rgb)
+    return noise_moved
+
+
+# ------------------------------------------------------------------------------------------ stage 3
+def stage3_pair(a, b):
+    """a, b: (rgb [B,3], idx_fg [B] bool, dense total_order [B,160])."""
+    same_fg = a[1] == b[1]
+    both = a[1] & b[1]
+    same_order = torch.ones_like(same_fg)
+    same_order[both] = (a[2][both] == b[2][both]).all(-1)
+    diff = (a[0] - b[0]).abs().max(-1).values
+    ok = same_fg & same_order
+    sw = same_fg & ~same_order
+    return {"fg_flips": int((~same_fg).sum()), "rays_with_a_swapped_pair": int(sw.sum()), "rgb_linf_same_order": float(diff[ok].max()),
+            "rgb_linf_swapped": float(diff[sw].max()) if bool(sw.any()) else 0.0, "rays_over_1e-4": int((diff > 1e-4).sum()),
+            "fg_rays": int(b[1].sum())}
+
+
+def stage3_tables(bsd, hsd, b, t_rand, jit, dev, transitions=(0.4,), hos=None):
+    """`b`: a stage-3 item (CPU tensors + host scalars), `t_rand` [B,128], `jit` three [B] draws.  `hos`: a built HOSNeRF on `dev`."""
+    from hosnerf_amd.hosnerf import HOSNeRF
+    from hosnerf_amd.human_nerf import default_cfg
+    from hosnerf_amd.train import batch_to_device, prepare_patch_targets
+    B = b["near"].shape[0]
+
+    def oracle(device, dtype):
+        bb = cast(b, device, dtype)
+        bk = {"rays_o": bb["rays_o_bkg"], "rays_d": bb["rays_d_bkg"], "viewdirs": bb["viewdirs_bkg"], "radii": bb["radii"], "times": b["time"]}
+        with torch.no_grad():
+            _, hist = ob.mipnerf360_forward(cast(bsd, device, dtype), bk, 1.0, True, 0.1, 1e6, transitions_times=list(transitions),
+                                            jitters=[j.view(B, 1) for j in jit], render=False)
+            human = oh.human_forward(cast(hsd, device, dtype), bb, transitions_times=list(transitions),
+                                     t_rand=t_rand.to(device=device, dtype=dtype), stage=3)
+            rgb, fg, order, _, _ = oh.stage3_composite(hist[-1]["tdist"], hist[-1]["rgb"], hist[-1]["density"], human, bk["rays_o"], bk["rays_d"],
+                                                       bb["newsmpl_to_scale_world"])
+        dense = torch.zeros(B, 160, dtype=torch.int64)
+        dense[fg.cpu()] = order.cpu().long()
+        return rgb.double().cpu(), fg.cpu().bool(), dense
+
+    ev = {"oracle_fp32_cpu": oracle("cpu", torch.float32), "oracle_fp32_rocm": oracle(dev, torch.float32), "oracle_fp64": oracle(dev, torch.float64)}
+    if hos is None:
+        cfg = default_cfg(basedir(transitions))
+        cfg.perturb = 1.0
+        hos = HOSNeRF(cfg)
+        hos.model.load_state_dict(bsd, strict=False)
+        hos.human.load_state_dict(hsd, strict=True)
+        hos = hos.to(dev)
+    gb = batch_to_device(prepare_patch_targets(b), dev)
+    with torch.no_grad():
+        out = hos.render(gb, randomized=True, is_train=True, jitters=[j.to(dev) for j in jit], t_rand=t_rand.to(dev))
+    assert hos.model.gemm_mode is None and hos.human.gemm_mode is None, "the HIP forward left the exact fp16 hi/lo range (fp32 fallback taken)"
+    fg_h = out["idx_fg"].bool().cpu()
+    dense = torch.zeros(B, 160, dtype=torch.int64)
+    dense[fg_h] = out["total_order"].cpu().long()[fg_h]
+    ev["hip"] = (out["rgb"].double().cpu(), fg_h, dense)
+    return {f"{x} vs {y}": stage3_pair(ev[x], ev[y]) for x, y in PAIRS}
+
+
+def assert_stage3(pairs):
+    ref = [pairs[k] for k in pairs if not k.startswith("hip")]
+    noise_sw = max(r["rays_with_a_swapped_pair"] for r in ref)
+    noise_fg = max(r["fg_flips"] for r in ref)
+    noise_rgb = max(r["rgb_linf_swapped"] for r in ref)
+    for k in ("hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
+        assert pairs[k]["rgb_linf_same_order"] < 1e-4, (k, pairs[k])             # the north-star tolerance: against the fp32 reference
+    e64 = max(pairs[k]["rgb_linf_same_order"] for k in ("oracle_fp32_cpu vs oracle_fp64", "oracle_fp32_rocm vs oracle_fp64"))
+    assert pairs["hip vs oracle_fp64"]["rgb_linf_same_order"] <= 1.5 * e64 + 1e-5, (pairs["hip vs oracle_fp64"], e64)
+    for k in ("hip vs oracle_fp64", "hip vs oracle_fp32_rocm", "hip vs oracle_fp32_cpu"):
+        h = pairs[k]
+        assert h["rays_with_a_swapped_pair"] <= noise_sw + 2, (k, h, noise_sw)
+        assert h["fg_flips"] <= noise_fg + 2, (k, h, noise_fg)
+        assert h["rgb_linf_swapped"] <= 2 * noise_rgb + 1e-4, (k, h, noise_rgb)
+    return noise_sw

@@ -109,3 +109,52 @@ def test_flat_grad_allreduce_world2():
     res = [torch.load(os.path.join(out, f"r{r}.pt")) for r in range(2)]
     assert all(r["ok"] and r["pad_ok"] and r["gather_ok"] for r in res)
     assert res[0]["sum"] == res[1]["sum"]
+
+
+def _shard_worker(rank, world, port, basedir, out_dir):
+    """`run.shard_decoder = True` checkpoints: `gather_decoder_shards(optimizer)` completes the parameters AND both Adam
+    moment buffers on every rank, so the optimiser state rank 0 writes holds the rows of every owner."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hosnerf_amd.human_nerf import Network, default_cfg
+    from hosnerf_amd.train import FusedAdam, FusedAdamOptimizer, ShardComm
+    torch.manual_seed(0)
+    net = Network(default_cfg(basedir), stage=2)
+    net.shard_decoder(ShardComm(rank, world))
+    fused = FusedAdam(net, lr=1e-3)
+    opt = FusedAdamOptimizer(fused)
+    mine = net.decoder_shard_spans()
+    assert len(mine) == 3
+    # what a few sharded steps leave behind: every rank has written ITS rows of the parameters and of both moments, the other
+    # ranks' rows are stale (here: poisoned, so that a row nobody fetched is visible)
+    for flat, base in ((net.flat_param, 1.0), (fused.exp_avg, 10.0), (fused.exp_avg_sq, 100.0)):
+        with torch.no_grad():
+            for n in net._shard_layers:
+                off, row, cin = net._shard_rows(n)
+                flat[off:off + cin * row].fill_(float("nan"))
+            for off, n in mine:
+                flat[off:off + n].fill_(base * (rank + 1))
+    net.gather_decoder_shards(opt)
+    ok = True
+    for flat, base in ((net.flat_param, 1.0), (fused.exp_avg, 10.0), (fused.exp_avg_sq, 100.0)):
+        for n in net._shard_layers:
+            off, row, cin = net._shard_rows(n)
+            cs = cin // world
+            for r in range(world):
+                ok = ok and bool(torch.all(flat[off + r * cs * row: off + (r + 1) * cs * row] == base * (r + 1)))
+    sd = opt.state_dict()["fused"][0]
+    ok = ok and bool(torch.isfinite(sd["exp_avg"]).all()) and bool(torch.isfinite(sd["exp_avg_sq"]).all())     # nothing stale is left to save
+    torch.save({"ok": ok, "sum": float(sd["exp_avg"].double().sum())}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_decoder_checkpoint_carries_every_ranks_adam_state():
+    d = tempfile.mkdtemp(prefix="hos_dist_")
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({"f0": {"time": 0.4}}, f)
+    out = tempfile.mkdtemp(prefix="hos_dist_out_")
+    mp.spawn(_shard_worker, args=(2, _free_port(), d, out), nprocs=2, join=True)
+    res = [torch.load(os.path.join(out, f"s{r}.pt")) for r in range(2)]
+    assert all(r["ok"] for r in res)
+    assert res[0]["sum"] == res[1]["sum"]          # the state rank 0 saves is the state every rank would save

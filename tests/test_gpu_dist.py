@@ -94,6 +94,39 @@ def test_bench_two_ranks_share_one_gpu_strong_scaling(shard):
         assert d["launch"].startswith("hipGraph replay (fwd+bwd)") and "all-reduce" in d["launch"], d["launch"]
 
 
+def test_bench_default_command_two_ranks_rehearsal():
+    """The command the driver runs at N > 1 -- `bench.py --gpus N --steps K --warmup W`, nothing skipped -- rehearsed as two processes
+    on the one GPU (gloo stands in for RCCL): the ONE JSON line must carry the proof of who took part (`comm`), the strong-scaling
+    primary, the weak-scaling stage-3 leg (4096 rays PER rank, the reference's DDP semantic, 3rd_Complete_HOSNeRF/run.py:173-190),
+    the sharded-decoder leg, stage 1 and the 1080p frame -- every secondary leg inside its guard."""
+    e = _env()
+    e["HOS_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rays_per_gpu"] == 2048
+    c = d["comm"]
+    assert c["rccl_ranks_seen"] == 2 and len(c["devices"]) == 2 and c["devices"][0].startswith("rank 0:") and c["devices"][1].startswith("rank 1:")
+    assert "gloo" in c["backend"]                       # said, not hidden: this rehearsal is not an RCCL run
+    assert "parity_note" in d and "roofline" in d
+    st = d["stages"]
+    for k in ("stage1", "stage3_weak", "stage3_sharded_onegraph", "infer_1080p"):
+        assert k in st and "error" not in st[k], (k, st.get(k))
+    w = st["stage3_weak"]
+    assert w["scaling"] == "weak" and w["rays_per_gpu"] == 4096 and w["global_rays"] == 8192 and w["value"] > 0
+    sh = st["stage3_sharded_onegraph"]
+    assert sh["rays_per_gpu"] == 2048 and sh["launch"].startswith("eager (volume decoder sharded") and 0 < sh["final_loss"] < 1.0
+    assert st["infer_1080p"]["n_gpus"] == 2 and st["infer_1080p"]["finite"]
+    out = os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu_rehearsal.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    with open(out, "w") as f:
+        f.write(lines[0] + "\n")
+
+
 _FAILED_CAPTURE = r"""
 import os, sys
 sys.path.insert(0, os.environ["HOS_ROOT"])

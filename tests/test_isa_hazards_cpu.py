@@ -34,6 +34,18 @@ def test_planes_gemm_main_loops_never_touch_an_inflight_fragment():
         assert not found, (k, found[:4])
 
 
+def test_planes_gemm_untracked_epilogue_loads_are_never_touched_before_their_wait():
+    """the FWD bias / DGRAD bit-mask operands of the planes GEMM are requested by inline-asm `global_load_dword` before the
+    K loop; nothing may name their destination VGPRs until the first vmcnt(0) (re-run on every ROCm bump: it checks the
+    register allocation of THIS compiler)."""
+    import scan_inflight_reads as S
+    rep = S.scan_untracked_global_loads(os.path.join(ROOT, "hosnerf_amd", "csrc", "hos_gemmp.hip"), ["gemmp_kernel"])
+    assert len(rep) == 12, list(rep)
+    assert sum(n for n, _ in rep.values()) >= 12, "the scan did not see the asm loads (ASMSTART markers / mnemonic changed?)"
+    for k, (n, found) in rep.items():
+        assert not found, (k, found[:4])
+
+
 def test_no_packed_fp32_instruction_in_any_kernel():
     """The two-stream step (HOSNeRF.two_streams) lets kernels of the two branches share CUs.  v_pk_{mul,add,fma}_f32 / v_pk_mov_b32
     in a wave that shares its SIMD with MFMA-issuing waves of another kernel gave wrong results in lanes 48-63 (28 of 30 runs
