@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 // ---- round 4: ONE norm launch + ONE update launch per training step, whatever the number of flat buffers / learning-rate ranges,
 // and the fp16 range guard consumed on the device.
-constexpr int OPT_SPANS = 16;      // (round 5: 8 -> 16; a rank that owns a SHARD of the volume decoder has a few more active spans)
+constexpr int OPT_SPANS = 32;      // (round 5: 8 -> 16 for the sharded decoder; round 6: -> 32, every lazily updated span is a span of its own)
 constexpr int SUMSQ_BLOCKS = 1024;
 struct SumsqSpans { const float* g[OPT_SPANS]; long start4[OPT_SPANS + 1]; int count; };      // spans in float4 units (n % 4 == 0)
 
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const SumsqSpans t,
 struct AdamSpans {
     float* p[OPT_SPANS]; const float* g[OPT_SPANS]; float* m[OPT_SPANS]; float* v[OPT_SPANS];
     const float* hyper[OPT_SPANS];                       // device {lr, 1-b1^t, 1/sqrt(1-b2^t)} of the span, or NULL: the host values below
+    const float* lazy[OPT_SPANS];                        // device {t, active, 1-b1^t, 1/sqrt(1-b2^t)} of a lazily updated span (hos_adam_lazy_prepare), or NULL
     float lr[OPT_SPANS], bc1[OPT_SPANS], rsbc2[OPT_SPANS];
     long start4[OPT_SPANS + 1]; int count;
 };
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
         const long j = i - t.start4[s];
         float lr = t.lr[s], bc1 = t.bc1[s], rsbc2 = t.rsbc2[s];
         if (t.hyper[s] != nullptr) { lr = t.hyper[s][0]; bc1 = t.hyper[s][1]; rsbc2 = t.hyper[s][2]; }
+        if (t.lazy[s] != nullptr) {          // torch.optim.Adam skips a parameter whose .grad is None and counts ITS steps only
+            if (t.lazy[s][1] == 0.f) continue;
+            bc1 = t.lazy[s][2]; rsbc2 = t.lazy[s][3];
+        }
         float4* p4 = reinterpret_cast<float4*>(t.p[s]) + j;
         float4* m4 = reinterpret_cast<float4*>(t.m[s]) + j;
         float4* v4 = reinterpret_cast<float4*>(t.v[s]) + j;
@@ -154,7 +159,53 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
     }
 }
 
+// One workgroup per lazily updated span: state[s] = {t, active, 1-b1^t, 1/sqrt(1-b2^t)}.  active = the span's (already reduced)
+// gradient is not identically zero; then t += 1 and the bias corrections are those of ITS t-th update.
+struct LazySpans { const float* g[OPT_SPANS]; float* state[OPT_SPANS]; long count[OPT_SPANS]; };
+__global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const LazySpans t, float b1, float b2, const unsigned int* __restrict__ guard) {
+    const int s = blockIdx.x;
+    const float* g = t.g[s];
+    int any = 0;
+    for (long i = threadIdx.x; i < t.count[s]; i += 256) any |= (g[i] != 0.f) ? 1 : 0;
+    __shared__ int flag;
+    if (threadIdx.x == 0) flag = 0;
+    __syncthreads();
+    if (any) atomicOr(&flag, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* st = t.state[s];
+        const bool poisoned = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        if (flag && !poisoned) {          // (a step the range guard is about to skip updates nothing and counts nothing)
+            const float n = st[0] + 1.f;
+            st[0] = n; st[1] = 1.f;
+            st[2] = 1.f - powf(b1, n);
+            st[3] = 1.f / sqrtf(1.f - powf(b2, n));
+        } else {
+            st[1] = 0.f;
+        }
+    }
+}
+
 }  // namespace
+
+// Lazily updated spans (round 6): torch.optim.Adam -- the reference's optimiser under Lightning, whose zero_grad sets gradients to
+// None (torch 2.0.1 default) -- SKIPS a parameter that took no part in a step (no moment decay, no movement) and keeps a step count
+// PER PARAMETER for the bias corrections.  Such parameters exist: the state embeddings of the states a step's frame is not in
+// (M:224-296 / N:179-246: one state per call), the pose decoder before its kick-in iteration (N:589-605).  Their flat gradient is
+// identically zero in such a step, which is what this launch tests (after the all-reduce: every rank decides the same).
+// n <= 32 spans; state[s]: 4 floats {t, active, 1-beta1^t, 1/sqrt(1-beta2^t)}, zero-initialised by the caller, consumed by
+// hos_adam_multi_lazy.  guard: the range-guard word (NULL: off) -- a poisoned step counts nothing.
+extern "C" int hos_adam_lazy_prepare(int n, const float* const* g, const long long* count, float* const* state, float beta1, float beta2,
+                                     const unsigned int* guard, hos_stream_t stream) {
+    if (n <= 0 || n > OPT_SPANS || !g || !count || !state) return HOS_E_ARG;
+    LazySpans t{};
+    for (int s = 0; s < n; ++s) {
+        if (!g[s] || !state[s] || count[s] <= 0) return HOS_E_ARG;
+        t.g[s] = g[s]; t.state[s] = state[s]; t.count[s] = (long)count[s];
+    }
+    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), t, beta1, beta2, guard);
+    return hos_launch_status();
+}
 
 extern "C" int hos_sumsq(const float* g, int64_t n, float* sumsq, hos_stream_t stream) {
     if (!g || !sumsq || n <= 0) return HOS_E_ARG;
@@ -224,6 +275,15 @@ extern "C" int hos_sumsq_partials(int n, const float* const* g, const long long*
 extern "C" int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
                               const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
                               const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream) {
+    return hos_adam_multi_lazy(n, p, g, m, v, count, hyper, nullptr, lr, step, beta1, beta2, eps, grad_scale, partial, max_norm, guard, skipped, stream);
+}
+
+// hos_adam_multi with lazily updated spans: lazy[s] (NULL entries / NULL table: a plain span) = the span's state row written by
+// hos_adam_lazy_prepare earlier on the same stream: inactive -> the span is not touched; active -> its own bias corrections.
+extern "C" int hos_adam_multi_lazy(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
+                                   const float* const* hyper, const float* const* lazy, const float* lr, int step, float beta1, float beta2,
+                                   float eps, float grad_scale, const float* partial, float max_norm, const unsigned int* guard,
+                                   unsigned int* skipped, hos_stream_t stream) {
     if (n <= 0 || n > OPT_SPANS || !p || !g || !m || !v || !count) return HOS_E_ARG;
     AdamSpans t{};
     long pos = 0;
@@ -235,6 +295,7 @@ extern "C" int hos_adam_multi(int n, float* const* p, const float* const* g, flo
         const float* h = hyper ? hyper[s] : nullptr;
         if (!h && (!lr || step < 1)) return HOS_E_ARG;
         t.p[s] = p[s]; t.g[s] = g[s]; t.m[s] = m[s]; t.v[s] = v[s]; t.hyper[s] = h;
+        t.lazy[s] = lazy ? lazy[s] : nullptr;
         t.lr[s] = lr ? lr[s] : 0.f; t.bc1[s] = (float)bc1; t.rsbc2[s] = (float)(1.0 / sqrt(bc2));
         t.start4[s] = pos; pos += (long)(count[s] >> 2);
     }

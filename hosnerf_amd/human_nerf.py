@@ -446,6 +446,16 @@ class Network(FlatModule):
     _pending_vol = None
     _fwd_stream = None          # the stream the last training forward was queued on
 
+    def lazy_param_spans(self):
+        """[(offset, numel)] of the flat buffer that can be WITHOUT a gradient in a training step (torch's Adam skips such parameters):
+        every state embedding (one state per call, N:179-246) and the pose decoder, which is not evaluated before
+        `cfg.pose_decoder.kick_in_iter` (N:589-605; all its parameters start together, so one span = one step count)."""
+        spans = [(self._embeds.offset + k * 64, 64) for k in range(len(self.human_stateembeds))]
+        first = self._plain["pose_decoder.block_mlps.0.weight"]
+        lo = (first.data_ptr() - self.flat_param.data_ptr()) // 4
+        spans.append((int(lo), int(self._nr[0].W.offset - lo)))
+        return spans
+
     def decoder_span(self):
         """(offset, numel) of the volume decoder's parameters in the flat buffer (they are allocated first)."""
         first = self._plain["pose_decoder.block_mlps.0.weight"]

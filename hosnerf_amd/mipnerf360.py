@@ -615,6 +615,11 @@ class MipNeRF360(FlatModule):
 
     gemm_mode = None      # None: the process default (ops.set_gemm_mode); ops.GEMM_* pins the arithmetic of this module's GEMMs
 
+    def lazy_param_spans(self):
+        """[(offset, numel)] of the flat buffer that can be WITHOUT a gradient in a training step: every state embedding (one state
+        per call, M:224-296 -- the other states' embeddings have `grad None` in the reference and its Adam skips them)."""
+        return [(m._embeds.offset + k * EMBED, EMBED) for m in self.mlps for k in range(len(m.bkgd_stateembeds))]
+
     def _level0(self, B: int, dev):
         """The level-0 histogram of M:446-448 (constants): cached per (B, device) instead of three fills + a cat per call."""
         key = (B, str(dev))

@@ -223,7 +223,7 @@ class GradClip:
         for o in opts:
             g = o.module.flat_grad
             spans += [g[off:off + n] for off, n in o.module.store.active_spans()]
-        if len(spans) > 16 or any((t.numel() % 4) or (t.data_ptr() % 16) for t in spans):
+        if len(spans) > 32 or any((t.numel() % 4) or (t.data_ptr() % 16) for t in spans):
             return None
         dev = spans[0].device
         if getattr(self, "_partials", None) is None or self._partials.device != dev:
@@ -254,6 +254,29 @@ def _minus_inactive(lr_ranges, module: FlatModule):
     return out
 
 
+LAZY_ADAM = __import__("os").environ.get("HOS_LAZY_ADAM", "1") != "0"     # A/B switch: 0 = every span updated every step (rounds 1-5)
+
+
+def _split_at_lazy(ranges, lazy_spans):
+    """Cut the learning-rate ranges [(off, n, mult)] at the lazily updated spans [(off, n)] (each inside one range, float4-aligned):
+    returns (ranges, lazy index of every range or None)."""
+    out, idx = [], []
+    for off, n, mult in ranges:
+        pos, end = off, off + n
+        for k, (lo, ln) in enumerate(lazy_spans):
+            if lo + ln <= pos or lo >= end:
+                continue
+            if lo < pos or lo + ln > end or lo % 4 or ln % 4:
+                raise ValueError(f"lazy span ({lo}, {ln}) straddles a learning-rate range or is not float4-aligned")
+            if lo > pos:
+                out.append((pos, lo - pos, mult)); idx.append(None)
+            out.append((lo, ln, mult)); idx.append(k)
+            pos = lo + ln
+        if pos < end:
+            out.append((pos, end - pos, mult)); idx.append(None)
+    return out, idx
+
+
 class FusedAdam:
     """torch.optim.Adam semantics over the flat parameter buffer of a FlatModule: one sum-of-squares
     launch (norm clipping), one RCCL all-reduce of the whole gradient (multi-GPU) and one Adam launch."""
@@ -267,6 +290,15 @@ class FusedAdam:
         self.module = module
         self.lr_ranges = _minus_inactive(lr_ranges, module)
         self.lr, self.betas, self.eps = lr, betas, eps
+        # Lazily updated spans (round 6; hos_adam_lazy_prepare): torch's Adam -- the reference's, under Lightning's zero_grad(set_to_none) --
+        # SKIPS a parameter whose gradient is None and counts that parameter's own steps.  The modules name the spans that can be
+        # without a gradient in a step (`lazy_param_spans`: state embeddings of the other states, the pose decoder before its kick-in);
+        # each becomes a range of its own with a 4-float device state row {t, active, 1-b1^t, 1/sqrt(1-b2^t)}.
+        self.lazy_spans = sorted(module.lazy_param_spans()) if (LAZY_ADAM and hasattr(module, "lazy_param_spans")) else []
+        self._range_lazy = None
+        if self.lazy_spans:
+            self.lr_ranges, self._range_lazy = _split_at_lazy(self.lr_ranges or [(0, module.flat_param.numel(), 1.0)], self.lazy_spans)
+        self.lazy_state = torch.zeros(len(self.lazy_spans), 4, device=module.flat_param.device)
         self.clip = clip if clip is not None else GradClip(max_grad_norm)
         self.group = process_group
         p = module.flat_param
@@ -327,7 +359,7 @@ class FusedAdam:
         reduced, self.grad_is_reduced = reduced or self.grad_is_reduced, False
         g = self.module.flat_grad
         if self.exp_avg.device != g.device:       # the module was moved after the optimiser was built (`lit.to(device)`)
-            self.exp_avg, self.exp_avg_sq = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device)
+            self.exp_avg, self.exp_avg_sq, self.lazy_state = self.exp_avg.to(g.device), self.exp_avg_sq.to(g.device), self.lazy_state.to(g.device)
             self._hyper = None
         world = self.world_size() if reduced else allreduce_flat_grad(self.module, self.group)
         if clip_sumsq is False and _step_multi([self], [lr], dynamic, clear_guard):         # norm + Adam of this module as two launches
@@ -351,7 +383,8 @@ class FusedAdam:
     def state_dict(self):
         """Flat layout (version 1): the two moment buffers in the order of the module's flat parameter buffer."""
         return {"layout": "hosnerf_amd.flat.v1", "numel": int(self.exp_avg.numel()), "exp_avg": self.exp_avg.detach().cpu().clone(),
-                "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "step": self.step_count, "lr": self.lr}
+                "exp_avg_sq": self.exp_avg_sq.detach().cpu().clone(), "step": self.step_count, "lr": self.lr,
+                "lazy_spans": list(self.lazy_spans), "lazy_state": self.lazy_state.detach().cpu().clone()}
 
     def load_state_dict(self, sd):
         if sd.get("layout", "hosnerf_amd.flat.v1") != "hosnerf_amd.flat.v1" or int(sd.get("numel", self.exp_avg.numel())) != self.exp_avg.numel():
@@ -359,6 +392,15 @@ class FusedAdam:
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        if len(self.lazy_spans):
+            if [tuple(x) for x in sd.get("lazy_spans", [])] == [tuple(x) for x in self.lazy_spans]:
+                self.lazy_state.copy_(sd["lazy_state"])
+            else:       # a checkpoint written before round 6: every span was updated at every step
+                t = float(self.step_count)
+                self.lazy_state[:, 0] = t
+                self.lazy_state[:, 1] = 1.0
+                self.lazy_state[:, 2] = 1.0 - self.betas[0] ** max(t, 1.0)
+                self.lazy_state[:, 3] = 1.0 / math.sqrt(1.0 - self.betas[1] ** max(t, 1.0))
 
 
 MULTI_ADAM = __import__("os").environ.get("HOS_MULTI_ADAM", "1") != "0"     # A/B switch: 0 = one norm / Adam launch per span (round 3)
@@ -379,7 +421,7 @@ def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
     for o, l in zip(opts, lrs):
         p, g = o.module.flat_param, o.module.flat_grad
         if o.exp_avg.device != g.device:
-            o.exp_avg, o.exp_avg_sq = o.exp_avg.to(g.device), o.exp_avg_sq.to(g.device)
+            o.exp_avg, o.exp_avg_sq, o.lazy_state = o.exp_avg.to(g.device), o.exp_avg_sq.to(g.device), o.lazy_state.to(g.device)
             o._hyper = None
         if dynamic and o._hyper is None:
             return False
@@ -387,9 +429,10 @@ def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
         for r, (off, n, mult) in enumerate(o.lr_ranges or [(0, p.numel(), 1.0)]):
             if n % 4 or off % 4:
                 return False
+            k = o._range_lazy[r] if o._range_lazy is not None else None
             spans.append((p[off:off + n], g[off:off + n], o.exp_avg[off:off + n], o.exp_avg_sq[off:off + n],
-                          o._hyper[r] if dynamic else None, float(l) * mult))
-    if len(spans) > 16 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
+                          o._hyper[r] if dynamic else None, float(l) * mult, None if k is None else o.lazy_state[k]))
+    if len(spans) > 32 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
         return False
     partial = clip.partials(opts)
     if clip.max_norm > 0 and partial is None:
@@ -403,6 +446,9 @@ def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
             return False
     dev = spans[0][0].device
     guard = ops.range_guard_words(dev)       # with several ranks the word was MAX-reduced next to the gradients (allreduce_flat_grad)
+    lazy = [sp for sp in spans if sp[6] is not None]
+    if lazy:                                 # which lazily updated spans took part in this step (their reduced gradient is not all zero)
+        ops.adam_lazy_prepare([sp[1] for sp in lazy], [sp[6] for sp in lazy], opts[0].betas[0], opts[0].betas[1], guard[0])
     if not clear_guard:                      # an earlier launch of a multi-launch step: skip on the word, leave it (and the count) alone
         guard = (guard[0], None)
     ops.adam_multi(spans, opts[0].step_count if not dynamic else 0, opts[0].betas[0], opts[0].betas[1], opts[0].eps, 1.0 / world,

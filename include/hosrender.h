@@ -670,9 +670,9 @@ int hos_embed_bwd_res(const float* x, const float* band_w, int num_freqs, int id
 int hos_head_grad_padded(const float* g_density, const float* density, const float* g_rgb, const float* rgb, int P, float rgb_padding,
                          float* dz_density, int ld_dd, int col_dd, float* dz_rgb, int ld_dr, hos_stream_t stream);
 /* Gradient norm + Adam of a whole training step in TWO launches, whatever the number of flat buffers / learning-rate ranges.
- * hos_sumsq_partials: partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 16 spans (count % 4 == 0), fixed order,
+ * hos_sumsq_partials: partial[0 .. hos_sumsq_blocks()) = per-block sums of squares over n <= 32 spans (count % 4 == 0), fixed order,
  * nothing to zero first (`Trainer(gradient_clip_val=..., "norm")`, S1/run.py:155, 3rd_.../run.py:188-189).
- * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 16 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
+ * hos_adam_multi: torch.optim.Adam (M1:536-569, optimizer.py:19-60) over n <= 32 spans; span s takes {lr, 1-beta1^t, 1/sqrt(1-beta2^t)}
  * from device memory hyper[s] (graph replay) or, if NULL, from lr[s] / step; clip coefficient min(max_norm / (sqrt(sum partial) *
  * |grad_scale| + 1e-6), 1) when partial != NULL; guard (the word of hos_set_range_flag, NULL: off): non-zero -> no parameter is
  * touched by THIS launch, skipped[0] is incremented and the word is cleared again (by the launch's last workgroup; skipped[1] is its
@@ -683,6 +683,19 @@ int hos_sumsq_partials(int n, const float* const* g, const long long* count, flo
 int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
                    const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
                    const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream);
+/* Lazily updated spans (round 6).  The reference's optimiser is torch.optim.Adam under Lightning, whose zero_grad() sets gradients to
+ * None: a parameter that took no part in a step -- the state embeddings of the states the step's frame is not in (M:224-296,
+ * N:179-246), the pose decoder before its kick-in iteration (N:589-605) -- is SKIPPED (no moment decay, no movement) and its bias
+ * corrections count ITS OWN updates.  hos_adam_lazy_prepare (one launch, n <= 32 spans, after the gradient exchange): state[s]
+ * {t, active, 1-beta1^t, 1/sqrt(1-beta2^t)} (4 floats, zero-initialised once by the caller) -- active = the span's gradient is not
+ * identically zero (and the range-guard word, if given, is clear); then t += 1.  hos_adam_multi_lazy = hos_adam_multi with lazy[s]
+ * (NULL: a plain span) = that row: an inactive span is not touched, an active one uses its own corrections. */
+int hos_adam_lazy_prepare(int n, const float* const* g, const long long* count, float* const* state, float beta1, float beta2,
+                          const unsigned int* guard, hos_stream_t stream);
+int hos_adam_multi_lazy(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
+                        const float* const* hyper, const float* const* lazy, const float* lr, int step, float beta1, float beta2,
+                        float eps, float grad_scale, const float* partial, float max_norm, const unsigned int* guard,
+                        unsigned int* skipped, hos_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LPIPS term of the stage-2 / stage-3 training loss (hos_lpips.hip): `LPIPS(net='vgg')` of third_parties/lpips/lpips.py:22-122 as

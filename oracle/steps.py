@@ -128,7 +128,8 @@ def stage3_step(bsd, hsd, batch, device="cpu", lr: float = 6.667e-5, transitions
 
 
 # ------------------------------------------------------------------ trainers over CHANGING items (tests/test_gpu_convergence.py)
-def stage1_trainer(sd, device="cpu", transitions=(0.4,), grad_max_norm: float = GRAD_MAX_NORM, near: float = 0.1, far: float = 1e6):
+def stage1_trainer(sd, device="cpu", transitions=(0.4,), grad_max_norm: float = GRAD_MAX_NORM, near: float = 0.1, far: float = 1e6,
+                   set_to_none: bool = True):
     """The stage-1 loop of the reference (M1:491-514 training_step, M1:536-569 Adam + per-step learning rate, run.py:155 norm
     clip) over a stream of batches: returns (params, step) with `step(batch, lr, train_frac, jitters) -> loss`.  `batch` holds
     device tensors (`rays_o`, `rays_d`, `viewdirs`, `radii`, `times`, `target`); `jitters` are the per-level per-ray draws."""
@@ -138,7 +139,7 @@ def stage1_trainer(sd, device="cpu", transitions=(0.4,), grad_max_norm: float = 
     def step(batch, lr: float, train_frac: float, jitters=None):
         for g in opt.param_groups:                       # M1:551-567: optimizer_step rewrites every group's lr each step
             g["lr"] = lr
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=set_to_none)      # Lightning / torch 2.0.1 default: None -> Adam SKIPS parameters without a gradient
         rend, hist = ob.mipnerf360_forward(p, batch, train_frac, True, near, far, transitions_times=list(transitions), jitters=jitters)
         loss, _ = ob.stage1_loss(rend[-1]["rgb"], batch["target"], hist)
         loss.backward()

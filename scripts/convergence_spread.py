@@ -32,7 +32,7 @@ def main():
     if os.environ.get("MODE") == "pairs":
         # (HIP, oracle) pairs from the same perturbed initial weights: is there an OFFSET between the two paths beyond their spreads?
         b0, h0 = synth.background_state_dict(777, 2), synth.human_state_dict(777, 2)
-        for steps, scale, ks in ((400, 1.0, 3), (400, 0.3, 3)):
+        for steps, scale, ks in ((400, 1.0, 2), (400, 0.3, 3)):
             out = []
             for k in range(ks):
                 r, _, m = tc._train_stage1(rays, dev, perturbed(b0, k), steps, scale, oracle=True)
@@ -41,7 +41,7 @@ def main():
                 torch.cuda.empty_cache()
             print(json.dumps({"stage": 1, "steps": steps, "lr_scale": scale, "psnr_hip_oracle": out}), flush=True)
         tc.S2_DECAY_STEPS = 1
-        for steps, scale, ks in ((300, 0.3, 3), (900, 0.3, 2)):
+        for steps, scale, ks in ((500, 0.3, 3),):
             out = []
             for k in range(ks):
                 r, _, _ = tc._train_stage2(scene, px, dev, perturbed(h0, k), steps, scale, oracle=True)

@@ -218,3 +218,57 @@ def test_lit_hosnerf_clips_when_bound(dev):
         res[clip] = lit.model.flat_param.clone()
     d = float((res[CLIP] - res[0.0]).abs().max())
     assert d > 1e-6, d
+
+
+def test_adam_skips_parameters_without_a_gradient_like_torch(dev):
+    """Round 6 (found by tests/test_gpu_convergence.py): the reference's optimiser is torch.optim.Adam under Lightning, whose
+    `zero_grad()` sets gradients to None (torch 2.0.1 default) -- a parameter that took no part in a step (the state embeddings of
+    the states the step's frame is not in, M:224-296) is SKIPPED: no moment decay, no movement, and its bias corrections count its
+    own updates.  Six clipped stage-1 steps whose frames alternate between the two states: the flat Adam (lazily updated spans,
+    hos_adam_lazy_prepare) against torch's Adam fed the SAME gradients (None where the flat gradient of an embedding is all zero)."""
+    from hosnerf_amd.mipnerf360 import MipNeRF360
+    from hosnerf_amd.train import FusedAdam, stage1_loss
+    LR_LAZY = 2e-4       # (2e-3 without the schedule's warm-up kills the 1024-wide MLP in two 64-ray steps: softplus' underflows to 0 everywhere)
+    torch.manual_seed(0)
+    model = MipNeRF360(_basedir(), opaque_background=True)
+    model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+    model = model.to(dev)
+    opt = FusedAdam(model, lr=LR_LAZY, max_grad_norm=CLIP)
+    assert len(opt.lazy_spans) == 6
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    topt = torch.optim.Adam(list(ref.values()), lr=LR_LAZY)
+    times = [0.2, 0.7, 0.7, 0.2, 0.7, 0.2]
+    for i, t in enumerate(times):
+        b = {k: v.to(dev) for k, v in synth.stage1_batch(64, seed=60 + i).items()}
+        b["times"] = t
+        opt.zero_grad()
+        rend, hist = model(b, 0.5, True, True, 0.1, 1e6)
+        loss, _ = stage1_loss(rend[-1]["rgb"], b["target"], hist)
+        loss.backward()
+        model.store.ensure_bound()
+        topt.zero_grad()                                   # set_to_none=True
+        unused = []
+        for n, p in model.named_parameters():
+            g = p.grad.detach().clone()
+            if "stateembeds" in n and not bool(g.any()):
+                unused.append(n)
+                continue                                   # .grad stays None: torch skips it
+            ref[n].grad = g
+        assert len(unused) == 3, (i, t, unused)            # one embedding per MLP belongs to the other state
+        torch.nn.utils.clip_grad_norm_([p for p in ref.values() if p.grad is not None], CLIP)
+        topt.step()
+        opt.step(LR_LAZY)
+    torch.cuda.synchronize()
+    p0 = synth.background_state_dict(777, 2)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        moved = float((ref[n].detach() - p0[n].to(dev)).abs().max()) if n in p0 else 0.0
+        err = float((p.detach() - ref[n].detach()).abs().max())
+        if moved > 0:
+            worst = max(worst, err / moved)
+        else:
+            assert err == 0.0, n
+    assert worst < 2e-3, worst                             # same gradients -> same steps, up to the norm's summation order
+    # and the embeddings DID behave differently from an every-step update: their step counts are their own
+    t_state = opt.lazy_state[:, 0].cpu().tolist()
+    assert sorted(set(t_state)) == [3.0] and opt.step_count == 6, (t_state, opt.step_count)

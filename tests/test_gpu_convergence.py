@@ -5,13 +5,18 @@ training_step (:1501-1658; stage 1: 1st_State-Conditional_Scene/src/model/mipner
 2nd_State_Conditional_Human-Object/src/model/mipnerf360/model.py:571-634) are what is compared: a synthetic, multi-view
 consistent scene DIRECTORY (the on-disk formats of SURVEY 8(f).4) is trained twice from identical initial weights, items,
 sampling draws, learning-rate schedule and gradient clip --
-  (a) stage 1, S1_STEPS x 1024 background rays (single-image batches, train_frac annealing, warm-up + log-linear decay),
-  (b) stage 2, S2_STEPS x two 32x32 patches cut by the subject's box (<= 2048 rays x 128 samples, flow + cycle terms),
+  (a) stage 1, 400 steps x 1024 background rays (single-image batches that alternate between the two states, train_frac annealing,
+      warm-up + log-linear decay at 0.3 x the reference's rate),
+  (b) stage 2, 500 steps x two 32x32 patches cut by the subject's box (<= 2048 rays x 128 samples, flow + cycle terms; 0.3 x the
+      reference's rates, its 0.1 ** (step / 500 k) decay compressed into the run),
 once through the HIP path (`MipNeRF360` / `Network` + `FusedAdam`) and once through the reference's op graph as PyTorch-ROCm ops
 (`oracle.steps.stage1_trainer` / `stage2_trainer`: torch autograd + `clip_grad_norm_` + torch Adam).  Asserted: the PSNR on
 HELD-OUT frames agrees within 0.1 dB and the smoothed final losses agree.  Two fp32 trainings are two chaotic trajectories (the
 inverse-CDF resampling and Adam's normalisation amplify a last-bit difference), so weight-for-weight equality is not expected
-and not asserted.
+and not asserted; the learning rates are those at which two trainings of the SAME path agree to a few hundredths of a dB (see the
+constants below).  This test found a real difference in round 6: a flat Adam that updates parameters WITHOUT a gradient (the other
+state's embeddings) where torch's skips them -- +0.3 dB against the reference graph at stage 1's full rate, gone with the lazily
+updated spans of hos_adam_lazy_prepare (profiles/r06_convergence_pairs_before_lazy_adam.jsonl vs r06_convergence_pairs.jsonl).
 Then, on the HIP-TRAINED weights (sharper densities -> more empty proposal bins; larger pre-activations against the fp16-hi
 planes' +-65504): the full-size forward parity tables of tests/test_gpu_selfnoise.py again -- 1e-4 RGB L-inf on rays whose
 discrete decisions agree, flip counts within the multiple of the reference's own fp32-vs-fp32 noise -- for stage 1 and for
@@ -35,9 +40,17 @@ from tests._record import record
 pytestmark = pytest.mark.gpu
 
 S1_STEPS = int(os.environ.get("HOS_CONV_S1_STEPS", "400"))
-S2_STEPS = int(os.environ.get("HOS_CONV_S2_STEPS", "300"))
+S2_STEPS = int(os.environ.get("HOS_CONV_S2_STEPS", "500"))
 S1_RAYS = 1024
-S2_DECAY_STEPS = int(os.environ.get("HOS_CONV_S2_DECAY", "0"))     # > 0: the decay 0.1 ** (2 step / steps) instead of the reference's 500 k-step one
+S2_DECAY_STEPS = int(os.environ.get("HOS_CONV_S2_DECAY", "1"))     # > 0: the decay 0.1 ** (2 step / steps) instead of the reference's 500 k-step one
+# The regime: a comparison of two trainings resolves what two fp32 trainings of the SAME path differ by.  Measured with the HIP path
+# from initial weights perturbed by one ulp (scripts/convergence_spread.py, profiles/r06_convergence_spread_hip.jsonl): at the full
+# stage-1 rate (2e-3) the held-out PSNR of four runs spreads over 0.16 dB after 400 steps and 0.75 dB after 1200; at 0.3 x the rate
+# over 0.06 dB.  Stage 2: 0.27 dB at the full rate with the reference's (here: flat) decay, 0.03-0.08 dB at 0.3 x with the decay
+# compressed into the run.  HIP / oracle pairs in the chosen regimes differ by 0.00-0.03 dB (stage 1) and 0.02-0.07 dB (stage 2)
+# (profiles/r06_convergence_pairs.jsonl); at the full stage-1 rate by +-0.12 dB in either direction, i.e. by the spread.
+S1_LR_SCALE = float(os.environ.get("HOS_CONV_S1_LR", "0.3"))
+S2_LR_SCALE = float(os.environ.get("HOS_CONV_S2_LR", "0.3"))
 HW = 96
 N_FRAMES = 16
 HELD_OUT = (5, 11)
@@ -120,11 +133,12 @@ def _stage1_heldout(render, rays):
     return _psnr(torch.cat(pred), torch.cat(truth))
 
 
-def _train_stage1(rays, dev, sd0=None, steps=None, lr_scale=1.0, oracle=True):
+def _train_stage1(rays, dev, sd0=None, steps=None, lr_scale=None, oracle=True):
     from hosnerf_amd.mipnerf360 import MipNeRF360
     from hosnerf_amd.train import FusedAdam, stage1_loss
     sd0 = synth.background_state_dict(777, 2) if sd0 is None else sd0
     steps = S1_STEPS if steps is None else steps
+    lr_scale = S1_LR_SCALE if lr_scale is None else lr_scale
     model = MipNeRF360(par.basedir(TRANSITIONS), opaque_background=True)
     model.load_state_dict(sd0, strict=False)
     model = model.to(dev)
@@ -173,10 +187,10 @@ def _stage2_items(scene, px, dev, steps):
     return ds, items
 
 
-def _train_stage2(scene, px, dev, sd0=None, steps=None, lr_scale=1.0, oracle=True):
+def _train_stage2(scene, px, dev, sd0=None, steps=None, lr_scale=None, oracle=True):
     from hosnerf_amd.human_nerf import Network, default_cfg
     from hosnerf_amd.train import FusedAdam, human_lr_ranges, train_step_stage2
-    LR = 6.667e-4 * lr_scale
+    LR = 6.667e-4 * (S2_LR_SCALE if lr_scale is None else lr_scale)
     sd0 = synth.human_state_dict(777, 2) if sd0 is None else sd0
     steps = S2_STEPS if steps is None else steps
     cfg = default_cfg(par.basedir(TRANSITIONS))
