@@ -918,6 +918,17 @@ def main():
         t = threading.Timer(limit_s, fire)
         t.daemon = True
         t.start()
+        # ... and a leg that KILLS the process (abort() inside RCCL, a fault in a captured collective, the launcher's SIGTERM after
+        # another rank died) leaves the same line as its last words (libhoscomm's signal handlers; multi-rank legs only)
+        armed = False
+        if world > 1:
+            try:
+                from hosnerf_amd import comm as _comm
+                snap = dict(out)
+                snap["stages"] = dict(stages, **{label: {"error": "the process was killed by a signal inside this leg (the legs after it were not run)"}})
+                armed = _comm.crash_line_set((json.dumps(snap) + "\n") if rank == 0 else "")
+            except Exception:
+                armed = False
         try:
             return fn()
         except Exception as e:
@@ -929,6 +940,8 @@ def main():
             return {"error": f"{type(e).__name__}: {e}"}
         finally:
             t.cancel()
+            if armed:
+                _comm.crash_line_clear()
 
     events = not args.no_kernel_events
     stages, out, emitted = {}, {}, []
@@ -1026,33 +1039,34 @@ def main():
                                                    describe=Stage3.describe.replace("4096 rays/batch GLOBAL", f"{GLOBAL_RAYS_S3} rays/batch PER GPU (weak scaling)")))
             if "value" in r:
                 r["scaling"] = "weak"
-            # ---- the sharded volume decoder with the collectives inside ONE hipGraph per rank (libhoscomm / RCCL on the capture
-            # stream) -- the best strong-scaling form, opt-in until it has met N real devices
-            prev = {k: os.environ.get(k) for k in ("HOS_SHARD_DECODER", "HOS_HOSCOMM")}
-            os.environ["HOS_SHARD_DECODER"] = "1"
-            if not one_gpu:                       # (RCCL refuses two ranks on one device: the one-GPU rehearsal shards over gloo, eagerly)
-                os.environ["HOS_HOSCOMM"] = "1"
-            try:
-                r = leg("stage3_sharded_onegraph", lambda: measure("stage3", False, describe=Stage3.describe + "; volume decoder SHARDED over the ranks"
-                                                                   + ("" if one_gpu else ", collectives inside one hipGraph per rank (libhoscomm)")))
-                if "value" in r:
-                    r["vs_default_path"] = r["value"] / prim["value"]
-            finally:
-                from hosnerf_amd import train as _train
-                _train.use_hoscomm(None)
-                c = _HOSCOMM.pop("c", None)
-                if c is not None:
-                    try:
-                        c.close()
-                    except Exception:
-                        pass
-                for k, v in prev.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
     if not args.only_primary and not args.no_infer and args.gemm == "planes":
         leg("infer_1080p", lambda: infer_1080p(dev, rank, world, dist, events))
+    if not args.only_primary and args.primary == "stage3" and world > 1:      # LAST: the one leg that has never met N real devices
+        # ---- the sharded volume decoder with the collectives inside ONE hipGraph per rank (libhoscomm / RCCL on the capture
+        # stream) -- the best strong-scaling form, opt-in until it has met N real devices
+        prev = {k: os.environ.get(k) for k in ("HOS_SHARD_DECODER", "HOS_HOSCOMM")}
+        os.environ["HOS_SHARD_DECODER"] = "1"
+        if not one_gpu:                       # (RCCL refuses two ranks on one device: the one-GPU rehearsal shards over gloo, eagerly)
+            os.environ["HOS_HOSCOMM"] = "1"
+        try:
+            r = leg("stage3_sharded_onegraph", lambda: measure("stage3", False, describe=Stage3.describe + "; volume decoder SHARDED over the ranks"
+                                                               + ("" if one_gpu else ", collectives inside one hipGraph per rank (libhoscomm)")))
+            if "value" in r:
+                r["vs_default_path"] = r["value"] / prim["value"]
+        finally:
+            from hosnerf_amd import train as _train
+            _train.use_hoscomm(None)
+            c = _HOSCOMM.pop("c", None)
+            if c is not None:
+                try:
+                    c.close()
+                except Exception:
+                    pass
+            for k, v in prev.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     if world == 1 and not args.only_primary and rank == 0:
         torch_rocm = {}
         if not args.no_torch_baseline:

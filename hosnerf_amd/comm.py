@@ -31,6 +31,8 @@ PROTOTYPES = {
     "hos_allreduce_max_u32": [c_void_p, c_void_p, c_int64, c_void_p],
     "hos_allgather_f32": [c_void_p, c_void_p, c_void_p, c_int64, c_void_p],
     "hos_allreduce_avg_f32_spans": [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "hos_crash_line_set": [ctypes.c_char_p, c_int64],
+    "hos_crash_line_clear": [],
 }
 _lib = None
 
@@ -121,3 +123,18 @@ class HosComm:
         recv = torch.empty((self.world,) + tuple(send.shape), device=send.device, dtype=send.dtype)
         _check(load().hos_allgather_f32(self._h, _f32(send), _f32(recv), send.numel(), stream_ptr()), "hos_allgather_f32")
         return recv
+
+
+def crash_line_set(line: str) -> bool:
+    """`hos_crash_line_set`: if this process dies of a signal from here on (abort() inside RCCL, a fault, the launcher's SIGTERM), `line`
+    is written to stdout and the process exits 0.  Returns False (and does nothing) where libhoscomm.so was not built."""
+    if not os.path.exists(LIB_PATH):
+        return False
+    data = line.encode()
+    _check(load().hos_crash_line_set(data, len(data)), "hos_crash_line_set")
+    return True
+
+
+def crash_line_clear():
+    if os.path.exists(LIB_PATH):
+        _check(load().hos_crash_line_clear(), "hos_crash_line_clear")

@@ -1,7 +1,9 @@
 // libhoscomm.so: include/hoscomm.h over RCCL.  Host code only (no kernels): compiled with hipcc for the hip runtime headers.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <signal.h>
 #include <string.h>
+#include <unistd.h>
 
 #include "hoscomm.h"
 
@@ -72,4 +74,44 @@ extern "C" int hos_allreduce_avg_f32_spans(hos_comm_t comm, float* const* bufs, 
         if (r != ncclSuccess) { ncclGroupEnd(); return rc_of(r); }
     }
     return rc_of(ncclGroupEnd());
+}
+
+
+// ---- last words (include/hoscomm.h)
+static char g_crash_line[1 << 20];
+static volatile long g_crash_len = 0;
+static const int g_crash_signals[] = {SIGSEGV, SIGBUS, SIGABRT, SIGFPE, SIGILL, SIGTERM};
+
+static void hos_crash_handler(int) {
+    long done = 0;
+    const long n = g_crash_len;
+    while (done < n) {
+        const ssize_t w = write(1, g_crash_line + done, (size_t)(n - done));
+        if (w <= 0) break;
+        done += w;
+    }
+    _exit(0);
+}
+
+extern "C" int hos_crash_line_set(const char* line, int64_t len) {
+    if (len < 0 || len > (int64_t)sizeof(g_crash_line) || (len > 0 && !line)) return -1;
+    g_crash_len = 0;
+    if (len > 0) memcpy(g_crash_line, line, (size_t)len);
+    g_crash_len = (long)len;
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = hos_crash_handler;
+    sigemptyset(&sa.sa_mask);
+    for (int s : g_crash_signals) sigaction(s, &sa, nullptr);
+    return 0;
+}
+
+extern "C" int hos_crash_line_clear(void) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = SIG_DFL;
+    sigemptyset(&sa.sa_mask);
+    for (int s : g_crash_signals) sigaction(s, &sa, nullptr);
+    g_crash_len = 0;
+    return 0;
 }

@@ -45,6 +45,13 @@ int hos_allgather_f32(hos_comm_t comm, const float* send, float* recv, int64_t c
 /* Several spans in ONE RCCL group call (the human network's exchange: the volume gradient + the parameter spans outside the
  * volume decoder): bufs / counts are HOST arrays of n entries. */
 int hos_allreduce_avg_f32_spans(hos_comm_t comm, float* const* bufs, const int64_t* counts, int n, void* stream);
+/* Last words of a multi-rank job (bench.py's optional legs: a first execution of a collective path on N real devices can die in a
+ * way no try/except sees -- abort() inside RCCL, a fault in a captured collective, the launcher's SIGTERM after another rank died).
+ * hos_crash_line_set: keep a copy of `line` (len bytes, <= 1 MiB; len 0: say nothing) and install handlers for SIGSEGV, SIGBUS,
+ * SIGABRT, SIGFPE, SIGILL and SIGTERM that write() it to file descriptor 1 and _exit(0) -- async-signal-safe calls only.
+ * hos_crash_line_clear: restore the default dispositions.  The reference has no counterpart (Lightning's launcher just dies). */
+int hos_crash_line_set(const char* line, int64_t len);
+int hos_crash_line_clear(void);
 
 #ifdef __cplusplus
 }

@@ -158,3 +158,23 @@ def test_sharded_decoder_checkpoint_carries_every_ranks_adam_state():
     res = [torch.load(os.path.join(out, f"s{r}.pt")) for r in range(2)]
     assert all(r["ok"] for r in res)
     assert res[0]["sum"] == res[1]["sum"]          # the state rank 0 saves is the state every rank would save
+
+
+def test_crash_line_is_the_last_word_of_a_killed_process():
+    """bench.py arms libhoscomm's signal handlers around its optional multi-rank legs (include/hoscomm.h `hos_crash_line_set`): a process
+    that dies of SIGABRT / SIGSEGV / SIGTERM inside a leg still prints the one JSON line it has and exits 0; cleared handlers die normally."""
+    import subprocess
+    import sys
+    from hosnerf_amd import comm
+    if not os.path.exists(comm.LIB_PATH):
+        import pytest
+        pytest.skip("libhoscomm.so not built (no RCCL under the ROCm path)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, signal, sys; sys.path.insert(0, %r); from hosnerf_amd import comm; "
+            "comm.crash_line_set('{\"value\": 1}\\n'); SIG = getattr(signal, sys.argv[1]); "
+            "comm.crash_line_clear() if sys.argv[2] == 'clear' else None; os.kill(os.getpid(), SIG); import time; time.sleep(5); print('survived')") % root
+    for sig in ("SIGABRT", "SIGSEGV", "SIGTERM"):
+        r = subprocess.run([sys.executable, "-c", code, sig, "armed"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout == '{"value": 1}\n', (sig, r.returncode, r.stdout, r.stderr[-300:])
+    r = subprocess.run([sys.executable, "-c", code, "SIGTERM", "clear"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stdout == ""
