@@ -159,29 +159,41 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
     }
 }
 
-// One workgroup per lazily updated span: state[s] = {t, active, 1-b1^t, 1/sqrt(1-b2^t)}.  active = the span's (already reduced)
-// gradient is not identically zero; then t += 1 and the bias corrections are those of ITS t-th update.
+// LAZY_BLOCKS workgroups per lazily updated span: state[s] = {t, active, 1-b1^t, 1/sqrt(1-b2^t), <flag scratch>, <ticket scratch>, -, -}
+// (8 floats).  active = the span's (already reduced) gradient is not identically zero; then t += 1 and the bias corrections are those
+// of ITS t-th update.  Every workgroup ORs what it found into the flag word and takes a ticket; the last one decides and re-arms both
+// scratch words (self-resetting: a replayed graph behaves the same).
+constexpr int LAZY_BLOCKS = 16;
 struct LazySpans { const float* g[OPT_SPANS]; float* state[OPT_SPANS]; long count[OPT_SPANS]; };
 __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const LazySpans t, float b1, float b2, const unsigned int* __restrict__ guard) {
-    const int s = blockIdx.x;
-    const float* g = t.g[s];
+    const int s = blockIdx.x / LAZY_BLOCKS, part = blockIdx.x % LAZY_BLOCKS;
+    const float4* g4 = reinterpret_cast<const float4*>(t.g[s]);
+    const long n4 = t.count[s] >> 2;                      // (spans are float4-aligned multiples of 4)
     int any = 0;
-    for (long i = threadIdx.x; i < t.count[s]; i += 256) any |= (g[i] != 0.f) ? 1 : 0;
-    __shared__ int flag;
-    if (threadIdx.x == 0) flag = 0;
-    __syncthreads();
-    if (any) atomicOr(&flag, 1);
-    __syncthreads();
+    for (long i = (long)part * 256 + threadIdx.x; i < n4; i += (long)LAZY_BLOCKS * 256) {
+        const float4 v = g4[i];
+        any |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    }
+    float* st = t.state[s];
+    unsigned int* flag = reinterpret_cast<unsigned int*>(st + 4);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(st + 5);
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    __syncthreads();                                       // every wave's atomicOr is issued before this workgroup's ticket
     if (threadIdx.x == 0) {
-        float* st = t.state[s];
-        const bool poisoned = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-        if (flag && !poisoned) {          // (a step the range guard is about to skip updates nothing and counts nothing)
-            const float n = st[0] + 1.f;
-            st[0] = n; st[1] = 1.f;
-            st[2] = 1.f - powf(b1, n);
-            st[3] = 1.f / sqrtf(1.f - powf(b2, n));
-        } else {
-            st[1] = 0.f;
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == LAZY_BLOCKS - 1) {
+            __threadfence();
+            const bool nonzero = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            const bool poisoned = guard != nullptr && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (nonzero && !poisoned) {          // (a step the range guard is about to skip updates nothing and counts nothing)
+                const float n = st[0] + 1.f;
+                st[0] = n; st[1] = 1.f;
+                st[2] = 1.f - powf(b1, n);
+                st[3] = 1.f / sqrtf(1.f - powf(b2, n));
+            } else {
+                st[1] = 0.f;
+            }
+            *flag = 0u; *ticket = 0u;
         }
     }
 }
@@ -193,17 +205,18 @@ __global__ __launch_bounds__(256) void adam_lazy_prepare_kernel(const LazySpans 
 // PER PARAMETER for the bias corrections.  Such parameters exist: the state embeddings of the states a step's frame is not in
 // (M:224-296 / N:179-246: one state per call), the pose decoder before its kick-in iteration (N:589-605).  Their flat gradient is
 // identically zero in such a step, which is what this launch tests (after the all-reduce: every rank decides the same).
-// n <= 32 spans; state[s]: 4 floats {t, active, 1-beta1^t, 1/sqrt(1-beta2^t)}, zero-initialised by the caller, consumed by
-// hos_adam_multi_lazy.  guard: the range-guard word (NULL: off) -- a poisoned step counts nothing.
+// n <= 32 spans (float4-aligned, count % 4 == 0); state[s]: 8 floats {t, active, 1-beta1^t, 1/sqrt(1-beta2^t), two scratch words, 2 unused},
+// zero-initialised by the caller, consumed by hos_adam_multi_lazy.  guard: the range-guard word (NULL: off) -- a poisoned step counts nothing.
 extern "C" int hos_adam_lazy_prepare(int n, const float* const* g, const long long* count, float* const* state, float beta1, float beta2,
                                      const unsigned int* guard, hos_stream_t stream) {
     if (n <= 0 || n > OPT_SPANS || !g || !count || !state) return HOS_E_ARG;
     LazySpans t{};
     for (int s = 0; s < n; ++s) {
         if (!g[s] || !state[s] || count[s] <= 0) return HOS_E_ARG;
+        if ((count[s] & 3) || ((uintptr_t)g[s] & 15u) || ((uintptr_t)state[s] & 3u)) return HOS_E_ALIGN;
         t.g[s] = g[s]; t.state[s] = state[s]; t.count[s] = (long)count[s];
     }
-    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(n), dim3(256), 0, static_cast<hipStream_t>(stream), t, beta1, beta2, guard);
+    hipLaunchKernelGGL(adam_lazy_prepare_kernel, dim3(n * LAZY_BLOCKS), dim3(256), 0, static_cast<hipStream_t>(stream), t, beta1, beta2, guard);
     return hos_launch_status();
 }
 

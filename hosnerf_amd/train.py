@@ -293,12 +293,12 @@ class FusedAdam:
         # Lazily updated spans (round 6; hos_adam_lazy_prepare): torch's Adam -- the reference's, under Lightning's zero_grad(set_to_none) --
         # SKIPS a parameter whose gradient is None and counts that parameter's own steps.  The modules name the spans that can be
         # without a gradient in a step (`lazy_param_spans`: state embeddings of the other states, the pose decoder before its kick-in);
-        # each becomes a range of its own with a 4-float device state row {t, active, 1-b1^t, 1/sqrt(1-b2^t)}.
+        # each becomes a range of its own with a device state row {t, active, 1-b1^t, 1/sqrt(1-b2^t), scratch}.
         self.lazy_spans = sorted(module.lazy_param_spans()) if (LAZY_ADAM and hasattr(module, "lazy_param_spans")) else []
         self._range_lazy = None
         if self.lazy_spans:
             self.lr_ranges, self._range_lazy = _split_at_lazy(self.lr_ranges or [(0, module.flat_param.numel(), 1.0)], self.lazy_spans)
-        self.lazy_state = torch.zeros(len(self.lazy_spans), 4, device=module.flat_param.device)
+        self.lazy_state = torch.zeros(len(self.lazy_spans), 8, device=module.flat_param.device)     # rows of hos_adam_lazy_prepare
         self.clip = clip if clip is not None else GradClip(max_grad_norm)
         self.group = process_group
         p = module.flat_param
@@ -393,8 +393,9 @@ class FusedAdam:
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
         if len(self.lazy_spans):
-            if [tuple(x) for x in sd.get("lazy_spans", [])] == [tuple(x) for x in self.lazy_spans]:
+            if [tuple(x) for x in sd.get("lazy_spans", [])] == [tuple(x) for x in self.lazy_spans] and tuple(sd["lazy_state"].shape) == tuple(self.lazy_state.shape):
                 self.lazy_state.copy_(sd["lazy_state"])
+                self.lazy_state[:, 4:] = 0
             else:       # a checkpoint written before round 6: every span was updated at every step
                 t = float(self.step_count)
                 self.lazy_state[:, 0] = t

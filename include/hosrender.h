@@ -687,7 +687,8 @@ int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* 
  * None: a parameter that took no part in a step -- the state embeddings of the states the step's frame is not in (M:224-296,
  * N:179-246), the pose decoder before its kick-in iteration (N:589-605) -- is SKIPPED (no moment decay, no movement) and its bias
  * corrections count ITS OWN updates.  hos_adam_lazy_prepare (one launch, n <= 32 spans, after the gradient exchange): state[s]
- * {t, active, 1-beta1^t, 1/sqrt(1-beta2^t)} (4 floats, zero-initialised once by the caller) -- active = the span's gradient is not
+ * {t, active, 1-beta1^t, 1/sqrt(1-beta2^t), 2 scratch words, 2 unused} (8 floats, zero-initialised once by the caller; spans
+ * float4-aligned with count % 4 == 0) -- active = the span's gradient is not
  * identically zero (and the range-guard word, if given, is clear); then t += 1.  hos_adam_multi_lazy = hos_adam_multi with lazy[s]
  * (NULL: a plain span) = that row: an inactive span is not touched, an active one uses its own corrections. */
 int hos_adam_lazy_prepare(int n, const float* const* g, const long long* count, float* const* state, float beta1, float beta2,
