@@ -228,6 +228,13 @@ def run(args, gin):
         lit.lpips = LPIPS.from_files(args.lpips_vgg16, args.lpips_lin, dev)          # M:582-584
         print(f"[run] LPIPS term enabled (weight 1.0): {args.lpips_vgg16}, {args.lpips_lin}")
     items = torch.load(args.items, weights_only=False) if args.items else None
+    if items and model_name == "hosnerf":
+        # The stage-3 reference unpacks the rendered rays with a PLAIN reshape (`_unpack_imgs`, S3 model.py:41-50: patches are never
+        # cut by the box in stage 3, core/data/human_nerf/train.py:322-330), for the MSE and for the LPIPS term alike: an item whose
+        # `patch_masks` has holes is a stage-2 item and would be rendered against the wrong pixels -- refuse it here, once, on the host
+        for n, it in enumerate(items):
+            if "patch_masks" in it and not bool(torch.as_tensor(it["patch_masks"]).all()):
+                raise SystemExit(f"--items[{n}]: patch_masks has holes; stage 3 takes whole patches (the reference's stage-3 _unpack_imgs is a reshape)")
     scene = None
     if args.scene_dir:
         if model_name == "state_mipnerf360":
