@@ -172,3 +172,27 @@ def stage2_trainer(sd, device="cpu", lr: float = 6.667e-4, transitions=(0.4,), g
         return loss.detach()
 
     return p, step
+
+
+def stage3_trainer(bsd, hsd, device="cpu", lr: float = 6.667e-5, transitions=(0.4,), grad_max_norm: float = GRAD_MAX_NORM):
+    """The stage-3 loop (M:1501-1658: both renderers + merged composite + get_loss, ONE Adam over both modules with the per-parameter
+    groups of optimizer.py:19-60, ONE gradient norm) over a stream of items: returns (background params, human params, step) with
+    `step(item, t_rand, jitters, lr_scale=1.0) -> loss`.  `jitters`: three [B,1] host tensors (H:364 draws on the host)."""
+    pb, ph = _params(bsd, device), _params(hsd, device)
+    groups = _human_groups(ph, lr) + [{"params": [v], "lr": lr, "name": k} for k, v in pb.items()]
+    base = [g["lr"] for g in groups]
+    opt = torch.optim.Adam(groups, lr=lr, betas=(0.9, 0.999))
+
+    def step(item, t_rand, jitters, lr_scale: float = 1.0):
+        for g, b0 in zip(opt.param_groups, base):        # M:1631-1656: every group's lr = its base * decay(step)
+            g["lr"] = b0 * lr_scale
+        opt.zero_grad()
+        out = stage3_render(pb, ph, item, transitions, t_rand=t_rand, jitters=jitters)
+        loss, _ = ol.stage3_losses(out, item, float(item["time"]))
+        loss.backward()
+        if grad_max_norm > 0:         # ONE norm over every parameter that received a gradient (the proposal MLPs do not)
+            torch.nn.utils.clip_grad_norm_([v for v in list(pb.values()) + list(ph.values()) if v.grad is not None], grad_max_norm)
+        opt.step()
+        return loss.detach()
+
+    return pb, ph, step

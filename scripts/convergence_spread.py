@@ -29,6 +29,32 @@ def main():
     regimes1 = [(400, 1.0), (400, 0.3), (1200, 1.0), (1200, 0.3)]
     regimes2 = [(300, 1.0), (300, 0.3), (900, 1.0), (900, 0.3)]
     stages = os.environ.get("STAGES", "1,2").split(",")
+    if os.environ.get("MODE") == "reference_rates":
+        # The REFERENCE's own learning rates (stage 1: 2e-3 -> 2e-5 with warm-up; stage 2: 6.667e-4 with its flat 500 k-step decay),
+        # where one comparison cannot resolve 0.1 dB (the spread of one path alone is larger): K (HIP, oracle) pairs from perturbed
+        # initial weights -- do the two DISTRIBUTIONS of held-out PSNR coincide?
+        import statistics as st
+        b0, h0 = synth.background_state_dict(777, 2), synth.human_state_dict(777, 2)
+        K1, K2 = int(os.environ.get("K1", "4")), int(os.environ.get("K2", "4"))
+        out = []
+        for k in range(K1):
+            r, _, m = tc._train_stage1(rays, dev, perturbed(b0, k), 800, 1.0, oracle=True)
+            del m
+            out.append((r["psnr_hip"], r["psnr_oracle"]))
+            torch.cuda.empty_cache()
+        h, o = [a for a, _ in out], [b for _, b in out]
+        print(json.dumps({"stage": 1, "steps": 800, "lr_scale": 1.0, "psnr_hip_oracle": out, "hip_mean_sd": [st.mean(h), st.pstdev(h)],
+                          "oracle_mean_sd": [st.mean(o), st.pstdev(o)], "mean_difference_db": st.mean(h) - st.mean(o)}), flush=True)
+        tc.S2_DECAY_STEPS = 0
+        out = []
+        for k in range(K2):
+            r, _, _ = tc._train_stage2(scene, px, dev, perturbed(h0, k), 400, 1.0, oracle=True)
+            out.append((r["psnr_hip"], r["psnr_oracle"]))
+            torch.cuda.empty_cache()
+        h, o = [a for a, _ in out], [b for _, b in out]
+        print(json.dumps({"stage": 2, "steps": 400, "lr_scale": 1.0, "fast_decay": 0, "psnr_hip_oracle": out, "hip_mean_sd": [st.mean(h), st.pstdev(h)],
+                          "oracle_mean_sd": [st.mean(o), st.pstdev(o)], "mean_difference_db": st.mean(h) - st.mean(o)}), flush=True)
+        return
     if os.environ.get("MODE") == "pairs":
         # (HIP, oracle) pairs from the same perturbed initial weights: is there an OFFSET between the two paths beyond their spreads?
         b0, h0 = synth.background_state_dict(777, 2), synth.human_state_dict(777, 2)

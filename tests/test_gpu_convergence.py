@@ -9,6 +9,8 @@ sampling draws, learning-rate schedule and gradient clip --
       warm-up + log-linear decay at 0.3 x the reference's rate),
   (b) stage 2, 500 steps x two 32x32 patches cut by the subject's box (<= 2048 rays x 128 samples, flow + cycle terms; 0.3 x the
       reference's rates, its 0.1 ** (step / 500 k) decay compressed into the run),
+  (c) stage 3, 150 joint steps x 2048 rays warm-started from (a) and (b) as the reference's launcher does (S3/run.py:206-212), at the
+      reference's own rates (ONE Adam and ONE gradient norm over both modules),
 once through the HIP path (`MipNeRF360` / `Network` + `FusedAdam`) and once through the reference's op graph as PyTorch-ROCm ops
 (`oracle.steps.stage1_trainer` / `stage2_trainer`: torch autograd + `clip_grad_norm_` + torch Adam).  Asserted: the PSNR on
 HELD-OUT frames agrees within 0.1 dB and the smoothed final losses agree.  Two fp32 trainings are two chaotic trajectories (the
@@ -49,6 +51,7 @@ S2_DECAY_STEPS = int(os.environ.get("HOS_CONV_S2_DECAY", "1"))     # > 0: the de
 # over 0.06 dB.  Stage 2: 0.27 dB at the full rate with the reference's (here: flat) decay, 0.03-0.08 dB at 0.3 x with the decay
 # compressed into the run.  HIP / oracle pairs in the chosen regimes differ by 0.00-0.03 dB (stage 1) and 0.02-0.07 dB (stage 2)
 # (profiles/r06_convergence_pairs.jsonl); at the full stage-1 rate by +-0.12 dB in either direction, i.e. by the spread.
+S3_STEPS = int(os.environ.get("HOS_CONV_S3_STEPS", "150"))
 S1_LR_SCALE = float(os.environ.get("HOS_CONV_S1_LR", "0.3"))
 S2_LR_SCALE = float(os.environ.get("HOS_CONV_S2_LR", "0.3"))
 HW = 96
@@ -236,6 +239,65 @@ def _train_stage2(scene, px, dev, sd0=None, steps=None, lr_scale=None, oracle=Tr
     return res, sd_hip, frames
 
 
+def _stage3_items(scene, px, dev, frames, n, seed, n_patches=2):
+    from hosnerf_amd.dataset import SceneItems
+    ds = SceneItems(scene, px["images"], px["alphas"], px["flows"], n_patches=n_patches, patch_size=32, device=dev, seed=seed)
+    rs = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for k in range(n):
+        it = ds[frames[rs.randint(len(frames))] if n > len(frames) else frames[k]]
+        it["iter_val"] = torch.full((1,), 3e5)
+        B = int(it["near"].shape[0])
+        items.append((it, torch.rand(B, 128, generator=g).to(dev), [torch.rand(B, generator=g) for _ in range(3)]))
+    return items
+
+
+def _train_stage3(scene, px, dev, bsd, hsd, steps=None, lr_scale=1.0, oracle=True):
+    """Stage 3 warm-started from the two trained modules (S3/run.py:206-212), `steps` joint steps (M:1501-1658: both renderers, merged
+    composite, ONE Adam / ONE clip over both modules) through the HIP path and through the reference's op graph; held-out PSNR =
+    the rays of eight 32x32 patches per held-out frame, training sampling with the SAME injected draws for both."""
+    from hosnerf_amd.hosnerf import HOSNeRF
+    from hosnerf_amd.human_nerf import default_cfg
+    from hosnerf_amd.train import FusedAdam, GradClip, human_lr_decay, human_lr_ranges, train_step_stage3
+    LR = 6.667e-5 * lr_scale
+    steps = S3_STEPS if steps is None else steps
+    cfg = default_cfg(par.basedir(TRANSITIONS))
+    cfg.perturb = 1.0
+    hos = HOSNeRF(cfg)
+    hos.model.load_state_dict(bsd, strict=False)
+    hos.human.load_state_dict(hsd, strict=True)
+    hos = hos.to(dev)
+    clip = GradClip(osteps.GRAD_MAX_NORM)
+    o_b = FusedAdam(hos.model, lr=LR, clip=clip)
+    o_h = FusedAdam(hos.human, lr=LR, lr_ranges=human_lr_ranges(hos.human, LR, LR / 10.0), clip=clip)
+    pb, ph, ora_step = osteps.stage3_trainer(bsd, hsd, dev, LR, TRANSITIONS) if oracle else (None, None, None)
+    train_frames = [i for i in range(N_FRAMES) if i not in HELD_OUT]
+    loss_h, loss_o = [], []
+    for step, (it, t_rand, jit) in enumerate(_stage3_items(scene, px, dev, train_frames, steps, 41)):
+        decay = human_lr_decay(step)
+        batch = {k: v for k, v in it.items() if k not in NET_DROP}
+        loss, _ = train_step_stage3(hos, o_b, o_h, batch, LR * decay, jitters=[j.to(dev) for j in jit], t_rand=t_rand)
+        loss_h.append(loss)
+        loss_o.append(ora_step(it, t_rand, [j.view(-1, 1) for j in jit], decay) if oracle else loss)
+    loss_h, loss_o = torch.stack(loss_h).cpu(), torch.stack(loss_o).cpu()
+    held = _stage3_items(scene, px, dev, list(HELD_OUT), len(HELD_OUT), 43, n_patches=8)
+
+    def heldout(render):
+        with torch.no_grad():
+            return _psnr(torch.cat([render(it, t, j) for it, t, j in held]), torch.cat([it["target_rgbs"] for it, _, _ in held]))
+
+    def render_hip(it, t_rand, jit):
+        return hos.render({k: v for k, v in it.items() if k not in NET_DROP}, randomized=True, is_train=True, jitters=[j.to(dev) for j in jit],
+                          t_rand=t_rand, with_cycle=False)["rgb"]
+
+    def render_ora(it, t_rand, jit):
+        return osteps.stage3_render(pb, ph, it, TRANSITIONS, t_rand=t_rand, jitters=[j.view(-1, 1) for j in jit])["rgb"]
+
+    return {"steps": steps, "rays_per_step": 2048, "psnr_hip": heldout(render_hip), "psnr_oracle": heldout(render_ora) if oracle else None,
+            "loss_first": [float(loss_h[0]), float(loss_o[0])], "loss_last20_mean": [float(loss_h[-20:].mean()), float(loss_o[-20:].mean())]}
+
+
 class _LinearPeaks:
     """Records max |output| of every `F.linear` / matmul-form linear the oracle runs (call order = layer order)."""
 
@@ -270,11 +332,14 @@ def trained(tmp_path_factory):
     torch.cuda.empty_cache()
     s2, hsd, frames2 = _train_stage2(scene, px, dev)
     torch.cuda.empty_cache()
+    s3 = _train_stage3(scene, px, dev, bsd, hsd)
+    torch.cuda.empty_cache()
     skipped = int(range_skips(dev)) - int(skips0)
     record("convergence.stage1", s1)
     record("convergence.stage2", s2)
+    record("convergence.stage3", s3)
     record("convergence.range_skips_during_training", skipped)
-    return {"dev": dev, "scene": scene, "px": px, "rays": rays, "s1": s1, "s2": s2, "bsd": bsd, "hsd": hsd, "skipped": skipped, "frames2": frames2}
+    return {"dev": dev, "scene": scene, "px": px, "rays": rays, "s1": s1, "s2": s2, "s3": s3, "bsd": bsd, "hsd": hsd, "skipped": skipped, "frames2": frames2}
 
 
 def test_stage1_heldout_psnr_matches_the_reference_graph(trained):
@@ -291,6 +356,16 @@ def test_stage2_heldout_psnr_matches_the_reference_graph(trained):
     assert abs(s["psnr_hip"] - s["psnr_oracle"]) <= 0.1, s
     assert abs(s["loss_last20_mean"][0] - s["loss_last20_mean"][1]) <= 0.03 * abs(s["loss_last20_mean"][1]), s
     assert abs(s["loss_first"][0] - s["loss_first"][1]) <= 1e-4 * abs(s["loss_first"][1]), s
+
+
+def test_stage3_heldout_psnr_matches_the_reference_graph(trained):
+    """BASELINE's metric config: the joint stage-3 step, warm-started from the trained stage-1 / stage-2 modules."""
+    s = trained["s3"]
+    assert abs(s["psnr_hip"] - s["psnr_oracle"]) <= 0.1, s
+    # (the training loss of 20 single-item steps carries the flow / cycle terms of those items on two slightly different weight sets:
+    # measured 3.7 % apart with the held-out PSNR 0.011 dB apart)
+    assert abs(s["loss_last20_mean"][0] - s["loss_last20_mean"][1]) <= 0.08 * abs(s["loss_last20_mean"][1]), s
+    assert abs(s["loss_first"][0] - s["loss_first"][1]) <= 2e-4 * abs(s["loss_first"][1]), s
 
 
 def test_no_step_was_skipped_by_the_range_guard(trained):
