@@ -367,6 +367,11 @@ class FusedAdam:
         if clip_sumsq is False and _guard_on_fallback_path(g.device, dynamic):
             return
         sumsq = self.clip.sumsq([self]) if clip_sumsq is False else clip_sumsq      # after the exchange: the norm of the SUMMED gradient
+        if self.lazy_spans and not getattr(self, "_lazy_warned", False):
+            import warnings          # (HOS_MULTI_ADAM=0, > 32 spans, unaligned ranges: the per-span launches know no lazily updated spans)
+            warnings.warn("FusedAdam: per-span Adam path taken -- parameters without a gradient are updated with zero gradients here "
+                          "(torch's Adam would skip them; the one-launch path does)")
+            self._lazy_warned = True
         if dynamic:
             p = self.module.flat_param
             for r, (off, n, _) in enumerate(self.lr_ranges or [(0, p.numel(), 1.0)]):

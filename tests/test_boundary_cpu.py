@@ -326,3 +326,37 @@ def _merge(spans):
         else:
             out.append((off, n))
     return out
+
+
+def test_lazy_spans_cover_exactly_the_parameters_that_can_be_without_a_gradient():
+    """Round 6 (`hos_adam_lazy_prepare`): the spans the optimiser treats like torch's "grad is None" parameters are exactly the state
+    embeddings (one span each) and the pose decoder (one span: its parameters start together at the kick-in iteration), every span is
+    float4-aligned, and the optimiser's learning-rate ranges are cut at them without losing or duplicating a float."""
+    from hosnerf_amd.human_nerf import Network, default_cfg
+    from hosnerf_amd.mipnerf360 import MipNeRF360
+    from hosnerf_amd.train import FusedAdam, _split_at_lazy, human_lr_ranges
+    d = _basedir()
+    for mod, lazy_names in ((MipNeRF360(d, opaque_background=True), ("stateembeds",)), (Network(default_cfg(d)), ("stateembeds", "pose_decoder"))):
+        spans = sorted(mod.lazy_param_spans())
+        base = mod.flat_param.data_ptr()
+        inside = lambda off, n: any(lo <= off and off + n <= lo + ln for lo, ln in spans)
+        for name, p in mod.named_parameters():
+            off = (p.data_ptr() - base) // 4
+            lazy = any(k in name for k in lazy_names)
+            assert inside(off, p.numel()) == lazy, name
+            if "stateembeds" in name:
+                assert (off, p.numel()) in spans, name                  # an embedding IS a span (its own step count)
+        assert all(lo % 4 == 0 and ln % 4 == 0 for lo, ln in spans)
+        assert all(a[0] + a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+        opt = FusedAdam(mod, lr=1e-3, lr_ranges=human_lr_ranges(mod) if isinstance(mod, Network) else None)
+        assert opt.lazy_spans == spans and opt.lazy_state.shape == (len(spans), 8)
+        got = sorted((off, n) for off, n, _ in opt.lr_ranges)
+        assert all(a[0] + a[1] <= b[0] for a, b in zip(got, got[1:]))
+        want = sum(n for _, n in mod.store.active_spans())
+        assert sum(n for _, n in got) == want                           # nothing lost, nothing twice
+        assert [got.index(sp) for sp in spans] == [i for i, k in enumerate(opt._range_lazy) if k is not None]
+    # the cutter itself
+    r, idx = _split_at_lazy([(0, 100, 1.0), (100, 60, 0.1)], [(8, 4), (96, 4), (120, 40)])
+    assert r == [(0, 8, 1.0), (8, 4, 1.0), (12, 84, 1.0), (96, 4, 1.0), (100, 20, 0.1), (120, 40, 0.1)] and idx == [None, 0, None, 1, None, 2]
+    with pytest.raises(ValueError):
+        _split_at_lazy([(0, 100, 1.0), (100, 60, 0.1)], [(98, 4)])      # a span may not straddle two learning rates
