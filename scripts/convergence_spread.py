@@ -55,6 +55,20 @@ def main():
         print(json.dumps({"stage": 2, "steps": 400, "lr_scale": 1.0, "fast_decay": 0, "psnr_hip_oracle": out, "hip_mean_sd": [st.mean(h), st.pstdev(h)],
                           "oracle_mean_sd": [st.mean(o), st.pstdev(o)], "mean_difference_db": st.mean(h) - st.mean(o)}), flush=True)
         return
+    if os.environ.get("MODE") == "stage2_regimes":
+        # candidate stage-2 regimes for the test: (steps, lr scale, patches per item), K pairs each
+        h0 = synth.human_state_dict(777, 2)
+        tc.S2_DECAY_STEPS = 1
+        for steps, scale, patches, ks in ((900, 0.3, 1, 3), (700, 0.2, 2, 2)):
+            tc.S2_PATCHES = patches
+            out = []
+            for k in range(ks):
+                r, _, _ = tc._train_stage2(scene, px, dev, perturbed(h0, k), steps, scale, oracle=True)
+                out.append((r["psnr_hip"], r["psnr_oracle"]))
+                torch.cuda.empty_cache()
+            print(json.dumps({"stage": 2, "steps": steps, "lr_scale": scale, "patches": patches, "fast_decay": 1, "psnr_hip_oracle": out,
+                              "abs_diff": [abs(a - b) for a, b in out]}), flush=True)
+        return
     if os.environ.get("MODE") == "pairs":
         # (HIP, oracle) pairs from the same perturbed initial weights: is there an OFFSET between the two paths beyond their spreads?
         b0, h0 = synth.background_state_dict(777, 2), synth.human_state_dict(777, 2)

@@ -52,6 +52,7 @@ S2_DECAY_STEPS = int(os.environ.get("HOS_CONV_S2_DECAY", "1"))     # > 0: the de
 # compressed into the run.  HIP / oracle pairs in the chosen regimes differ by 0.00-0.03 dB (stage 1) and 0.02-0.07 dB (stage 2)
 # (profiles/r06_convergence_pairs.jsonl); at the full stage-1 rate by +-0.12 dB in either direction, i.e. by the spread.
 S3_STEPS = int(os.environ.get("HOS_CONV_S3_STEPS", "150"))
+S2_PATCHES = int(os.environ.get("HOS_CONV_S2_PATCHES", "2"))
 S1_LR_SCALE = float(os.environ.get("HOS_CONV_S1_LR", "0.3"))
 S2_LR_SCALE = float(os.environ.get("HOS_CONV_S2_LR", "0.3"))
 HW = 96
@@ -176,7 +177,7 @@ def _train_stage1(rays, dev, sd0=None, steps=None, lr_scale=None, oracle=True):
 
 def _stage2_items(scene, px, dev, steps):
     from hosnerf_amd.dataset import SceneItems
-    ds = SceneItems(scene, px["images"], px["alphas"], px["flows"], n_patches=2, patch_size=32, sample_subject_ratio=0.8, device=dev,
+    ds = SceneItems(scene, px["images"], px["alphas"], px["flows"], n_patches=S2_PATCHES, patch_size=32, sample_subject_ratio=0.8, device=dev,
                     seed=9, stage=2)
     rs = np.random.RandomState(23)
     g = torch.Generator().manual_seed(23)
