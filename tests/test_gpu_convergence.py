@@ -50,7 +50,9 @@ S2_DECAY_STEPS = int(os.environ.get("HOS_CONV_S2_DECAY", "1"))     # > 0: the de
 # stage-1 rate (2e-3) the held-out PSNR of four runs spreads over 0.16 dB after 400 steps and 0.75 dB after 1200; at 0.3 x the rate
 # over 0.06 dB.  Stage 2: 0.27 dB at the full rate with the reference's (here: flat) decay, 0.03-0.08 dB at 0.3 x with the decay
 # compressed into the run.  HIP / oracle pairs in the chosen regimes differ by 0.00-0.03 dB (stage 1) and 0.02-0.07 dB (stage 2)
-# (profiles/r06_convergence_pairs.jsonl); at the full stage-1 rate by +-0.12 dB in either direction, i.e. by the spread.
+# (profiles/r06_convergence_pairs.jsonl); at the full stage-1 rate by +-0.12 dB in either direction, i.e. by the spread.  Longer,
+# slower or smaller-batch stage-2 regimes (900 steps x 1 patch, 700 steps at 0.2 x) do not narrow the stage-2 pairs further: 0.03-0.06 dB
+# (profiles/r06_convergence_stage2_regimes.jsonl); over all fourteen stage-2 pairs measured the largest difference is 0.07 dB.
 S3_STEPS = int(os.environ.get("HOS_CONV_S3_STEPS", "150"))
 S2_PATCHES = int(os.environ.get("HOS_CONV_S2_PATCHES", "2"))
 S1_LR_SCALE = float(os.environ.get("HOS_CONV_S1_LR", "0.3"))
