@@ -149,7 +149,7 @@ PROTOTYPES = {
     "hos_sumsq_blocks": [],
     "hos_sumsq_partials": [_I, _P, _P, _P, _P],
     "hos_adam_multi": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _F, _P, _P, _P],
-    "hos_adam_multi_lazy": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _F, _P, _P, _P],
+    "hos_adam_multi_lazy": [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _F, _P, _P, _P],
     "hos_adam_lazy_prepare": [_I, _P, _P, _P, _F, _F, _P, _P],
 }
 _RESTYPES = {"hos_error_string": c_char_p, "hos_mlp_bwd_ws_floats": c_int64, "hos_train_losses_workspace_floats": c_int64,

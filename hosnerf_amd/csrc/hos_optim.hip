@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const SumsqSpans t,
 struct AdamSpans {
     float* p[OPT_SPANS]; const float* g[OPT_SPANS]; float* m[OPT_SPANS]; float* v[OPT_SPANS];
     const float* hyper[OPT_SPANS];                       // device {lr, 1-b1^t, 1/sqrt(1-b2^t)} of the span, or NULL: the host values below
-    const float* lazy[OPT_SPANS];                        // device {t, active, 1-b1^t, 1/sqrt(1-b2^t)} of a lazily updated span (hos_adam_lazy_prepare), or NULL
+    const float* lazy[OPT_SPANS];                        // device {t, active, 1-b1^t, 1/sqrt(1-b2^t), ..} rows (8 floats each) of a lazily updated span, or NULL
+    int lazy_row4[OPT_SPANS];                            // 0: one state row for the span; else the span is ROWS of this many float4 with one state row each
     float lr[OPT_SPANS], bc1[OPT_SPANS], rsbc2[OPT_SPANS];
     long start4[OPT_SPANS + 1]; int count;
 };
@@ -143,8 +144,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamSpans t, floa
         float lr = t.lr[s], bc1 = t.bc1[s], rsbc2 = t.rsbc2[s];
         if (t.hyper[s] != nullptr) { lr = t.hyper[s][0]; bc1 = t.hyper[s][1]; rsbc2 = t.hyper[s][2]; }
         if (t.lazy[s] != nullptr) {          // torch.optim.Adam skips a parameter whose .grad is None and counts ITS steps only
-            if (t.lazy[s][1] == 0.f) continue;
-            bc1 = t.lazy[s][2]; rsbc2 = t.lazy[s][3];
+            const float* lz = t.lazy[s] + (t.lazy_row4[s] > 0 ? (j / t.lazy_row4[s]) * 8 : 0);
+            if (lz[1] == 0.f) continue;
+            bc1 = lz[2]; rsbc2 = lz[3];
         }
         float4* p4 = reinterpret_cast<float4*>(t.p[s]) + j;
         float4* m4 = reinterpret_cast<float4*>(t.m[s]) + j;
@@ -288,13 +290,15 @@ extern "C" int hos_sumsq_partials(int n, const float* const* g, const long long*
 extern "C" int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
                               const float* const* hyper, const float* lr, int step, float beta1, float beta2, float eps, float grad_scale,
                               const float* partial, float max_norm, const unsigned int* guard, unsigned int* skipped, hos_stream_t stream) {
-    return hos_adam_multi_lazy(n, p, g, m, v, count, hyper, nullptr, lr, step, beta1, beta2, eps, grad_scale, partial, max_norm, guard, skipped, stream);
+    return hos_adam_multi_lazy(n, p, g, m, v, count, hyper, nullptr, nullptr, lr, step, beta1, beta2, eps, grad_scale, partial, max_norm, guard, skipped, stream);
 }
 
 // hos_adam_multi with lazily updated spans: lazy[s] (NULL entries / NULL table: a plain span) = the span's state row written by
 // hos_adam_lazy_prepare earlier on the same stream: inactive -> the span is not touched; active -> its own bias corrections.
+// lazy_row[s] (NULL table / 0: one row for the whole span) > 0: the span consists of consecutive ROWS of lazy_row[s] floats (a
+// multiple of 4 that divides count[s]) with consecutive 8-float state rows -- the [n_states, 64] block of state embeddings is ONE span.
 extern "C" int hos_adam_multi_lazy(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
-                                   const float* const* hyper, const float* const* lazy, const float* lr, int step, float beta1, float beta2,
+                                   const float* const* hyper, const float* const* lazy, const int* lazy_row, const float* lr, int step, float beta1, float beta2,
                                    float eps, float grad_scale, const float* partial, float max_norm, const unsigned int* guard,
                                    unsigned int* skipped, hos_stream_t stream) {
     if (n <= 0 || n > OPT_SPANS || !p || !g || !m || !v || !count) return HOS_E_ARG;
@@ -309,6 +313,11 @@ extern "C" int hos_adam_multi_lazy(int n, float* const* p, const float* const* g
         if (!h && (!lr || step < 1)) return HOS_E_ARG;
         t.p[s] = p[s]; t.g[s] = g[s]; t.m[s] = m[s]; t.v[s] = v[s]; t.hyper[s] = h;
         t.lazy[s] = lazy ? lazy[s] : nullptr;
+        t.lazy_row4[s] = 0;
+        if (t.lazy[s] && lazy_row && lazy_row[s] > 0) {
+            if ((lazy_row[s] & 3) || count[s] % lazy_row[s]) return HOS_E_ALIGN;
+            t.lazy_row4[s] = lazy_row[s] >> 2;
+        }
         t.lr[s] = lr ? lr[s] : 0.f; t.bc1[s] = (float)bc1; t.rsbc2[s] = (float)(1.0 / sqrt(bc2));
         t.start4[s] = pos; pos += (long)(count[s] >> 2);
     }

@@ -1162,7 +1162,7 @@ def sumsq_partials(spans, partial: torch.Tensor):
 
 
 def adam_multi(spans, step: int, beta1: float, beta2: float, eps: float, grad_scale: float, partial, max_norm: float, guard=(None, None)):
-    """torch.optim.Adam over up to 32 spans in one launch.  spans: (p, g, m, v, hyper | None, lr[, lazy | None]) -- hyper: device [3] row
+    """torch.optim.Adam over up to 32 spans in one launch.  spans: (p, g, m, v, hyper | None, lr[, lazy | None[, row length]]) -- hyper: device [3] row
     {lr, 1-b1^t, 1/sqrt(1-b2^t)} (graph replay), else lr / `step` from the host; lazy: the span's [4] state row of `adam_lazy_prepare`
     (an identically-zero gradient = torch's `grad is None`: the span is skipped and counts its own steps).
     guard: (range word, skipped counter) or Nones."""
@@ -1170,8 +1170,9 @@ def adam_multi(spans, step: int, beta1: float, beta2: float, eps: float, grad_sc
     n = len(spans)
     col = lambda i: _table([ptr(sp[i]) for sp in spans])
     lazy = _table([ptr(sp[6]) if len(sp) > 6 else None for sp in spans]) if any(len(sp) > 6 and sp[6] is not None for sp in spans) else None
+    rows = _table([int(sp[7]) if len(sp) > 7 and sp[7] else 0 for sp in spans], ctypes.c_int) if lazy is not None else None
     call("hos_adam_multi_lazy", n, col(0), col(1), col(2), col(3), _table([sp[0].numel() for sp in spans], ctypes.c_longlong),
-         col(4), lazy, _table([float(sp[5]) for sp in spans], ctypes.c_float), int(step), float(beta1), float(beta2), float(eps),
+         col(4), lazy, rows, _table([float(sp[5]) for sp in spans], ctypes.c_float), int(step), float(beta1), float(beta2), float(eps),
          float(grad_scale), ptr(partial), float(max_norm), ptr(guard[0], torch.int32), ptr(guard[1], torch.int32))
 
 
@@ -1179,8 +1180,10 @@ def adam_lazy_prepare(grads, states, beta1: float, beta2: float, guard=None):
     """One launch: for every lazily updated span (grads[i]: its slice of the reduced flat gradient, states[i]: its [4] fp32 state row)
     decide active / inactive (gradient identically zero) and advance the span's own step count (hos_adam_lazy_prepare)."""
     import ctypes
-    call("hos_adam_lazy_prepare", len(grads), _table([ptr(g) for g in grads]), _table([g.numel() for g in grads], ctypes.c_longlong),
-         _table([ptr(s) for s in states]), float(beta1), float(beta2), ptr(guard, torch.int32))
+    for i in range(0, len(grads), 32):                     # (<= 32 spans per launch)
+        g_, s_ = grads[i:i + 32], states[i:i + 32]
+        call("hos_adam_lazy_prepare", len(g_), _table([ptr(g) for g in g_]), _table([g.numel() for g in g_], ctypes.c_longlong),
+             _table([ptr(s) for s in s_]), float(beta1), float(beta2), ptr(guard, torch.int32))
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, sumsq_buf=None, max_norm=0.0):

@@ -258,20 +258,38 @@ LAZY_ADAM = __import__("os").environ.get("HOS_LAZY_ADAM", "1") != "0"     # A/B 
 
 
 def _split_at_lazy(ranges, lazy_spans):
-    """Cut the learning-rate ranges [(off, n, mult)] at the lazily updated spans [(off, n)] (each inside one range, float4-aligned):
-    returns (ranges, lazy index of every range or None)."""
+    """Cut the learning-rate ranges [(off, n, mult)] at the lazily updated spans [(off, n)] (sorted; each inside one range, float4-
+    aligned).  A RUN of adjacent spans of equal length inside one range (the [n_states, 64] block of state embeddings) stays ONE range
+    with a row length: returns (ranges, per range None | (index of its first lazy span, number of rows, row length))."""
+    runs, i = [], 0
+    while i < len(lazy_spans):
+        lo, ln = lazy_spans[i]
+        k = 1
+        while i + k < len(lazy_spans) and lazy_spans[i + k] == (lo + k * ln, ln):
+            k += 1
+        runs.append((lo, ln, i, k))
+        i += k
     out, idx = [], []
     for off, n, mult in ranges:
         pos, end = off, off + n
-        for k, (lo, ln) in enumerate(lazy_spans):
-            if lo + ln <= pos or lo >= end:
+        pending = []
+        for lo, ln, first, k in runs:
+            if lo + k * ln <= pos or lo >= end:
                 continue
-            if lo < pos or lo + ln > end or lo % 4 or ln % 4:
+            if lo < pos or lo % 4 or ln % 4:
                 raise ValueError(f"lazy span ({lo}, {ln}) straddles a learning-rate range or is not float4-aligned")
+            if lo + k * ln > end:                          # a run may end with the range only on a span boundary
+                fit = (end - lo) // ln
+                if fit <= 0 or lo + fit * ln != end:
+                    raise ValueError(f"lazy span ({lo}, {ln}) straddles a learning-rate range or is not float4-aligned")
+                pending.append((lo + fit * ln, ln, first + fit, k - fit))
+                k = fit
             if lo > pos:
                 out.append((pos, lo - pos, mult)); idx.append(None)
-            out.append((lo, ln, mult)); idx.append(k)
-            pos = lo + ln
+            out.append((lo, k * ln, mult)); idx.append((first, k, ln))
+            pos = lo + k * ln
+        runs = [r for r in runs if not (off <= r[0] < end)] + pending
+        runs.sort()
         if pos < end:
             out.append((pos, end - pos, mult)); idx.append(None)
     return out, idx
@@ -437,7 +455,8 @@ def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
                 return False
             k = o._range_lazy[r] if o._range_lazy is not None else None
             spans.append((p[off:off + n], g[off:off + n], o.exp_avg[off:off + n], o.exp_avg_sq[off:off + n],
-                          o._hyper[r] if dynamic else None, float(l) * mult, None if k is None else o.lazy_state[k]))
+                          o._hyper[r] if dynamic else None, float(l) * mult, None if k is None else o.lazy_state[k[0]:k[0] + k[1]],
+                          0 if (k is None or k[1] == 1) else k[2]))
     if len(spans) > 32 or any(o.betas != opts[0].betas or o.eps != opts[0].eps for o in opts):
         return False
     partial = clip.partials(opts)
@@ -452,9 +471,15 @@ def _step_multi(opts, lrs, dynamic: bool, clear_guard: bool = True) -> bool:
             return False
     dev = spans[0][0].device
     guard = ops.range_guard_words(dev)       # with several ranks the word was MAX-reduced next to the gradients (allreduce_flat_grad)
-    lazy = [sp for sp in spans if sp[6] is not None]
-    if lazy:                                 # which lazily updated spans took part in this step (their reduced gradient is not all zero)
-        ops.adam_lazy_prepare([sp[1] for sp in lazy], [sp[6] for sp in lazy], opts[0].betas[0], opts[0].betas[1], guard[0])
+    lg, ls = [], []
+    for sp in spans:                         # one (gradient slice, state row) per lazily updated span -- a row-span contributes its rows
+        if sp[6] is not None:
+            rows = sp[6].shape[0]
+            rl = sp[1].numel() // rows
+            lg += [sp[1][i * rl:(i + 1) * rl] for i in range(rows)]
+            ls += [sp[6][i] for i in range(rows)]
+    if lg:                                   # which of them took part in this step (their reduced gradient is not all zero)
+        ops.adam_lazy_prepare(lg, ls, opts[0].betas[0], opts[0].betas[1], guard[0])
     if not clear_guard:                      # an earlier launch of a multi-launch step: skip on the word, leave it (and the count) alone
         guard = (guard[0], None)
     ops.adam_multi(spans, opts[0].step_count if not dynamic else 0, opts[0].betas[0], opts[0].betas[1], opts[0].eps, 1.0 / world,

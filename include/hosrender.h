@@ -690,11 +690,13 @@ int hos_adam_multi(int n, float* const* p, const float* const* g, float* const* 
  * {t, active, 1-beta1^t, 1/sqrt(1-beta2^t), 2 scratch words, 2 unused} (8 floats, zero-initialised once by the caller; spans
  * float4-aligned with count % 4 == 0) -- active = the span's gradient is not
  * identically zero (and the range-guard word, if given, is clear); then t += 1.  hos_adam_multi_lazy = hos_adam_multi with lazy[s]
- * (NULL: a plain span) = that row: an inactive span is not touched, an active one uses its own corrections. */
+ * (NULL: a plain span) = that row: an inactive span is not touched, an active one uses its own corrections.  lazy_row[s] > 0 (NULL
+ * table / 0: one row for the span): the span is consecutive ROWS of that many floats with consecutive 8-float state rows at lazy[s]
+ * (the [n_states, 64] block of state embeddings as ONE span, whatever the number of states). */
 int hos_adam_lazy_prepare(int n, const float* const* g, const long long* count, float* const* state, float beta1, float beta2,
                           const unsigned int* guard, hos_stream_t stream);
 int hos_adam_multi_lazy(int n, float* const* p, const float* const* g, float* const* m, float* const* v, const long long* count,
-                        const float* const* hyper, const float* const* lazy, const float* lr, int step, float beta1, float beta2,
+                        const float* const* hyper, const float* const* lazy, const int* lazy_row, const float* lr, int step, float beta1, float beta2,
                         float eps, float grad_scale, const float* partial, float max_norm, const unsigned int* guard,
                         unsigned int* skipped, hos_stream_t stream);
 

@@ -354,9 +354,21 @@ def test_lazy_spans_cover_exactly_the_parameters_that_can_be_without_a_gradient(
         assert all(a[0] + a[1] <= b[0] for a, b in zip(got, got[1:]))
         want = sum(n for _, n in mod.store.active_spans())
         assert sum(n for _, n in got) == want                           # nothing lost, nothing twice
-        assert [got.index(sp) for sp in spans] == [i for i, k in enumerate(opt._range_lazy) if k is not None]
-    # the cutter itself
-    r, idx = _split_at_lazy([(0, 100, 1.0), (100, 60, 0.1)], [(8, 4), (96, 4), (120, 40)])
-    assert r == [(0, 8, 1.0), (8, 4, 1.0), (12, 84, 1.0), (96, 4, 1.0), (100, 20, 0.1), (120, 40, 0.1)] and idx == [None, 0, None, 1, None, 2]
+        # every lazy span lies in exactly one lazy range, as row (k - first) of it; adjacent embeddings share ONE range (rows)
+        covered = []
+        for (off, n, _), k in zip(opt.lr_ranges, opt._range_lazy):
+            if k is not None:
+                first, rows, rl = k
+                assert n == rows * rl
+                covered += [(off + i * rl, rl) for i in range(rows)]
+                assert spans[first:first + rows] == covered[-rows:]
+        assert covered == spans
+        assert len(opt.lr_ranges) <= 8                                  # whatever the number of states
+    # the cutter itself: a run of adjacent equal spans stays one range with a row length
+    r, idx = _split_at_lazy([(0, 100, 1.0), (100, 60, 0.1)], [(8, 4), (12, 4), (96, 4), (120, 40)])
+    assert r == [(0, 8, 1.0), (8, 8, 1.0), (16, 80, 1.0), (96, 4, 1.0), (100, 20, 0.1), (120, 40, 0.1)]
+    assert idx == [None, (0, 2, 4), None, (2, 1, 4), None, (3, 1, 40)]
+    r, idx = _split_at_lazy([(0, 16, 1.0), (16, 16, 0.1)], [(8, 4), (12, 4), (16, 4)])       # a run cut by a learning-rate boundary
+    assert r == [(0, 8, 1.0), (8, 8, 1.0), (16, 4, 0.1), (20, 12, 0.1)] and idx == [None, (0, 2, 4), (2, 1, 4), None]
     with pytest.raises(ValueError):
         _split_at_lazy([(0, 100, 1.0), (100, 60, 0.1)], [(98, 4)])      # a span may not straddle two learning rates

@@ -220,7 +220,8 @@ def test_lit_hosnerf_clips_when_bound(dev):
     assert d > 1e-6, d
 
 
-def test_adam_skips_parameters_without_a_gradient_like_torch(dev):
+@pytest.mark.parametrize("n_states", [2, 4])
+def test_adam_skips_parameters_without_a_gradient_like_torch(dev, n_states):
     """Round 6 (found by tests/test_gpu_convergence.py): the reference's optimiser is torch.optim.Adam under Lightning, whose
     `zero_grad()` sets gradients to None (torch 2.0.1 default) -- a parameter that took no part in a step (the state embeddings of
     the states the step's frame is not in, M:224-296) is SKIPPED: no moment decay, no movement, and its bias corrections count its
@@ -230,14 +231,18 @@ def test_adam_skips_parameters_without_a_gradient_like_torch(dev):
     from hosnerf_amd.train import FusedAdam, stage1_loss
     LR_LAZY = 2e-4       # (2e-3 without the schedule's warm-up kills the 1024-wide MLP in two 64-ray steps: softplus' underflows to 0 everywhere)
     torch.manual_seed(0)
-    model = MipNeRF360(_basedir(), opaque_background=True)
-    model.load_state_dict(synth.background_state_dict(777, 2), strict=False)
+    d = tempfile.mkdtemp(prefix="hos_basedir_")
+    cuts = [0.4] if n_states == 2 else [0.25, 0.5, 0.75]
+    with open(os.path.join(d, "transitions_times.json"), "w") as f:
+        json.dump({f"f{i}": {"time": t} for i, t in enumerate(cuts)}, f)
+    model = MipNeRF360(d, opaque_background=True)
+    model.load_state_dict(synth.background_state_dict(777, n_states), strict=False)
     model = model.to(dev)
     opt = FusedAdam(model, lr=LR_LAZY, max_grad_norm=CLIP)
-    assert len(opt.lazy_spans) == 6
+    assert len(opt.lazy_spans) == 3 * n_states and len(opt.lr_ranges) == 6          # the embeddings of an MLP are ONE range of rows
     ref = {n: p.detach().clone().requires_grad_(True) for n, p in model.named_parameters()}
     topt = torch.optim.Adam(list(ref.values()), lr=LR_LAZY)
-    times = [0.2, 0.7, 0.7, 0.2, 0.7, 0.2]
+    times = [0.2, 0.7, 0.7, 0.2, 0.7, 0.2] if n_states == 2 else [0.1, 0.3, 0.6, 0.9, 0.3, 0.1]
     for i, t in enumerate(times):
         b = {k: v.to(dev) for k, v in synth.stage1_batch(64, seed=60 + i).items()}
         b["times"] = t
@@ -254,12 +259,12 @@ def test_adam_skips_parameters_without_a_gradient_like_torch(dev):
                 unused.append(n)
                 continue                                   # .grad stays None: torch skips it
             ref[n].grad = g
-        assert len(unused) == 3, (i, t, unused)            # one embedding per MLP belongs to the other state
+        assert len(unused) == 3 * (n_states - 1), (i, t, unused)            # per MLP every embedding but the frame's state
         torch.nn.utils.clip_grad_norm_([p for p in ref.values() if p.grad is not None], CLIP)
         topt.step()
         opt.step(LR_LAZY)
     torch.cuda.synchronize()
-    p0 = synth.background_state_dict(777, 2)
+    p0 = synth.background_state_dict(777, n_states)
     worst = 0.0
     for n, p in model.named_parameters():
         moved = float((ref[n].detach() - p0[n].to(dev)).abs().max()) if n in p0 else 0.0
@@ -271,4 +276,5 @@ def test_adam_skips_parameters_without_a_gradient_like_torch(dev):
     assert worst < 2e-3, worst                             # same gradients -> same steps, up to the norm's summation order
     # and the embeddings DID behave differently from an every-step update: their step counts are their own
     t_state = opt.lazy_state[:, 0].cpu().tolist()
-    assert sorted(set(t_state)) == [3.0] and opt.step_count == 6, (t_state, opt.step_count)
+    want = [3.0, 3.0] if n_states == 2 else [2.0, 2.0, 1.0, 1.0]
+    assert t_state == want * 3 and opt.step_count == 6, (t_state, opt.step_count)
