@@ -741,7 +741,12 @@ def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
     `human_weights_sorted`, so the numerator is unchanged, and the denominator sum(M) over the selected [B_fg, S, 1] block
     is S * sum_fg(M_ray).  No synchronisation, fixed shapes; the cycle set's row count may live on the device."""
     rgb = out["rgb"]
-    target = batch["target_rgbs"] if "target_rgbs" in batch else batch["target_patches"].reshape(-1, 3)
+    # The reference compares the plain reshape of the rendered rays with `target_patches` (M:1598-1602, `_unpack_imgs` M:41-50) -- NOT
+    # with `target_rgbs`.  The two differ where a patch leaves the subject's box: stage 3 keeps the patch whole ("to keep the patch size",
+    # core/data/human_nerf/train.py:322-330), a patch pixel outside the box is rendered by the PREVIOUS box ray (cumsum(ray_mask) - 1) and
+    # compared with the PATCH pixel's colour, while `target_rgbs` holds the colour of that substituted ray's own pixel.  (Round 6: this
+    # used `target_rgbs` when the item carried it -- found by tests/test_gpu_convergence.py on a frame whose patch crossed the box.)
+    target = batch["target_patches"].reshape(-1, 3) if "target_patches" in batch else batch["target_rgbs"]
     flow = "deform_pts_prev_final" in out and "ray_grid" in batch                 # time > 0.005 and training
     total, parts = ops.train_losses(
         rgb, target, batch.get("mse_const", 0.0), batch.get("mse_count"),

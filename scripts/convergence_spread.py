@@ -55,6 +55,20 @@ def main():
         print(json.dumps({"stage": 2, "steps": 400, "lr_scale": 1.0, "fast_decay": 0, "psnr_hip_oracle": out, "hip_mean_sd": [st.mean(h), st.pstdev(h)],
                           "oracle_mean_sd": [st.mean(o), st.pstdev(o)], "mean_difference_db": st.mean(h) - st.mean(o)}), flush=True)
         return
+    if os.environ.get("MODE") == "stage3_regimes":
+        # stage 3 warm-started from ONE pair of HIP-trained modules; (steps, lr scale), K (HIP, oracle) pairs from perturbed copies
+        _, bsd, m = tc._train_stage1(rays, dev, oracle=False)
+        del m
+        _, hsd, _ = tc._train_stage2(scene, px, dev, oracle=False)
+        torch.cuda.empty_cache()
+        for steps, scale, ks in ((150, 1.0, 4), (150, 0.3, 4), (300, 0.3, 3)):
+            out = []
+            for k in range(ks):
+                r = tc._train_stage3(scene, px, dev, perturbed(bsd, k), perturbed(hsd, k), steps, scale, oracle=True)
+                out.append((r["psnr_hip"], r["psnr_oracle"]))
+                torch.cuda.empty_cache()
+            print(json.dumps({"stage": 3, "steps": steps, "lr_scale": scale, "psnr_hip_oracle": out, "abs_diff": [abs(a - b) for a, b in out]}), flush=True)
+        return
     if os.environ.get("MODE") == "stage2_regimes":
         # candidate stage-2 regimes for the test: (steps, lr scale, patches per item), K pairs each
         h0 = synth.human_state_dict(777, 2)

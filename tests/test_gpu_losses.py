@@ -117,3 +117,31 @@ def test_losses_deterministic_and_scaled_upstream():
     assert abs(float(ref) - float(t2)) < 1e-6
     for a, b in ((rgb.grad, r2.grad), (pts.grad, p2.grad), (w.grad, w2.grad)):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-10
+
+
+def test_stage3_mse_is_against_target_patches_not_target_rgbs():
+    """M:1598-1602 + `_unpack_imgs` (M:41-50): stage 3 compares the plain reshape of the rendered rays with `target_patches`.  A patch that
+    leaves the subject's box keeps its size (core/data/human_nerf/train.py:322-330): its outside pixels are rendered by a substituted box
+    ray, so the item's `target_rgbs` (colour of that ray's own pixel) differs from `target_patches` there -- the loss must not use it."""
+    import oracle.losses as ol
+    from hosnerf_amd.train import stage3_losses
+    g = torch.Generator().manual_seed(5)
+    B = 2 * 16 * 16
+    rgb = torch.rand(B, 3, generator=g).to(DEV).requires_grad_(True)
+    patches = torch.rand(2, 16, 16, 3, generator=g).to(DEV)
+    rgbs = patches.reshape(-1, 3).clone()
+    rgbs[40:90] = torch.rand(50, 3, generator=g).to(DEV)                       # the substituted rays' own colours
+    obs = torch.randn(64, 3, generator=g).to(DEV)
+    dfm = (obs + 0.02).requires_grad_(True)
+    out = {"rgb": rgb, "idx_fg": torch.ones(B, dtype=torch.int32, device=DEV), "observe_pts": obs, "deform_pts_final": dfm}
+    batch = {"target_patches": patches, "target_rgbs": rgbs, "patch_masks": torch.ones(2, 16, 16, dtype=torch.bool, device=DEV),
+             "patch_div_indices": torch.tensor([0, 256, 512]), "bgcolor": torch.zeros(3, device=DEV), "mse_const": 0.0, "mse_count": float(patches.numel())}
+    total, parts = stage3_losses(out, batch)
+    total.backward()
+    r2, d2 = rgb.detach().clone().requires_grad_(True), dfm.detach().clone().requires_grad_(True)
+    ref, pref = ol.stage3_losses({"rgb": r2, "idx_fg": torch.ones(B, dtype=torch.bool, device=DEV), "observe_pts": obs, "deform_pts_final": d2}, batch, 0.0)
+    ref.backward()
+    assert abs(float(total) - float(ref)) < 1e-7 and abs(float(parts["mse"]) - float(pref["mse"])) < 1e-7
+    assert float((rgb.grad - r2.grad).abs().max()) <= 1e-6 * float(r2.grad.abs().max())
+    wrong = float(torch.mean((rgb.detach() - rgbs) ** 2))
+    assert abs(wrong - float(pref["mse"])) > 1e-4                               # the two targets do differ in this item
