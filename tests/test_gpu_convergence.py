@@ -9,8 +9,8 @@ sampling draws, learning-rate schedule and gradient clip --
       warm-up + log-linear decay at 0.3 x the reference's rate),
   (b) stage 2, 500 steps x two 32x32 patches cut by the subject's box (<= 2048 rays x 128 samples, flow + cycle terms; 0.3 x the
       reference's rates, its 0.1 ** (step / 500 k) decay compressed into the run),
-  (c) stage 3, 150 joint steps x 2048 rays warm-started from (a) and (b) as the reference's launcher does (S3/run.py:206-212), at the
-      reference's own rates (ONE Adam and ONE gradient norm over both modules),
+  (c) stage 3, 150 joint steps x 2048 rays warm-started from (a) and (b) as the reference's launcher does (S3/run.py:206-212), at 0.3 x
+      the reference's rates (ONE Adam and ONE gradient norm over both modules),
 once through the HIP path (`MipNeRF360` / `Network` + `FusedAdam`) and once through the reference's op graph as PyTorch-ROCm ops
 (`oracle.steps.stage1_trainer` / `stage2_trainer`: torch autograd + `clip_grad_norm_` + torch Adam).  Asserted: the PSNR on
 HELD-OUT frames agrees within 0.1 dB and the smoothed final losses agree.  Two fp32 trainings are two chaotic trajectories (the
@@ -19,6 +19,8 @@ and not asserted; the learning rates are those at which two trainings of the SAM
 constants below).  This test found a real difference in round 6: a flat Adam that updates parameters WITHOUT a gradient (the other
 state's embeddings) where torch's skips them -- +0.3 dB against the reference graph at stage 1's full rate, gone with the lazily
 updated spans of hos_adam_lazy_prepare (profiles/r06_convergence_pairs_before_lazy_adam.jsonl vs r06_convergence_pairs.jsonl).
+And a second one: the stage-3 MSE was taken against the item's `target_rgbs` where the reference takes `target_patches` (they differ
+where a patch leaves the subject's box) -- a systematic 0.06 dB, visible as ONE step at which the two NeRF-MLP trajectories parted.
 Then, on the HIP-TRAINED weights (sharper densities -> more empty proposal bins; larger pre-activations against the fp16-hi
 planes' +-65504): the full-size forward parity tables of tests/test_gpu_selfnoise.py again -- 1e-4 RGB L-inf on rays whose
 discrete decisions agree, flip counts within the multiple of the reference's own fp32-vs-fp32 noise -- for stage 1 and for
@@ -57,6 +59,10 @@ S3_STEPS = int(os.environ.get("HOS_CONV_S3_STEPS", "150"))
 S2_PATCHES = int(os.environ.get("HOS_CONV_S2_PATCHES", "2"))
 S1_LR_SCALE = float(os.environ.get("HOS_CONV_S1_LR", "0.3"))
 S2_LR_SCALE = float(os.environ.get("HOS_CONV_S2_LR", "0.3"))
+# Stage 3 (profiles/r06_convergence_stage3_pairs.jsonl): four pairs at 0.3 x the reference's rates differ by 0.001-0.009 dB, at the full
+# rates by 0.001-0.05 dB.  BEFORE the loss target was fixed (r06_convergence_stage3_pairs_before_target_fix.jsonl) the same pairs sat
+# 0.06-0.08 dB apart at 0.3 x -- with 0.01 dB of spread on either side: a systematic difference, traced to ONE step whose patch left the box.
+S3_LR_SCALE = float(os.environ.get("HOS_CONV_S3_LR", "0.3"))
 HW = 96
 N_FRAMES = 16
 HELD_OUT = (5, 11)
@@ -256,14 +262,14 @@ def _stage3_items(scene, px, dev, frames, n, seed, n_patches=2):
     return items
 
 
-def _train_stage3(scene, px, dev, bsd, hsd, steps=None, lr_scale=1.0, oracle=True):
+def _train_stage3(scene, px, dev, bsd, hsd, steps=None, lr_scale=None, oracle=True):
     """Stage 3 warm-started from the two trained modules (S3/run.py:206-212), `steps` joint steps (M:1501-1658: both renderers, merged
     composite, ONE Adam / ONE clip over both modules) through the HIP path and through the reference's op graph; held-out PSNR =
     the rays of eight 32x32 patches per held-out frame, training sampling with the SAME injected draws for both."""
     from hosnerf_amd.hosnerf import HOSNeRF
     from hosnerf_amd.human_nerf import default_cfg
     from hosnerf_amd.train import FusedAdam, GradClip, human_lr_decay, human_lr_ranges, train_step_stage3
-    LR = 6.667e-5 * lr_scale
+    LR = 6.667e-5 * (S3_LR_SCALE if lr_scale is None else lr_scale)
     steps = S3_STEPS if steps is None else steps
     cfg = default_cfg(par.basedir(TRANSITIONS))
     cfg.perturb = 1.0
@@ -365,9 +371,7 @@ def test_stage3_heldout_psnr_matches_the_reference_graph(trained):
     """BASELINE's metric config: the joint stage-3 step, warm-started from the trained stage-1 / stage-2 modules."""
     s = trained["s3"]
     assert abs(s["psnr_hip"] - s["psnr_oracle"]) <= 0.1, s
-    # (the training loss of 20 single-item steps carries the flow / cycle terms of those items on two slightly different weight sets:
-    # measured 3.7 % apart with the held-out PSNR 0.011 dB apart)
-    assert abs(s["loss_last20_mean"][0] - s["loss_last20_mean"][1]) <= 0.08 * abs(s["loss_last20_mean"][1]), s
+    assert abs(s["loss_last20_mean"][0] - s["loss_last20_mean"][1]) <= 0.03 * abs(s["loss_last20_mean"][1]), s
     assert abs(s["loss_first"][0] - s["loss_first"][1]) <= 2e-4 * abs(s["loss_first"][1]), s
 
 
