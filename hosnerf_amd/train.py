@@ -746,7 +746,10 @@ def stage3_losses(out: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor], 
     # core/data/human_nerf/train.py:322-330), a patch pixel outside the box is rendered by the PREVIOUS box ray (cumsum(ray_mask) - 1) and
     # compared with the PATCH pixel's colour, while `target_rgbs` holds the colour of that substituted ray's own pixel.  (Round 6: this
     # used `target_rgbs` when the item carried it -- found by tests/test_gpu_convergence.py on a frame whose patch crossed the box.)
-    target = batch["target_patches"].reshape(-1, 3) if "target_patches" in batch else batch["target_rgbs"]
+    # Items whose patches are CUT (the synthetic items of tests / bench sweeps, e.g. 512 rays of one 32 x 32 patch: not a stage-3 item of the
+    # reference, whose launcher path refuses them) keep the masked unpack of stage 2: their `target_rgbs` are the unmasked patch pixels.
+    tp = batch.get("target_patches")
+    target = tp.reshape(-1, 3) if (tp is not None and tp.numel() == rgb.numel()) else batch["target_rgbs"]
     flow = "deform_pts_prev_final" in out and "ray_grid" in batch                 # time > 0.005 and training
     total, parts = ops.train_losses(
         rgb, target, batch.get("mse_const", 0.0), batch.get("mse_count"),
