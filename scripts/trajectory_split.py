@@ -1,7 +1,7 @@
 """Bug-hunting companion of tests/test_gpu_convergence.py: train the HIP path and the reference's op graph side by side on the SAME items
 and draws and print, per step, how far selected parameters of the two have drifted apart.  Chaos grows that distance smoothly; a STEP
 at which it jumps marks an item on which the two compute a different gradient (this is how the stage-3 `target_patches` difference of
-round 6 was found: one step, one patch that left the subject's box).   python scripts/trajectory_split.py {1|2} [steps]"""
+round 6 was found: one step, one patch that left the subject's box).   python scripts/trajectory_split.py {1|2|3} [steps]"""
 import os, sys, tempfile, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle.steps as osteps
@@ -30,6 +30,31 @@ def main():
             lo = ora_step(b, lr, frac, [j.view(-1, 1) for j in jit])
             d = [float((params[n].detach() - p_ora[n].detach()).double().norm()) for n in watch]
             prev = report(step, b["times"], float(loss), float(lo), d, prev)
+    elif stage == 3:
+        from hosnerf_amd.hosnerf import HOSNeRF
+        from hosnerf_amd.human_nerf import default_cfg
+        from hosnerf_amd.train import FusedAdam, GradClip, human_lr_decay, human_lr_ranges, train_step_stage3
+        _, bsd, m = tc._train_stage1(rays, dev, oracle=False)
+        del m
+        _, hsd, _ = tc._train_stage2(scene, px, dev, oracle=False)
+        LR = 6.667e-5 * tc.S3_LR_SCALE
+        cfg = default_cfg(par.basedir(tc.TRANSITIONS)); cfg.perturb = 1.0
+        hos = HOSNeRF(cfg); hos.model.load_state_dict(bsd, strict=False); hos.human.load_state_dict(hsd, strict=True); hos = hos.to(dev)
+        clip = GradClip(osteps.GRAD_MAX_NORM)
+        o_b = FusedAdam(hos.model, lr=LR, clip=clip)
+        o_h = FusedAdam(hos.human, lr=LR, lr_ranges=human_lr_ranges(hos.human, LR, LR / 10.0), clip=clip)
+        pb, ph, ora_step = osteps.stage3_trainer(bsd, hsd, dev, LR, tc.TRANSITIONS)
+        train_frames = [i for i in range(tc.N_FRAMES) if i not in tc.HELD_OUT]
+        wb, wh = ["mlps.2.pts_linear.3.weight", "mlps.2.rgb_layer.weight"], ["cnl_mlp.pts_linears.4.weight", "non_rigid_mlp.block_mlps.4.weight", "pose_decoder.block_mlps.2.weight"]
+        pm, phm = dict(hos.model.named_parameters()), dict(hos.human.named_parameters())
+        for step, (it, t_rand, jit) in enumerate(tc._stage3_items(scene, px, dev, train_frames, steps, 41)):
+            decay = human_lr_decay(step)
+            batch = {k: v for k, v in it.items() if k not in tc.NET_DROP}
+            loss, _ = train_step_stage3(hos, o_b, o_h, batch, LR * decay, jitters=[j.to(dev) for j in jit], t_rand=t_rand)
+            lo = ora_step(it, t_rand, [j.view(-1, 1) for j in jit], decay)
+            d = [float((pm[n].detach() - pb[n].detach()).double().norm()) for n in wb] + \
+                [float((phm[n].detach().reshape(ph[n].shape) - ph[n].detach()).double().norm()) for n in wh]
+            prev = report(step, it["time"], float(loss), float(lo), d, prev)
     else:
         from hosnerf_amd.human_nerf import Network, default_cfg
         from hosnerf_amd.train import FusedAdam, human_lr_ranges, train_step_stage2
