@@ -454,7 +454,7 @@ def test_trained_weights_stage3_fullsize_parity(trained):
     jit = [torch.rand(B, generator=g) for _ in range(3)]
     pairs = par.stage3_tables(trained["bsd"], trained["hsd"], b, t_rand, jit, dev, transitions=TRANSITIONS)
     record("trained.stage3[2048 rays of a held-out frame, trained weights]", pairs)
-    par.assert_stage3(pairs)
+    par.assert_stage3(pairs, outliers=1)
 
 
 def test_trained_weights_whole_frame_evaluation_psnr(trained):
