@@ -2,7 +2,7 @@
 draws), overall and for the background model alone.  The background norms agree to 1e-4..1e-3; the overall norm -- dominated by the
 ill-conditioned pose-decoder / non-rigid head gradients of the human branch -- differs by up to a few per cent on some steps, and through the
 ONE shared clip coefficient that is what makes the two NeRF-MLP trajectories part (profiles/r06_stage3_clip_norm_hip_vs_oracle.txt).
-  python scripts/clip_norm_trace.py"""
+  python scripts/clip_norm_trace.py            (HUMAN_FP32=1: the same with the human network pinned to exact fp32 MFMA)"""
 import os, sys, json, tempfile, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import oracle.steps as osteps
@@ -17,6 +17,9 @@ _, hsd, _ = tc._train_stage2(scene, px, dev, oracle=False)
 LR = 6.667e-5 * 0.3
 cfg = default_cfg(par.basedir(tc.TRANSITIONS)); cfg.perturb = 1.0
 hos = HOSNeRF(cfg); hos.model.load_state_dict(bsd, strict=False); hos.human.load_state_dict(hsd, strict=True); hos = hos.to(dev)
+if os.environ.get("HUMAN_FP32") == "1":       # diagnosis: the human network's GEMMs on the exact fp32 MFMA (module-level arithmetic pin)
+    from hosnerf_amd import ops
+    hos.human.gemm_mode = ops.GEMM_FP32
 clip = GradClip(osteps.GRAD_MAX_NORM)
 o_b = FusedAdam(hos.model, lr=LR, clip=clip)
 o_h = FusedAdam(hos.human, lr=LR, lr_ranges=human_lr_ranges(hos.human, LR, LR / 10.0), clip=clip)
