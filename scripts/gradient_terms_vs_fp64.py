@@ -1,8 +1,8 @@
 """Which loss term carries the ill-conditioned part of the human network's gradient, and who is closer to float64?  One stage-3 item on
 trained weights; per loss term (MSE / flow / cycle alone) the gradient of selected parameters from the HIP path (human network pinned to
 exact fp32 MFMA, so that no 16-bit split is involved) against the oracle evaluated in fp32 AND in float64 on the same device.
-Round 6 result (profiles/r06_stage3_gradient_terms_vs_fp64.txt, two runs): on the cycle term any fp32 evaluation -- HIP or the
-reference's op graph -- is 0.4-1.5 % away from float64; the two fp32 evaluations are 0.004 % apart in one run and 2-5 % apart in the other.
+Round 6 result (profiles/r06_stage3_gradient_terms_vs_fp64.txt, two runs): on the cycle term the HIP path is 0.4-1.5 % away
+from float64 in both runs, the reference's op graph in fp32 0.7-1.5 % in one run (0.004 % from the HIP path) and 2-5 % in the other.
   python scripts/gradient_terms_vs_fp64.py"""
 import os, sys, json, tempfile, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
