@@ -993,6 +993,21 @@ def main():
                             "; arithmetic of this line: 3-product 16-bit split MFMA with fp32 accumulation (SURVEY 7.1's admissible mode), "
                             "the exact-fp32 MFMA companions are stages.stage3_fp32_exact / stage2_fp32_exact")),
         })
+        # BASELINE's metric also names "PSNR vs. reference": the held-out PSNR of the HIP path and of the reference's op graph trained side
+        # by side (tests/test_gpu_convergence.py) -- REPLAYED from the committed record of that test, not measured by this run
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06_parity_counts.json")) as f:
+                pc = json.load(f)
+            eq = {k.split(".")[1]: {"psnr_db_hip": pc[k]["psnr_hip"], "psnr_db_reference_graph": pc[k]["psnr_oracle"], "steps": pc[k]["steps"]}
+                  for k in ("convergence.stage1", "convergence.stage2", "convergence.stage3") if k in pc}
+            wf = pc.get("trained.stage3.whole_frame_eval[held-out frame, jointly trained weights]")
+            if wf:
+                eq["stage3_whole_frame_eval_same_weights"] = {"psnr_db_hip": wf["psnr_hip"], "psnr_db_reference_graph": wf["psnr_oracle"], "rgb_linf": wf["rgb_linf"]}
+            if eq:
+                out["psnr_vs_reference"] = dict(eq, source="profiles/r06_parity_counts.json (tests/test_gpu_convergence.py on a synthetic scene directory; "
+                                                             "replayed, not measured in this run; the Backpack sequence does not exist offline)")
+        except Exception:
+            pass
         if model_shard() > 1:
             out["metric"] += f" -- ONE-GPU TIMING MODEL of rank 0 of {model_shard()} with the sharded volume decoder, collectives replaced by identities"
             out["model_shard"] = model_shard()
